@@ -1,0 +1,97 @@
+"""The CPU oracle against the golden vectors made from the reference (tools/make_golden.py).
+fp32 both sides; differences are summation-order round-off only, hence the tight tolerance."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+RTOL, ATOL = 2e-4, 2e-5      # fp32 round-off through ~60 layers; logits are O(1)
+
+
+@pytest.mark.parametrize("name", list(G.FORWARD_CASES))
+def test_forward_matches_reference_golden(name, synth_sd):
+    c = G.FORWARD_CASES[name]
+    want = G.load("fwd_" + name)
+    sd = synth_sd(c["kind"], c["wseed"])
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    with torch.no_grad():
+        out, inter = O.forward(sd, grd, sat, c["kind"], c["circular"], c["ori_noise"],
+                               return_intermediates=True)
+    got = G.summarize_forward(out)
+    # arg-max pixel exact (north_star), and the orientation vector there
+    assert (got["top4_idx"][:, 0] == want["top4_idx"][:, 0]).all()
+    G.assert_close(got["logits_s4"], want["logits_s4"], RTOL, ATOL, "logits")
+    G.assert_close(got["top4_val"], want["top4_val"], RTOL, ATOL, "top4")
+    G.assert_close(got["heat_at_top4"], want["heat_at_top4"], 1e-3, 0, "heatmap@top4")
+    G.assert_close(got["heat_sum"], want["heat_sum"], 1e-5, 0, "heatmap sum")
+    G.assert_close(got["ori_at_argmax"], want["ori_at_argmax"], 1e-3, 1e-4, "ori@argmax")
+    # unit vectors: where the raw 2-vector is tiny the direction is ill-conditioned
+    G.assert_close(got["ori_s8"], want["ori_s8"], 0, 5e-3, "ori")
+    for i in range(1, 7):
+        assert got["score%d" % i].shape == want["score%d" % i].shape
+        G.assert_close(got["score%d" % i], want["score%d" % i], RTOL, 2e-6, "score%d" % i)
+        G.assert_close(got["score%d_mean" % i], want["score%d_mean" % i], RTOL, 2e-6, "mean")
+    G.assert_close(inter["grd_feature"][:, ::8].numpy(), want["grd_feature_c8"], RTOL, ATOL, "grd feat")
+    G.assert_close(inter["sat_feature"][:, ::8].numpy(), want["sat_feature_c8"], RTOL, ATOL, "sat feat")
+    for l in range(6):
+        G.assert_close(inter["grd_descriptors"][l].numpy(), want["grd_desc%d" % (l + 1)],
+                       RTOL, ATOL, "grd desc %d" % (l + 1))
+    for blk, t in zip(O.SKIP_BLOCKS, inter["sat_skips"]):
+        st = max(1, t.shape[-1] // 16)
+        G.assert_close(t[:, :, ::st, ::st].numpy(), want["sat_block%d_s" % blk], RTOL, ATOL, "skip")
+
+
+@pytest.mark.parametrize("circ", [True, False])
+def test_effnet_modules(circ, synth_sd):
+    want = G.load("effnet_modules_" + ("circ" if circ else "zero"))
+    sd = synth_sd("vigor", 0)
+    pfx = "grd_efficientnet" if circ else "sat_efficientnet"
+    with torch.no_grad():
+        x = synth.normal((2, 3, 32, 48), 4242)
+        got = O.swish(O.bn_eval(O.same_conv(x, sd[pfx + "._conv_stem.weight"], 3, 2, 224, circ),
+                                sd, pfx + "._bn0"))
+        G.assert_close(got.numpy(), want["stem"], 1e-5, 1e-5, "stem")
+        sched = 112
+        for i, (k, s, e, cin, cout) in enumerate(O.B0_BLOCKS):
+            if "block%d" % i in want:
+                xin = synth.normal((2, cin) + G.BLOCK_HW, 5000 + i)
+                got = O.mbconv(xin, sd, "%s._blocks.%d" % (pfx, i), k, s, e, cin, cout, sched, circ)
+                G.assert_close(got.numpy(), want["block%d" % i], 1e-5, 1e-5, "block%d" % i)
+            sched = -(-sched // s)
+        xin = synth.normal((2, 320, 5, 6), 6000)
+        got = O.swish(O.bn_eval(torch.nn.functional.conv2d(xin, sd[pfx + "._conv_head.weight"]),
+                                sd, pfx + "._bn1"))
+        G.assert_close(got.numpy(), want["head"], 1e-5, 1e-5, "head")
+
+
+def test_losses():
+    want = G.load("losses")
+    for n_cols in (1280, 20480):
+        sc = synth.uniform((3, n_cols), 8000 + n_cols, -1.0, 1.0)
+        lab = synth.uniform((3, n_cols), 8100 + n_cols) ** 6
+        G.assert_close(O.infonce_loss(sc, lab).numpy(), want["infonce_%d" % n_cols], 1e-5, 0, "infonce")
+    lg = synth.normal((3, 262144), 8200, 2.0)
+    lab = synth.uniform((3, 262144), 8201) ** 20
+    lab = lab / lab.sum(1, keepdim=True)
+    G.assert_close(O.cross_entropy_loss(lg, lab).numpy(), want["ce"], 1e-5, 0, "ce")
+    ori = torch.nn.functional.normalize(synth.normal((3, 2, 512, 512), 8300), dim=1)
+    gto = torch.nn.functional.normalize(synth.normal((3, 2, 512, 512), 8301), dim=1)
+    G.assert_close(O.orientation_loss(ori, gto, lab.reshape(3, 1, 512, 512)).numpy(), want["ori"],
+                   1e-5, 0, "ori loss")
+
+
+def test_synth_is_stable():
+    """The hash generator must give the same bits everywhere (fixtures depend on it)."""
+    u = synth.uniform((4,), 6)
+    h = synth.hash_u32(4, 1).tolist()
+    assert all(0 <= v < 2 ** 32 for v in h)
+    # pinned values (computed in the build container)
+    assert synth.hash_u32(3, 7).tolist() == PINNED_HASH
+    assert torch.equal(u, torch.tensor(PINNED_UNIFORM))
+
+
+PINNED_HASH = [4181168224, 2125990995, 531683462]
+PINNED_UNIFORM = [0.5901376008987427, 0.5631661415100098, 0.5688017010688782, 0.8550075888633728]
