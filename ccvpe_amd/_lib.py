@@ -1,0 +1,99 @@
+"""ctypes binding of libccvpe_hip.so (C ABI declared in include/ccvpe_hip.h).
+
+There is NO fallback: if the library is missing or a symbol is absent this raises, and every
+operator in ccvpe_amd.ops goes through it.  `import torch` must precede the load so that the
+library binds to the HIP runtime torch already mapped (same SONAME libamdhip64.so.7) — streams
+and device pointers are then shared with torch.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch  # noqa: F401  (must be imported before the HIP library is mapped)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libccvpe_hip.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+c_float_p = ctypes.c_void_p   # device pointers travel as integers
+c_int = ctypes.c_int
+c_float = ctypes.c_float
+c_void_p = ctypes.c_void_p
+
+
+class ConvDesc(ctypes.Structure):
+    """struct ccvpe_conv_desc (include/ccvpe_hip.h)."""
+    _fields_ = [
+        ("src0", c_void_p), ("src1", c_void_p), ("gate", c_void_p), ("w", c_void_p),
+        ("scale", c_void_p), ("shift", c_void_p), ("residual", c_void_p), ("dst", c_void_p),
+        ("c0", c_int), ("ld0", c_int), ("c1", c_int), ("ld1", c_int),
+        ("batch", c_int), ("in_h", c_int), ("in_w", c_int),
+        ("kh", c_int), ("kw", c_int), ("stride", c_int), ("pad", c_int),
+        ("n", c_int), ("kpad", c_int), ("ldd", c_int), ("ldres", c_int),
+        ("act", c_int), ("out_mode", c_int),
+    ]
+
+
+# name -> (restype, argtypes); must list EVERY symbol include/ccvpe_hip.h declares
+# (tests/test_abi.py parses the header and checks this table and the .so against it).
+PROTOTYPES = {
+    "ccvpe_last_error": (ctypes.c_char_p, []),
+    "ccvpe_abi_version": (c_int, []),
+    "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
+    "ccvpe_stem_conv_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "ccvpe_dwconv_nblk": (c_int, [c_int] * 4),
+    "ccvpe_dwconv_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
+    "ccvpe_se_gate_f32": (c_int, [c_void_p, c_int, c_float] + [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_ground_descriptor_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
+                                            c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ccvpe_match_level_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int),
+                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_void_p]),
+    "ccvpe_head_conv3x3_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ccvpe_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ccvpe_infonce_loss_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ccvpe_cross_entropy_loss_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "ccvpe_orientation_loss_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+}
+
+_lib = None
+
+
+def build(verbose=False):
+    """Compile libccvpe_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout)
+        print(res.stderr)
+    if res.returncode != 0:
+        raise RuntimeError("building libccvpe_hip.so failed (see output above)")
+    return LIB_PATH
+
+
+def load():
+    """Map the library and attach prototypes.  Raises if it is missing — no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            "libccvpe_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C ccvpe_amd/csrc`).  ccvpe_amd has no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class CcvpeError(RuntimeError):
+    pass
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().ccvpe_last_error()
+        raise CcvpeError("%s failed (%d): %s" % (what, status, msg.decode() if msg else "?"))

@@ -1,0 +1,269 @@
+// EfficientNet-B0 memory-bound operators: stem conv, depthwise conv (+BN+swish+SE squeeze), SE gate.
+// All HBM-bound (AI < 10 F/B): the design rules are coalesced 16-byte NHWC
+// accesses, one pass over the tensor, and every elementwise op fused into the producing kernel.
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// Stem: 3x3 stride-2 conv, NCHW image -> NHWC [.,32], folded BN + swish.
+// efficientnet_pytorch/model.py:181-182,289 ; padding utils.py:265-277 (zero), :341-353 (circular W)
+// One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, float* __restrict__ y,
+                                                        int B, int H, int W, int Ho, int Wo, int circular) {
+  __shared__ __attribute__((aligned(16))) float ws[27 * 32];
+  __shared__ float ssc[32], ssh[32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = w[i];
+  if (threadIdx.x < 32) {
+    ssc[threadIdx.x] = scale[threadIdx.x];
+    ssh[threadIdx.x] = shift[threadIdx.x];
+  }
+  __syncthreads();
+  const long total = (long)B * Ho * Wo;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int ox = (int)(idx % Wo);
+  const int oy = (int)((idx / Wo) % Ho);
+  const int b = (int)(idx / ((long)Wo * Ho));
+
+  float acc[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
+  const size_t plane = (size_t)H * W;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = 2 * oy + ky;  // pad before = 0
+    if (iy >= H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = 2 * ox + kx;
+      if (ix >= W) {
+        if (!circular) continue;
+        ix -= W;
+      }
+#pragma unroll
+      for (int ci = 0; ci < 3; ++ci) {
+        const float v = x[((size_t)(b * 3 + ci)) * plane + (size_t)iy * W + ix];
+        const float* wp = &ws[((ky * 3 + kx) * 3 + ci) * 32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+      }
+    }
+  }
+  f32x4* out = reinterpret_cast<f32x4*>(y + (size_t)idx * 32);
+#pragma unroll
+  for (int c4 = 0; c4 < 8; ++c4) {
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = c4 * 4 + j;
+      const float v = acc[c] * ssc[c] + ssh[c];
+      o[j] = v / (1.0f + expf(-v));
+    }
+    out[c4] = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise KxK, stride S, NHWC, folded BN + swish, + SE squeeze partial sums.
+// efficientnet_pytorch/model.py:70-73,108-110,114.
+// A thread owns 4 channels x a strip of TW=4 output columns and slides the input window through
+// registers (each input float4 is loaded once per strip row instead of once per tap).
+// Block = P strips x CGX channel groups; the per-channel sum of the block's outputs is written
+// to se_partial[b][blockIdx.x][c] (fixed order => bit-reproducible squeeze).
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_TW = 4;
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, float* __restrict__ y,
+                                                     float* __restrict__ se_partial, int H, int W, int C, int Ho,
+                                                     int Wo, int cgx, int P, int nblk, int circular) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;  // pad before (224-schedule SAME)
+  constexpr int NCOL = (DW_TW - 1) * S + K;
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [P][cgx] float4
+
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx;
+  const int pl = tid / cgx;
+  const int b = blockIdx.z;
+  const int cg = blockIdx.y * cgx + cgl;
+  const int c = cg * 4;
+  const int sxn = (Wo + DW_TW - 1) / DW_TW;
+  const int strip = blockIdx.x * P + pl;
+  const bool active = pl < P && strip < Ho * sxn && c < C;
+
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    const int oy = strip / sxn;
+    const int ox0 = (strip - oy * sxn) * DW_TW;
+    f32x4 acc[DW_TW];
+#pragma unroll
+    for (int t = 0; t < DW_TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (size_t)b * H * W * C + c;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S - PB + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 col[NCOL];
+#pragma unroll
+      for (int j = 0; j < NCOL; ++j) {
+        int ix = ox0 * S - PB + j;
+        bool ok = true;
+        if (circular) {
+          if (ix < 0) ix += W;
+          else if (ix >= W) ix -= W;
+          ok = (unsigned)ix < (unsigned)W;
+        } else {
+          ok = (unsigned)ix < (unsigned)W;
+        }
+        col[j] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(ky * K + kx) * C + c);
+#pragma unroll
+        for (int t = 0; t < DW_TW; ++t) acc[t] += col[t * S + kx] * wv;
+      }
+    }
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    float* yb = y + ((size_t)(b * Ho + oy) * Wo) * C + c;
+#pragma unroll
+    for (int t = 0; t < DW_TW; ++t) {
+      const int ox = ox0 + t;
+      if (ox < Wo) {
+        f32x4 v = acc[t] * sc + sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+        *reinterpret_cast<f32x4*>(yb + (size_t)ox * C) = v;
+        sum += v;
+      }
+    }
+  }
+  // block reduction over the P strips, fixed order
+  f32x4* red4 = reinterpret_cast<f32x4*>(red);
+  if (pl < P) red4[pl * cgx + cgl] = sum;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    f32x4 tot = red4[cgl];
+    for (int q = 1; q < P; ++q) tot += red4[q * cgx + cgl];
+    *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * nblk + blockIdx.x) * C + c) = tot;
+  }
+}
+
+static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* ychunks, int* nblk, int* Ho, int* Wo,
+                        int k) {
+  const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
+  *Ho = (H + total_pad - k) / stride + 1;
+  *Wo = (W + total_pad - k) / stride + 1;
+  const int cg = C / 4;
+  int yc = 1;
+  while (cg / yc > 256 || cg % yc) ++yc;
+  *ychunks = yc;
+  *cgx = cg / yc;
+  *P = 256 / *cgx;
+  const int sxn = (*Wo + DW_TW - 1) / DW_TW;
+  const int strips = *Ho * sxn;
+  *nblk = (strips + *P - 1) / *P;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SE gate (model.py:113-118): one workgroup per sample.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int nblk, float inv_hw,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int C, int Cs) {
+  extern __shared__ float sm[];  // mean[C] | z[Cs]
+  float* mean = sm;
+  float* z = sm + C;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    const float* p = part + (size_t)b * nblk * C + c;
+    float s = 0.f;
+    for (int q = 0; q < nblk; ++q) s += p[(size_t)q * C];
+    mean[c] = s * inv_hw;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int j = wave; j < Cs; j += 4) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)j * C + c], mean[c], s);
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float v = s + b1[j];
+      z[j] = v / (1.0f + expf(-v));
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float s = b2[c];
+    for (int j = 0; j < Cs; ++j) s = fmaf(w2[(size_t)c * Cs + j], z[j], s);
+    gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
+  }
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+extern "C" int ccvpe_stem_conv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                   int B, int H, int W, int circular, void* stream) {
+  if (B <= 0 || H < 3 || W < 3) return fail(CCVPE_EINVAL, "stem: bad shape");
+  if (!aligned16(y)) return fail(CCVPE_EINVAL, "stem: y must be 16-byte aligned");
+  const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
+  const long total = (long)B * Ho * Wo;
+  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
+                     scale, shift, y, B, H, W, Ho, Wo, circular);
+  return check_launch("stem_conv_kernel");
+}
+
+extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
+  // nblk does not depend on k for the SAME schedule (Ho = ceil-like of H/stride for both k)
+  int cgx, P, yc, nblk, Ho, Wo;
+  if (C <= 0 || C % 4) return CCVPE_EINVAL;
+  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, 3);
+  return nblk;
+}
+
+extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,
+                                void* stream) {
+  if (C <= 0 || C % 4) return fail(CCVPE_EINVAL, "dwconv: C %% 4 != 0");
+  if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "dwconv: k/stride unsupported");
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(se_partial) || !aligned16(scale) ||
+      !aligned16(shift))
+    return fail(CCVPE_EINVAL, "dwconv: pointers must be 16-byte aligned");
+  int cgx, P, yc, nblk, Ho, Wo;
+  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k);
+  if (circular && (k / 2 + 1 > W)) return fail(CCVPE_EINVAL, "dwconv: W too small for circular wrap");
+  dim3 grid(nblk, yc, B);
+  const size_t smem = (size_t)P * cgx * 16;
+  hipStream_t st = (hipStream_t)stream;
+#define DW_LAUNCH(K_, S_)                                                                                         \
+  hipLaunchKernelGGL((dwconv_kernel<K_, S_>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
+                     C, Ho, Wo, cgx, P, nblk, circular)
+  if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
+  else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);
+  else if (k == 5 && stride == 1) DW_LAUNCH(5, 1);
+  else DW_LAUNCH(5, 2);
+#undef DW_LAUNCH
+  return check_launch("dwconv_kernel");
+}
+
+extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, const float* w1, const float* b1,
+                                 const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
+  if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
+  const size_t smem = (size_t)(C + Cs) * sizeof(float);
+  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, part, nblk, inv_hw, w1, b1, w2, b2,
+                     gate, C, Cs);
+  return check_launch("se_gate_kernel");
+}

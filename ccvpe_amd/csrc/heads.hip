@@ -1,0 +1,301 @@
+// Small HBM/latency-bound ends of the path: ground-descriptor height collapse, the final 3x3 convs
+// to 1 / 2 channels (NCHW out, fused L2-normalise), the 262144-way softmax, and the three losses.
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------
+// D_l[b, x*Cd_l + c] = sum_y wh_l[y] * y1[b,y,x,off_l + c] + bh_l          (models.py:57-97)
+// ---------------------------------------------------------------------------------------------
+struct GdescCfg {
+  int cd[6];
+  int off[6];    // channel offset of level l inside y1
+  int obase[6];  // output offset of level l (= w * off[l])
+};
+
+__global__ __launch_bounds__(256) void gdesc_kernel(const float* __restrict__ y1, int ld, const float* __restrict__ wh,
+                                                    const float* __restrict__ bh, const GdescCfg cfg,
+                                                    float* __restrict__ out, int h, int w, int ctot) {
+  const int b = blockIdx.y;
+  const int o = blockIdx.x * 256 + threadIdx.x;
+  const int per_sample = w * ctot;
+  if (o >= per_sample) return;
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < 6; ++i)
+    if (o >= cfg.obase[i]) l = i;
+  const int rel = o - cfg.obase[l];
+  const int xx = rel / cfg.cd[l];
+  const int c = rel - xx * cfg.cd[l];
+  float s = 0.f;
+  for (int yy = 0; yy < h; ++yy)
+    s = fmaf(wh[l * h + yy], y1[((size_t)(b * h + yy) * w + xx) * ld + cfg.off[l] + c], s);
+  out[(size_t)b * per_sample + o] = s + bh[l];
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3 conv 16 -> COUT (1 or 2), pad 1, NHWC in, NCHW out, optional 2-vector normalise.
+// models.py:125-127 (conv1.2), :146-148 + :341 (conv1_ori.2 + F.normalize)
+// HBM-bound: 64 B read, 4-8 B written per pixel.  One thread per pixel, lanes along W.
+// ---------------------------------------------------------------------------------------------
+template <int COUT>
+__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ out,
+                                                        int H, int W, int normalize) {
+  __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 16];
+  for (int i = threadIdx.x; i < COUT * 9 * 16; i += 256) ws[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.z;
+  const int oy = blockIdx.y;
+  const int ox = blockIdx.x * 256 + threadIdx.x;
+  if (ox >= W) return;
+  float acc[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
+  const float* xb = x + (size_t)b * H * W * 16;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = oy + ky - 1;
+    if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ix = ox + kx - 1;
+      if ((unsigned)ix >= (unsigned)W) continue;
+      const f32x4* px = reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = px[q];
+#pragma unroll
+        for (int o = 0; o < COUT; ++o) {
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[((o * 3 + ky) * 3 + kx) * 16 + q * 4]);
+          acc[o] = fmaf(v[0], wv[0], acc[o]);
+          acc[o] = fmaf(v[1], wv[1], acc[o]);
+          acc[o] = fmaf(v[2], wv[2], acc[o]);
+          acc[o] = fmaf(v[3], wv[3], acc[o]);
+        }
+      }
+    }
+  }
+  if (COUT == 2 && normalize) {
+    const float n = fmaxf(sqrtf(acc[0] * acc[0] + acc[COUT - 1] * acc[COUT - 1]), 1e-12f);
+    acc[0] /= n;
+    acc[COUT - 1] /= n;
+  }
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) out[((size_t)(b * COUT + o) * H + oy) * W + ox] = acc[o];
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-wide reductions (1024 threads = 16 waves)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum(float v, float* sh) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sh[i];
+  return t;
+}
+__device__ __forceinline__ float block_max(float v, float* sh) {
+  v = wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) t = fmaxf(t, sh[i]);
+  return t;
+}
+
+// Softmax over a row (models.py:319-320).  One workgroup per row; the 1 MiB row stays L2-resident
+// between the three sweeps.
+__global__ __launch_bounds__(1024) void softmax_rows_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int n) {
+  __shared__ float sh[16];
+  const float* r = in + (size_t)blockIdx.x * n;
+  float* o = out + (size_t)blockIdx.x * n;
+  const int n4 = n >> 2;
+  const f32x4* r4 = reinterpret_cast<const f32x4*>(r);
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 v = r4[i];
+    m = fmaxf(fmaxf(m, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, r[i]);
+  m = block_max(m, sh);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 v = r4[i];
+    s += expf(v[0] - m) + expf(v[1] - m) + expf(v[2] - m) + expf(v[3] - m);
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) s += expf(r[i] - m);
+  s = block_sum(s, sh);
+  const float inv = 1.0f / s;
+  f32x4* o4 = reinterpret_cast<f32x4*>(o);
+  for (int i = threadIdx.x; i < n4; i += blockDim.x) {
+    const f32x4 v = r4[i];
+    f32x4 e;
+    e[0] = expf(v[0] - m) * inv; e[1] = expf(v[1] - m) * inv;
+    e[2] = expf(v[2] - m) * inv; e[3] = expf(v[3] - m) * inv;
+    o4[i] = e;
+  }
+  for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) o[i] = expf(r[i] - m) * inv;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Losses (losses.py).  Stage 1: one workgroup per sample writes partial (num, den); stage 2: one
+// wave combines them in fixed order.  masked_select is rewritten as a masked sum (graph-capturable).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void infonce_rows_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
+                                                            float inv_t, float* __restrict__ part, int n) {
+  __shared__ float sh[16];
+  const float* s = sc + (size_t)blockIdx.x * n;
+  const float* l = lab + (size_t)blockIdx.x * n;
+  float z = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) z += expf(s[i] * inv_t);   // losses.py:12,15
+  z = block_sum(z, sh);
+  const float logz = logf(z);
+  float num = 0.f, den = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float lv = l[i];
+    if (lv > 1e-2f) {                                                            // losses.py:13
+      num = fmaf(s[i] * inv_t - logz, lv, num);                                  // losses.py:16-17
+      den += lv;
+    }
+  }
+  num = block_sum(num, sh);
+  den = block_sum(den, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = num;
+    part[2 * blockIdx.x + 1] = den;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ce_rows_kernel(const float* __restrict__ lg, const float* __restrict__ lab,
+                                                       float* __restrict__ part, int n) {
+  __shared__ float sh[16];
+  const float* r = lg + (size_t)blockIdx.x * n;
+  const float* l = lab + (size_t)blockIdx.x * n;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, r[i]);
+  m = block_max(m, sh);
+  float z = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) z += expf(r[i] - m);
+  z = block_sum(z, sh);
+  const float logz = m + logf(z);
+  float num = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) num = fmaf(l[i], r[i] - logz, num);   // losses.py:24
+  num = block_sum(num, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = num;
+    part[2 * blockIdx.x + 1] = 0.f;
+  }
+}
+
+__global__ __launch_bounds__(1024) void ori_rows_kernel(const float* __restrict__ ori, const float* __restrict__ gto,
+                                                        const float* __restrict__ gt, float* __restrict__ part,
+                                                        int hw) {
+  __shared__ float sh[16];
+  const size_t b = blockIdx.x;
+  const float* o0 = ori + b * 2 * hw;
+  const float* g0 = gto + b * 2 * hw;
+  const float* w = gt + b * hw;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < hw; i += blockDim.x) {
+    const float d0 = g0[i] - o0[i], d1 = g0[hw + i] - o0[hw + i];
+    s = fmaf(d0 * d0 + d1 * d1, w[i], s);                                         // losses.py:29
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) {
+    part[2 * blockIdx.x] = s;
+    part[2 * blockIdx.x + 1] = 0.f;
+  }
+}
+
+// mode 0: -sum(num)/sum(den) ; mode 1: -sum(num)/B ; mode 2: +sum(num)/B
+__global__ void loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, int B, int mode) {
+  float num = 0.f, den = 0.f;
+  for (int i = threadIdx.x; i < B; i += 64) {
+    num += part[2 * i];
+    den += part[2 * i + 1];
+  }
+  num = wave_sum(num);
+  den = wave_sum(den);
+  if (threadIdx.x == 0) loss[0] = mode == 0 ? -num / den : (mode == 1 ? -num / (float)B : num / (float)B);
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+thread_local char ccvpe::g_err[512] = "";
+
+extern "C" const char* ccvpe_last_error(void) { return g_err; }
+extern "C" int ccvpe_abi_version(void) { return 1; }
+
+extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
+                                           float* out, int B, int h, int w, void* stream) {
+  if (!cd || B <= 0 || h <= 0 || w <= 0) return fail(CCVPE_EINVAL, "ground_descriptor: bad args");
+  GdescCfg cfg;
+  int off = 0;
+  for (int l = 0; l < 6; ++l) {
+    if (cd[l] <= 0) return fail(CCVPE_EINVAL, "ground_descriptor: cd[%d] <= 0", l);
+    cfg.cd[l] = cd[l];
+    cfg.off[l] = off;
+    cfg.obase[l] = w * off;
+    off += cd[l];
+  }
+  if (off > ld) return fail(CCVPE_EINVAL, "ground_descriptor: sum(cd) > ld");
+  dim3 grid((w * off + 255) / 256, B);
+  hipLaunchKernelGGL(gdesc_kernel, grid, dim3(256), 0, (hipStream_t)stream, y1, ld, wh, bh, cfg, out, h, w, off);
+  return check_launch("gdesc_kernel");
+}
+
+extern "C" int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, int B, int H,
+                                      int W, int cout, int normalize, void* stream) {
+  if (!aligned16(x)) return fail(CCVPE_EINVAL, "head_conv: x must be 16-byte aligned");
+  dim3 grid((W + 255) / 256, H, B);
+  if (cout == 1)
+    hipLaunchKernelGGL(head_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, 0);
+  else if (cout == 2)
+    hipLaunchKernelGGL(head_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, normalize);
+  else
+    return fail(CCVPE_EINVAL, "head_conv: cout must be 1 or 2");
+  return check_launch("head_conv_kernel");
+}
+
+extern "C" int ccvpe_softmax_rows_f32(const float* in, float* out, int rows, int n, void* stream) {
+  if (rows <= 0 || n <= 0) return fail(CCVPE_EINVAL, "softmax: bad shape");
+  if (!aligned16(in) || !aligned16(out) || (n % 4)) return fail(CCVPE_EINVAL, "softmax: 16-byte aligned rows required");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, in, out, n);
+  return check_launch("softmax_rows_kernel");
+}
+
+extern "C" int ccvpe_infonce_loss_f32(const float* scores, const float* labels, float temperature, float* loss,
+                                      float* scratch, int B, int n, void* stream) {
+  if (B <= 0 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(1024), 0, st, scores, labels, 1.0f / temperature, scratch, n);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, scratch, loss, B, 0);
+  return check_launch("infonce");
+}
+
+extern "C" int ccvpe_cross_entropy_loss_f32(const float* logits, const float* labels, float* loss, float* scratch,
+                                            int B, int n, void* stream) {
+  if (B <= 0 || n <= 0) return fail(CCVPE_EINVAL, "cross_entropy: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(B), dim3(1024), 0, st, logits, labels, scratch, n);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, scratch, loss, B, 1);
+  return check_launch("cross_entropy");
+}
+
+extern "C" int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const float* gt, float* loss,
+                                          float* scratch, int B, int hw, void* stream) {
+  if (B <= 0 || hw <= 0) return fail(CCVPE_EINVAL, "orientation_loss: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ori_rows_kernel, dim3(B), dim3(1024), 0, st, ori, gt_ori, gt, scratch, hw);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, scratch, loss, B, 2);
+  return check_launch("orientation_loss");
+}

@@ -1,0 +1,386 @@
+"""Drop-in model classes for the CCVPE dense cross-view matching path on MI355X.
+
+Mirrors the reference's module API for this path:
+    CVM_VIGOR(device, circular_padding)                       /root/reference/models.py:49-50
+    CVM_VIGOR_ori_prior(device, ori_noise, circular_padding)  /root/reference/models.py:346-347
+    CVM_KITTI(device)                                         /root/reference/models.py:655-656
+    forward(grd, sat) -> 9-tuple                              /root/reference/models.py:343,652,950
+with the same `state_dict()` keys, shapes and order (818 tensors), so checkpoints written by
+the reference's training scripts load strictly and vice versa.
+
+The modules only HOLD parameters (reference NCHW/OIHW fp32 layout).  On the first eval forward
+(and again whenever a parameter changed) they are re-packed once into the library's layouts —
+BN folded to scale/shift, conv weights to [N][tap][C] K-major rows, deconv weights to a
+[4*Cout][K] GEMM with the concat order this implementation uses — and every arithmetic step of
+forward() is a libccvpe_hip.so call (ccvpe_amd/ops.py).  There is no eager/CPU fallback.
+
+Scope this round: inference (eval-mode) forward.  Train-mode forward/backward (BN batch
+statistics, drop_connect, gradients) is not implemented yet and raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+from .synth import B0_BLOCKS, MODEL_SPECS, state_dict_spec, synthetic_state_dict
+
+BN_EPS = 1e-3                      # efficientnet_pytorch/utils.py:666
+SKIP_BLOCKS = (15, 10, 4, 2, 0)    # models.py:167-171 (decoder levels 6..2)
+MATCH_STRIDES = {"vigor": (64, 32, 16, 8, 4, 2),       # models.py:192,217,239,261,283,305
+                 "kitti": (128, 64, 32, 16, 8, 8)}     # models.py:794,818,841,864,887,910
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+class _Holder(nn.Module):
+    """Parameter container; gives the reference's dotted state_dict names."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder is not callable; use the owning CVM_* module")
+
+
+def _populate(root, kind, init):
+    for key, shape, role in state_dict_spec(kind):
+        parts = key.split(".")
+        node = root
+        for name in parts[:-1]:
+            child = node._modules.get(name)
+            if child is None:
+                child = _Holder()
+                node.add_module(name, child)
+            node = child
+        t = init[key].clone()
+        if role in ("bn_m", "bn_v", "bn_n"):
+            node.register_buffer(parts[-1], t)
+        else:
+            node.register_parameter(parts[-1], nn.Parameter(t))
+
+
+# ----------------------------------------------------------------------------------------
+# weight re-packing (runs once per weight version, on the device, with torch ops)
+# ----------------------------------------------------------------------------------------
+def _pad2(w, n_mult=16, k_mult=16):
+    n, k = w.shape
+    out = w.new_zeros((_round_up(n, n_mult), _round_up(k, k_mult)))
+    out[:n, :k] = w
+    return out.contiguous()
+
+
+def _pack_conv(w):
+    """OIHW -> [O][kh][kw][I] rows, zero-padded (N to 16, K to 16)."""
+    o = w.shape[0]
+    return _pad2(w.permute(0, 2, 3, 1).reshape(o, -1))
+
+
+def _fold_bn(sd, p):
+    scale = sd[p + ".weight"] / torch.sqrt(sd[p + ".running_var"] + BN_EPS)
+    shift = sd[p + ".bias"] - sd[p + ".running_mean"] * scale
+    return scale.contiguous(), shift.contiguous()
+
+
+class _Obj(object):
+    pass
+
+
+def _pack_encoder(sd, p):
+    e = _Obj()
+    e.stem_w = sd[p + "._conv_stem.weight"].permute(2, 3, 1, 0).contiguous()      # [ky][kx][ci][co]
+    e.stem_scale, e.stem_shift = _fold_bn(sd, p + "._bn0")
+    e.blocks = []
+    for i, (k, s, ex, cin, cout) in enumerate(B0_BLOCKS):
+        b = _Obj()
+        bp = "%s._blocks.%d" % (p, i)
+        b.k, b.s, b.expand, b.cin, b.cout, b.mid = k, s, ex != 1, cin, cout, cin * ex
+        if b.expand:
+            b.w_exp = _pack_conv(sd[bp + "._expand_conv.weight"])
+            b.s0, b.b0 = _fold_bn(sd, bp + "._bn0")
+        b.w_dw = sd[bp + "._depthwise_conv.weight"].reshape(b.mid, k, k).permute(1, 2, 0).contiguous()
+        b.s1, b.b1 = _fold_bn(sd, bp + "._bn1")
+        b.se_w1 = sd[bp + "._se_reduce.weight"].reshape(-1, b.mid).contiguous()
+        b.se_b1 = sd[bp + "._se_reduce.bias"].contiguous()
+        b.se_w2 = sd[bp + "._se_expand.weight"].reshape(b.mid, -1).contiguous()
+        b.se_b2 = sd[bp + "._se_expand.bias"].contiguous()
+        b.w_proj = _pack_conv(sd[bp + "._project_conv.weight"])
+        b.s2, b.b2 = _fold_bn(sd, bp + "._bn2")
+        b.skip = (s == 1 and cin == cout)                                          # model.py:126
+        e.blocks.append(b)
+    e.w_head = _pack_conv(sd[p + "._conv_head.weight"])
+    e.head_scale, e.head_shift = _fold_bn(sd, p + "._bn1")
+    return e
+
+
+def _pack_deconv(w, bias, col_map, ldo):
+    """ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM rows n=(dy*2+dx)*Cout+co over this
+    implementation's K order.  col_map: list of (dst_start, src_start, length)."""
+    cin, cout = w.shape[0], w.shape[1]
+    wg = w.permute(2, 3, 1, 0).reshape(4 * cout, cin)
+    out = w.new_zeros((4 * cout, ldo))
+    for d0, s0, n in col_map:
+        out[:, d0:d0 + n] = wg[:, s0:s0 + n]
+    return _pad2(out), bias.repeat(4).contiguous()
+
+
+def _pack_model(sd, kind, n_tail):
+    spec = MODEL_SPECS[kind]
+    pk = _Obj()
+    pk.grd = _pack_encoder(sd, "grd_efficientnet")
+    pk.sat = _pack_encoder(sd, "sat_efficientnet")
+    # six ground-descriptor heads fused into one 1x1 GEMM (N = sum Cd) + height collapse
+    ws, bs, wh, bh = [], [], [], []
+    for l in range(1, 7):
+        p = "grd_feature_to_descriptor%d" % l
+        ws.append(sd[p + ".0.weight"].reshape(-1, 1280))
+        bs.append(sd[p + ".0.bias"])
+        wh.append(sd[p + ".2.weight"].reshape(-1))
+        bh.append(sd[p + ".2.bias"].reshape(-1))
+    pk.gd_w = _pad2(torch.cat(ws, 0))
+    pk.gd_bias = torch.cat(bs, 0).contiguous()
+    pk.gd_n = pk.gd_bias.shape[0]
+    pk.gd_wh = torch.stack(wh, 0).contiguous()
+    pk.gd_bh = torch.cat(bh, 0).contiguous()
+    # aerial descriptor Linear(5120 -> N) == conv 2x2 stride 2 (models.py:102-104,173-184)
+    w = sd["sat_feature_to_descriptors.1.weight"]
+    pk.sd_w = _pack_conv(w.view(w.shape[0], 1280, 2, 2))
+    pk.sd_bias = sd["sat_feature_to_descriptors.1.bias"].contiguous()
+    pk.sd_n = w.shape[0]
+
+    pk.loc, pk.ori = [], []
+    n_rot = spec["n_rot"]
+    for j in range(6):
+        lvl = 6 - j
+        # ---- loc branch -------------------------------------------------------------------
+        dc_in, dc_out, c_in, c_out = spec["loc"][j]
+        c = dc_in - 1                                  # feature channels entering the level
+        ldo = _round_up(c + 1 + (n_tail if j == 0 else 0), 8)
+        lv = _Obj()
+        lv.c, lv.ldo, lv.up_n = c, ldo, 4 * dc_out
+        # reference concat order is [max, X]; ours is [X, max, (tail), pad]
+        lv.up_w, lv.up_b = _pack_deconv(sd["deconv%d.weight" % lvl], sd["deconv%d.bias" % lvl],
+                                        [(0, 1, c), (c, 0, 1)], ldo)
+        lv.c0, lv.c1 = dc_out, c_in - dc_out
+        lv.w_a = _pack_conv(sd["conv%d.0.weight" % lvl])
+        lv.b_a = sd["conv%d.0.bias" % lvl].contiguous()
+        lv.n_a = c_out
+        if lvl != 1:
+            lv.w_b = _pack_conv(sd["conv%d.2.weight" % lvl])
+            lv.n_b = c_out
+        else:
+            lv.w_b = sd["conv1.2.weight"].permute(0, 2, 3, 1).contiguous()      # [1][3][3][16]
+        lv.b_b = sd["conv%d.2.bias" % lvl].contiguous()
+        pk.loc.append(lv)
+        # ---- ori branch -------------------------------------------------------------------
+        dc_in, dc_out, c_in, c_out = spec["ori"][j]
+        ov = _Obj()
+        if j == 0:
+            c6 = dc_in - n_rot
+            ov.k = pk.loc[0].ldo
+            # reference order [scores(n_rot), X]; ours [X, max, scores, pad]
+            ov.up_w, ov.up_b = _pack_deconv(sd["deconv6_ori.weight"], sd["deconv6_ori.bias"],
+                                            [(0, n_rot, c6), (c6 + 1, 0, n_rot)], pk.loc[0].ldo)
+        else:
+            ov.k = dc_in
+            ov.up_w, ov.up_b = _pack_deconv(sd["deconv%d_ori.weight" % lvl], sd["deconv%d_ori.bias" % lvl],
+                                            [(0, 0, dc_in)], dc_in)
+        ov.up_n = 4 * dc_out
+        ov.c0, ov.c1 = dc_out, c_in - dc_out
+        ov.w_a = _pack_conv(sd["conv%d_ori.0.weight" % lvl])
+        ov.b_a = sd["conv%d_ori.0.bias" % lvl].contiguous()
+        ov.n_a = c_out
+        if lvl != 1:
+            ov.w_b = _pack_conv(sd["conv%d_ori.2.weight" % lvl])
+            ov.n_b = c_out
+        else:
+            ov.w_b = sd["conv1_ori.2.weight"].permute(0, 2, 3, 1).contiguous()  # [2][3][3][16]
+        ov.b_b = sd["conv%d_ori.2.bias" % lvl].contiguous()
+        pk.ori.append(ov)
+    return pk
+
+
+# ----------------------------------------------------------------------------------------
+# forward building blocks (every line below enqueues HIP kernels through the C ABI)
+# ----------------------------------------------------------------------------------------
+def _run_encoder(e, img, circular, multiscale):
+    """EfficientNet.extract_features[_multiscale] (efficientnet_pytorch/model.py:278-326)."""
+    x = ops.stem_conv(img, e.stem_w, e.stem_scale, e.stem_shift, circular)
+    feats = []
+    for blk in e.blocks:
+        b, h, w, _ = x.shape
+        t = x
+        if blk.expand:
+            t = ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w,
+                               scale=blk.s0, shift=blk.b0, act=ops.ACT_SWISH)
+        u, part = ops.dwconv(t, blk.w_dw, blk.s1, blk.b1, blk.k, blk.s, circular)
+        ho, wo = u.shape[1], u.shape[2]
+        gate = ops.se_gate(part, ho * wo, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        x = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate,
+                           scale=blk.s2, shift=blk.b2, residual=x if blk.skip else None)
+        if multiscale:
+            feats.append(x)
+    b, h, w, _ = x.shape
+    f = ops.conv_igemm(x, 320, e.w_head, 1280, batch=b, in_h=h, in_w=w, scale=e.head_scale,
+                       shift=e.head_shift, act=ops.ACT_SWISH)
+    return f, feats
+
+
+def _double_conv(lv, up, skip, batch, hw):
+    """deconv output (+ skip, read as a second source: the cat is never materialised) ->
+    3x3 + ReLU -> 3x3   (models.py:42-47,208-209)."""
+    y = ops.conv_igemm(up, lv.c0, lv.w_a, lv.n_a, batch=batch, in_h=hw, in_w=hw, kh=3, kw=3, pad=1,
+                       src1=skip, c1=lv.c1, shift=lv.b_a, act=ops.ACT_RELU)
+    return y
+
+
+_INIT_CACHE = {}
+
+
+class _CVMBase(nn.Module):
+    kind = "vigor"
+
+    def __init__(self, device, circular_padding, ori_noise=None):
+        super().__init__()
+        self.device = device                     # stored, never used (models.py:52)
+        self.circular_padding = circular_padding
+        self.ori_noise = ori_noise
+        # No network: instead of ImageNet-pretrained EfficientNet weights (utils.py:747) the
+        # parameters start from the deterministic synthetic init; load_state_dict() a checkpoint.
+        if self.kind not in _INIT_CACHE:
+            _INIT_CACHE[self.kind] = synthetic_state_dict(self.kind, 0)
+        _populate(self, self.kind, _INIT_CACHE[self.kind])
+        self._pack_cache = None
+        self._pack_key = None
+
+    # -- weight version tracking -------------------------------------------------------------
+    def _weights_key(self):
+        key = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            key.append((t.data_ptr(), t._version))
+        return tuple(key)
+
+    def _packed(self):
+        key = self._weights_key()
+        if self._pack_cache is None or key != self._pack_key:
+            sd = {k: v.detach() for k, v in self.state_dict().items()}
+            dev = next(self.parameters()).device
+            if dev.type != "cuda":
+                raise RuntimeError("ccvpe_amd: move the model to the MI355X first (.to('cuda'))")
+            n_tail = MODEL_SPECS[self.kind]["n_rot"]
+            with torch.no_grad():
+                self._pack_cache = _pack_model(sd, self.kind, n_tail)
+            self._pack_key = key
+        return self._pack_cache
+
+    def _loc_shifts(self):
+        n_rot = MODEL_SPECS[self.kind]["n_rot"]
+        if self.ori_noise is None:
+            return list(range(n_rot))                                   # models.py:191
+        k = int(self.ori_noise / 18)                                    # models.py:489
+        return list(range(-k, k + 1))
+
+    def forward(self, grd, sat):
+        if self.training:
+            raise NotImplementedError(
+                "ccvpe_amd: train-mode forward/backward is not implemented yet (eval() first); "
+                "there is deliberately no eager fallback")
+        if not (grd.is_cuda and sat.is_cuda):
+            raise RuntimeError("ccvpe_amd runs on the MI355X only: inputs must be device tensors")
+        spec = MODEL_SPECS[self.kind]
+        n_rot = spec["n_rot"]
+        strides = MATCH_STRIDES[self.kind]
+        circular = bool(self.circular_padding) and self.kind != "kitti"   # models.py:660
+        with torch.no_grad():
+            pk = self._packed()
+            grd = grd.contiguous().float()
+            sat = sat.contiguous().float()
+            batch = grd.shape[0]
+
+            # encoders + descriptors (models.py:151-184)
+            gfeat, _ = _run_encoder(pk.grd, grd, circular, False)
+            _, gh, gw, _ = gfeat.shape
+            if gh != spec["grd_h"]:
+                raise ValueError("ground feature height %d != %d expected by the descriptor heads"
+                                 % (gh, spec["grd_h"]))
+            y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw,
+                                shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4))
+            gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
+            svol, sfeats = _run_encoder(pk.sat, sat, False, True)
+            sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
+                                   in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
+
+            loc_shifts = self._loc_shifts()
+            scores_out = []
+            x = sdesc
+            cat6 = None
+            goff = 0
+            for j in range(6):
+                lv = pk.loc[j]
+                hw = x.shape[1]
+                cd = spec["cd"][j]
+                L = gw * cd
+                g = gdesc[:, goff:goff + L]
+                goff += L
+                if j == 0:
+                    if self.ori_noise is None:
+                        shifts, n_max = list(range(n_rot)), n_rot
+                    else:     # ori_prior recomputes the full volume for the ori decoder (:501-511)
+                        shifts, n_max = loc_shifts + list(range(n_rot)), len(loc_shifts)
+                    n_tail = n_rot
+                else:
+                    shifts, n_max, n_tail = loc_shifts, len(loc_shifts), 0
+                sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c)
+                if j == 0:
+                    cat6 = cat
+                    scores_out.append(sc if self.ori_noise is None else sc[:, n_max:])
+                else:
+                    scores_out.append(sc)
+                up = ops.conv_igemm(cat, lv.ldo, lv.up_w, lv.up_n, batch=batch, in_h=hw, in_w=hw,
+                                    shift=lv.up_b, out_mode=ops.OUT_DECONV2X)
+                skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+                y = _double_conv(lv, up, skip, batch, 2 * hw)
+                if j < 5:
+                    x = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
+                                       kh=3, kw=3, pad=1, shift=lv.b_b)
+                else:
+                    logits_map = ops.head_conv3x3(y, lv.w_b, lv.b_b, 1, False)      # [B,1,512,512]
+            logits = logits_map.reshape(batch, -1)                                   # models.py:319
+            heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)             # models.py:320
+
+            # orientation decoder (models.py:323-341)
+            xo = cat6
+            for j in range(6):
+                ov = pk.ori[j]
+                hw = xo.shape[1]
+                up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
+                                    shift=ov.up_b, out_mode=ops.OUT_DECONV2X)
+                skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+                y = _double_conv(ov, up, skip, batch, 2 * hw)
+                if j < 5:
+                    xo = ops.conv_igemm(y, ov.n_a, ov.w_b, ov.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
+                                        kh=3, kw=3, pad=1, shift=ov.b_b)
+                else:
+                    x_ori = ops.head_conv3x3(y, ov.w_b, ov.b_b, 2, True)            # + F.normalize (:341)
+        return (logits, heatmap, x_ori) + tuple(scores_out)
+
+
+class CVM_VIGOR(_CVMBase):
+    """models.py:49-343 — training-time VIGOR model, 20 rotation hypotheses at every level."""
+    kind = "vigor"
+
+    def __init__(self, device, circular_padding):
+        super().__init__(device, circular_padding, None)
+
+
+class CVM_VIGOR_ori_prior(_CVMBase):
+    """models.py:346-652 — test-time VIGOR model with an orientation prior of +-ori_noise deg."""
+    kind = "vigor"
+
+    def __init__(self, device, ori_noise, circular_padding=True):
+        super().__init__(device, circular_padding, ori_noise)
+
+
+class CVM_KITTI(_CVMBase):
+    """models.py:655-950 — KITTI model: 16 hypotheses, 2048-d aerial descriptor, no circular pad."""
+    kind = "kitti"
+
+    def __init__(self, device):
+        super().__init__(device, False, None)

@@ -1,0 +1,203 @@
+"""Python-side operator layer: torch tensors in, C-ABI calls out (include/ccvpe_hip.h).
+
+Each function enqueues exactly one library call on torch's current HIP stream.  torch is used
+for device memory and streams only; every arithmetic step runs in libccvpe_hip.so.  No
+function here has a CPU or eager fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+OUT_NHWC, OUT_DECONV2X = 0, 1
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(t, name):
+    if t is None:
+        return
+    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous fp32 device tensor (got %s %s contiguous=%s)" % (
+            name, t.device, t.dtype, t.is_contiguous()))
+
+
+def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0,
+               src1=None, c1=0, gate=None, scale=None, shift=None, residual=None, act=ACT_NONE,
+               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None):
+    """Implicit-GEMM conv / deconv / linear (ccvpe_conv_igemm_f32).  src tensors are NHWC."""
+    lib = _lib.load()
+    for t, nm in ((src0, "src0"), (src1, "src1"), (gate, "gate"), (w_packed, "w"), (scale, "scale"),
+                  (shift, "shift"), (residual, "residual"), (dst, "dst")):
+        _chk(t, nm)
+    ld0 = ld0 if ld0 is not None else src0.shape[-1]
+    ld1 = ld1 if ld1 is not None else (src1.shape[-1] if src1 is not None else 0)
+    ho = (in_h + 2 * pad - kh) // stride + 1
+    wo = (in_w + 2 * pad - kw) // stride + 1
+    if out_mode == OUT_DECONV2X:
+        cout = n // 4
+        oshape = (batch, 2 * ho, 2 * wo)
+    else:
+        cout = n
+        oshape = (batch, ho, wo)
+    if dst is None:
+        ldd = ldd if ldd is not None else cout
+        dst = torch.empty(oshape + (ldd,), device=src0.device, dtype=torch.float32)
+    elif ldd is None:
+        ldd = dst.shape[-1]
+    d = ConvDesc()
+    d.src0, d.src1, d.gate, d.w = _ptr(src0), _ptr(src1), _ptr(gate), _ptr(w_packed)
+    d.scale, d.shift, d.residual, d.dst = _ptr(scale), _ptr(shift), _ptr(residual), _ptr(dst)
+    d.c0, d.ld0, d.c1, d.ld1 = c0, ld0, c1, ld1
+    d.batch, d.in_h, d.in_w = batch, in_h, in_w
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.n, d.kpad = n, w_packed.shape[1]
+    d.ldd = ldd
+    d.ldres = residual.shape[-1] if residual is not None else 0
+    d.act, d.out_mode = act, out_mode
+    check(lib.ccvpe_conv_igemm_f32(ctypes.byref(d), _stream()), "ccvpe_conv_igemm_f32")
+    return dst
+
+
+def stem_conv(x_nchw, w, scale, shift, circular):
+    lib = _lib.load()
+    for t, nm in ((x_nchw, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):
+        _chk(t, nm)
+    b, c, h, wd = x_nchw.shape
+    if c != 3:
+        raise ValueError("stem expects 3 input channels")
+    ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
+    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=torch.float32)
+    check(lib.ccvpe_stem_conv_f32(_ptr(x_nchw), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), b, h, wd,
+                                  int(bool(circular)), _stream()), "ccvpe_stem_conv_f32")
+    return y
+
+
+def dwconv(x, w, scale, shift, k, stride, circular):
+    """Depthwise conv + BN + swish; returns (y, se_partial [B,nblk,C])."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):
+        _chk(t, nm)
+    b, h, wd, c = x.shape
+    tot = (k - 1) if stride == 1 else (k - 2)
+    ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
+    nblk = lib.ccvpe_dwconv_nblk(h, wd, c, stride)
+    if nblk <= 0:
+        raise _lib.CcvpeError("ccvpe_dwconv_nblk rejected shape %s" % (tuple(x.shape),))
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    part = torch.empty((b, nblk, c), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_dwconv_f32(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), _ptr(part), b, h, wd, c,
+                               k, stride, int(bool(circular)), _stream()), "ccvpe_dwconv_f32")
+    return y, part
+
+
+def se_gate(part, hw, w1, b1, w2, b2):
+    lib = _lib.load()
+    for t, nm in ((part, "part"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):
+        _chk(t, nm)
+    b, nblk, c = part.shape
+    cs = w1.shape[0]
+    gate = torch.empty((b, c), device=part.device, dtype=torch.float32)
+    check(lib.ccvpe_se_gate_f32(_ptr(part), nblk, 1.0 / float(hw), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
+                                _ptr(gate), b, c, cs, _stream()), "ccvpe_se_gate_f32")
+    return gate
+
+
+def ground_descriptor(y1, wh, bh, cd):
+    lib = _lib.load()
+    for t, nm in ((y1, "y1"), (wh, "wh"), (bh, "bh")):
+        _chk(t, nm)
+    b, h, w, ld = y1.shape
+    cd_arr = (ctypes.c_int * 6)(*cd)
+    out = torch.empty((b, w * sum(cd)), device=y1.device, dtype=torch.float32)
+    check(lib.ccvpe_ground_descriptor_f32(_ptr(y1), ld, _ptr(wh), _ptr(bh), cd_arr, _ptr(out), b, h, w,
+                                          _stream()), "ccvpe_ground_descriptor_f32")
+    return out
+
+
+def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None):
+    """Fused rotational matching.  x [B,H,W,ldx]; g [B,ldg] view with row stride ldg.
+    Returns (scores [B,n_shifts,H,W], dstx [B,H,W,ldo])."""
+    lib = _lib.load()
+    _chk(x, "x")
+    if not g.is_cuda or g.dtype != torch.float32 or g.stride(-1) != 1:
+        raise ValueError("g must be an fp32 device tensor with unit inner stride")
+    b, h, w, ldx = x.shape
+    c = channels if channels is not None else ldx
+    n = len(shifts)
+    sh = (ctypes.c_int * n)(*shifts)
+    scores = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
+    dstx = torch.empty((b, h, w, ldo), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_match_level_f32(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride,
+                                    _ptr(scores), _ptr(dstx), ldo, b, h * w, c, _stream()),
+          "ccvpe_match_level_f32")
+    return scores, dstx
+
+
+def head_conv3x3(x, w, bias, cout, normalize):
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w, "w"), (bias, "bias")):
+        _chk(t, nm)
+    b, h, wd, c = x.shape
+    if c != 16:
+        raise ValueError("head conv expects 16 input channels")
+    out = torch.empty((b, cout, h, wd), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_head_conv3x3_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), b, h, wd, cout,
+                                     int(bool(normalize)), _stream()), "ccvpe_head_conv3x3_f32")
+    return out
+
+
+def softmax_rows(logits):
+    lib = _lib.load()
+    _chk(logits, "logits")
+    rows, n = logits.shape
+    out = torch.empty_like(logits)
+    check(lib.ccvpe_softmax_rows_f32(_ptr(logits), _ptr(out), rows, n, _stream()), "ccvpe_softmax_rows_f32")
+    return out
+
+
+def _loss_common(fn, name, tensors, extra):
+    lib = _lib.load()
+    for i, t in enumerate(tensors):
+        _chk(t, "%s arg %d" % (name, i))
+    b = tensors[0].shape[0]
+    loss = torch.empty((1,), device=tensors[0].device, dtype=torch.float32)
+    scratch = torch.empty((2 * b,), device=tensors[0].device, dtype=torch.float32)
+    return lib, loss, scratch, b
+
+
+def infonce_loss(scores, labels, temperature=0.1):
+    """losses.py:4 infoNCELoss — forward value only (device scalar)."""
+    lib, loss, scratch, b = _loss_common(None, "infonce", (scores, labels), None)
+    n = scores.shape[1]
+    check(lib.ccvpe_infonce_loss_f32(_ptr(scores), _ptr(labels), float(temperature), _ptr(loss), _ptr(scratch),
+                                     b, n, _stream()), "ccvpe_infonce_loss_f32")
+    return loss[0]
+
+
+def cross_entropy_loss(logits, labels):
+    """losses.py:23 cross_entropy_loss — forward value only."""
+    lib, loss, scratch, b = _loss_common(None, "ce", (logits, labels), None)
+    check(lib.ccvpe_cross_entropy_loss_f32(_ptr(logits), _ptr(labels), _ptr(loss), _ptr(scratch), b,
+                                           logits.shape[1], _stream()), "ccvpe_cross_entropy_loss_f32")
+    return loss[0]
+
+
+def orientation_loss(ori, gt_orientation, gt):
+    """losses.py:28 orientation_loss — forward value only.  ori/gt_orientation [B,2,H,W], gt [B,1,H,W]."""
+    lib, loss, scratch, b = _loss_common(None, "ori", (ori, gt_orientation, gt), None)
+    hw = ori.shape[2] * ori.shape[3]
+    check(lib.ccvpe_orientation_loss_f32(_ptr(ori), _ptr(gt_orientation), _ptr(gt), _ptr(loss), _ptr(scratch),
+                                         b, hw, _stream()), "ccvpe_orientation_loss_f32")
+    return loss[0]

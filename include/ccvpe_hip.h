@@ -1,0 +1,169 @@
+/*
+ * ccvpe_hip.h — C ABI of libccvpe_hip.so: the MI355X (gfx950) implementation of CCVPE's dense
+ * cross-view matching forward path.
+ *
+ * The reference (tudelft-iv/CCVPE) has no FFI or plugin registry: the path sits behind a Python
+ * nn.Module (`CVM_VIGOR.forward(grd, sat)`, /root/reference/models.py:150) that hands every
+ * arithmetic step to a stock torch op.  Each entry point below therefore replaces one torch-op
+ * group of that forward; the comment on each cites the reference lines it stands in for.  The
+ * Python host (ccvpe_amd/models.py) binds them with ctypes — see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller.
+ *   - activations are fp32, NHWC ("pixel-major"): element (b,y,x,c) at ((b*H+y)*W+x)*ld + c with
+ *     ld >= C the pixel stride in floats (lets a kernel write into a wider concat buffer).
+ *   - the reference's NCHW fp32 tensors cross the boundary only at the two ends: the input images
+ *     (stem kernel reads NCHW) and the returned heat-map / orientation / score tensors (written
+ *     NCHW by the kernels that produce them).
+ *   - `stream` is a hipStream_t passed as void*; every call only ENQUEUES work on it (graph-capture
+ *     safe: no allocation, no synchronisation, no host-side state).
+ *   - return 0 on success, a negative CCVPE_E* code otherwise; ccvpe_last_error() gives the text.
+ *     No C++ exception crosses the ABI.
+ */
+#ifndef CCVPE_HIP_H
+#define CCVPE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCVPE_OK 0
+#define CCVPE_EINVAL (-1)   /* bad argument (shape/alignment not supported) */
+#define CCVPE_ELAUNCH (-2)  /* hipLaunchKernel / hipGetLastError failed     */
+
+#define CCVPE_ACT_NONE 0
+#define CCVPE_ACT_RELU 1
+#define CCVPE_ACT_SWISH 2
+
+#define CCVPE_OUT_NHWC 0      /* dst[(pixel)*ldd + n]                                            */
+#define CCVPE_OUT_DECONV2X 1  /* n = (dy*2+dx)*cout + co -> dst[(b,2y+dy,2x+dx)*ldd + co]        */
+
+#define CCVPE_MAX_SHIFTS 48
+
+const char* ccvpe_last_error(void);
+int ccvpe_abi_version(void);
+
+/* -------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+ *
+ *   out[m, n] = act( (sum_{tap, c} in[pixel(m) + tap, c] * w[n, tap, c]) * scale[n] + shift[n] )
+ *               (+ residual[m, n])
+ *
+ * One kernel covers every dense contraction of the path:
+ *   1x1  : MBConv expand / project (+SE gate on the input, +skip) and the 320->1280 head
+ *          (efficientnet_pytorch/model.py:62,86,104-106,121-130,209,299), the fused ground
+ *          descriptor 1x1 convs (models.py:57-97)
+ *   2x2/2: the aerial descriptor Linear over 2x2 patches (models.py:102-104,173-184)
+ *   3x3  : double_conv, reading cat[deconv_out, skip] as two sources without materialising the
+ *          concat (models.py:42-47,208-209,...)
+ *   deconv: ConvTranspose2d(k=2,s=2) as one GEMM with N = 4*cout and a pixel-shuffle store
+ *          (models.py:109-145)
+ *
+ * Weights are pre-packed by the host: w[n][k] row-major, k = tap*(c0+c1) + concat-channel,
+ * K zero-padded to `kpad` (multiple of 16), N zero-padded to a multiple of 16 rows.
+ * c0, c1 must be multiples of 8; ld0/ld1/ldd/ldres multiples of 4; pointers 16-byte aligned.
+ * ----------------------------------------------------------------------------------------- */
+typedef struct ccvpe_conv_desc {
+  const float* src0; /* [B,H,W,ld0] first source                                   */
+  const float* src1; /* [B,H,W,ld1] second (concatenated) source, or NULL           */
+  const float* gate; /* [B,c0] per-sample per-channel multiplier on src0 (SE), NULL  */
+  const float* w;    /* packed weights [npad16][kpad]                                */
+  const float* scale;    /* [n] or NULL (=1)   folded BN scale                       */
+  const float* shift;    /* [n] or NULL (=0)   folded BN shift / conv bias           */
+  const float* residual; /* [M,ldres] or NULL  MBConv identity skip                  */
+  float* dst;
+  int c0, ld0, c1, ld1;
+  int batch, in_h, in_w;
+  int kh, kw, stride, pad; /* (1,1,1,0) (3,3,1,1) (2,2,2,0)                          */
+  int n;                   /* real GEMM N (for deconv: 4*cout)                        */
+  int kpad;
+  int ldd, ldres;
+  int act;      /* CCVPE_ACT_*  */
+  int out_mode; /* CCVPE_OUT_*  */
+} ccvpe_conv_desc;
+
+int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* desc, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * EfficientNet stem: 3x3 stride-2 conv on the NCHW image + folded BN + swish, NHWC out.
+ * TF-"SAME" padding (0 before, 1 after) from the 224 schedule; `circular` wraps along W and
+ * zero-pads along H.  efficientnet_pytorch/model.py:181-182,289; utils.py:254-282,318-358.
+ *   x [B,3,H,W] NCHW, w [3][3][3][32] (ky,kx,ci,co), y [B,H/2,W/2,32]
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_stem_conv_f32(const float* x_nchw, const float* w, const float* scale, const float* shift,
+                        float* y, int batch, int in_h, int in_w, int circular, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Depthwise kxk conv (k in {3,5}, stride in {1,2}) + folded BN + swish, and the squeeze half of
+ * squeeze-excite: per-(sample, channel) partial sums of the activated output, one row per
+ * workgroup (fixed order => deterministic), reduced later by ccvpe_se_gate_f32.
+ * efficientnet_pytorch/model.py:70-73,108-110,114; padding as for the stem
+ * (stride 1: (k-1)/2 both sides; stride 2: k=3 (0,1), k=5 (1,2)).
+ *   x [B,H,W,C] (ld=C), w [k][k][C], y [B,Ho,Wo,C], se_partial [B][nblk][C]
+ * ccvpe_dwconv_nblk() returns nblk for a given shape (so the caller can size se_partial).
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_dwconv_nblk(int in_h, int in_w, int channels, int stride);
+int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                     float* se_partial, int batch, int in_h, int in_w, int channels, int k, int stride,
+                     int circular, void* stream);
+
+/* Squeeze-excite gate: mean -> 1x1 (C->Cs) + swish -> 1x1 (Cs->C) -> sigmoid.
+ * efficientnet_pytorch/model.py:113-118.  w1 [Cs][C], w2 [C][Cs], gate [B][C]. */
+int ccvpe_se_gate_f32(const float* se_partial, int nblk, float inv_hw, const float* w1, const float* b1,
+                      const float* w2, const float* b2, float* gate, int batch, int channels,
+                      int squeezed, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Ground descriptors: height collapse of the fused 1x1-conv output.
+ *   D_l[b, x*Cd_l + c] = sum_y wh_l[y] * y1[b,y,x,off_l + c] + bh_l      (models.py:57-97)
+ * y1 [B,h,w,ld] holds all six heads' channels side by side (conv bias already added);
+ * out [B][sum_l w*Cd_l], level l at offset w*off_l.  wh [6][h], bh [6], cd [6].
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
+                                float* out, int batch, int h, int w, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Rotational matching + LMU concat, fused (models.py:186-205 and the five blocks after it;
+ * ori_prior :484-514; KITTI :788-806):
+ *   score[b,i,p] = sum_{c<L} g[b,c] * X[b,p,(c + shift_i*stride) mod C]
+ *                  / ( ||X[b,p,window_i]||_2 * ||g[b]||_2 )               (no eps, as upstream)
+ *   dstx[b,p,0:C]        = X[b,p,:] / max(||X[b,p,:]||_2, 1e-12)
+ *   dstx[b,p,C]          = max_{i < n_max} score[b,i,p]
+ *   dstx[b,p,C+1+j]      = score[b, n_max_first + j, p]   j < n_tail   (level-1 orientation input)
+ *   dstx[b,p,C+1+n_tail : ldo] = 0
+ * X [B,H*W,ldx]; g [B,ldg] (first L entries); scores [B,n_shifts,H*W] (NCHW, returned to caller).
+ * The first n_max shifts feed the max; the last n_tail shifts are also copied into dstx.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
+                          int n_shifts, int n_max, int n_tail, int stride, float* scores, float* dstx,
+                          int ldo, int batch, int hw, int channels, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Final 3x3 conv to 1 or 2 channels, NCHW out (models.py:125-127 conv1.2, :146-148 conv1_ori.2);
+ * normalize!=0 divides the 2-vector by max(norm,1e-12) (models.py:341).
+ * x [B,H,W,16] NHWC, w [cout][3][3][16], out [B,cout,H,W].
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, float* out_nchw, int batch,
+                           int h, int w_, int cout, int normalize, void* stream);
+
+/* Row softmax over n columns (models.py:319-320: Softmax over the 262144 flattened logits). */
+int ccvpe_softmax_rows_f32(const float* logits, float* out, int rows, int n, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Losses (losses.py:4-29), device scalars out.  `acc` is caller-provided scratch.
+ *   infoNCE: accumulates num = sum_{label>1e-2} log(softmax(s/T))*label and den = sum label over
+ *            the whole batch; loss = -num/den.            scores/labels [B,n]
+ *   CE     : -sum(labels*log_softmax(logits))/B           [B,n]
+ *   ori    : sum(||gt_ori-ori||^2 * gt)/B                 ori/gt_ori [B,2,hw], gt [B,hw]
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_infonce_loss_f32(const float* scores, const float* labels, float temperature, float* loss,
+                           float* scratch, int batch, int n, void* stream);
+int ccvpe_cross_entropy_loss_f32(const float* logits, const float* labels, float* loss, float* scratch,
+                                 int batch, int n, void* stream);
+int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const float* gt, float* loss,
+                               float* scratch, int batch, int hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCVPE_HIP_H */

@@ -1,0 +1,90 @@
+"""CPU-side checks of the boundary: the C-ABI library loads and exports every symbol that
+include/ccvpe_hip.h declares (no compute calls without a GPU), the ctypes table covers the
+header, and the drop-in modules keep the reference's state_dict layout."""
+import os
+import re
+
+import pytest
+import torch
+
+from ccvpe_amd import _lib, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "ccvpe_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ccvpe_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.isfile(_lib.LIB_PATH):
+        _lib.build()
+    lib = _lib.load()
+    names = header_functions()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), "libccvpe_hip.so does not export %s" % n
+    assert sorted(_lib.PROTOTYPES) == names, "ctypes table and header disagree"
+    assert lib.ccvpe_abi_version() == 1
+
+
+def test_conv_desc_matches_header_field_order():
+    src = open(os.path.join(ROOT, "include", "ccvpe_hip.h")).read()
+    body = src[src.index("typedef struct ccvpe_conv_desc"):src.index("} ccvpe_conv_desc;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split("{", 1)[1].split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        names = decl.split(None, 1)[1] if not decl.startswith("const") else decl.split(None, 2)[2]
+        for n in names.split(","):
+            fields.append(n.strip().lstrip("*").strip())
+    assert fields == [f[0] for f in _lib.ConvDesc._fields_]
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libccvpe_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load()
+
+
+@pytest.mark.parametrize("kind", ["vigor", "kitti"])
+def test_state_dict_layout_and_roundtrip(kind, synth_sd):
+    from ccvpe_amd import models
+    net = models.CVM_KITTI("cpu") if kind == "kitti" else models.CVM_VIGOR("cpu", True)
+    spec = synth.state_dict_spec(kind)
+    sd = net.state_dict()
+    assert list(sd.keys()) == [k for k, _, _ in spec]
+    assert len(sd) == 818
+    for k, shape, _ in spec:
+        assert tuple(sd[k].shape) == tuple(shape), k
+    # dead _fc weights must round-trip
+    assert "grd_efficientnet._fc.weight" in sd and sd["sat_efficientnet._fc.weight"].shape == (1000, 1280)
+    src = synth_sd(kind, 3 if kind == "vigor" else 4)
+    net.load_state_dict(src, strict=True)
+    back = net.state_dict()
+    for k in src:
+        assert torch.equal(back[k], src[k]), k
+    # parameters vs buffers as in the reference (BN statistics are buffers)
+    pnames = {n for n, _ in net.named_parameters()}
+    assert "conv6.0.weight" in pnames and "grd_efficientnet._bn0.running_mean" not in pnames
+
+
+def test_vigor_and_ori_prior_share_checkpoints(synth_sd):
+    from ccvpe_amd import models
+    a = models.CVM_VIGOR("cpu", True)
+    b = models.CVM_VIGOR_ori_prior("cpu", 72, True)
+    b.load_state_dict(a.state_dict(), strict=True)
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+
+
+def test_cpu_inputs_are_rejected_not_emulated():
+    from ccvpe_amd import models
+    net = models.CVM_VIGOR_ori_prior("cpu", 0).eval()
+    grd, sat = synth.synthetic_pair(1, "vigor", 1)
+    with pytest.raises(RuntimeError, match="MI355X"):
+        net(grd, sat)

@@ -1,0 +1,106 @@
+"""Whole-path parity on the MI355X: the drop-in modules (ccvpe_amd.models) against the golden
+vectors generated from the reference and against the CPU oracle on the same seeded inputs.
+Tolerance (north_star): 1e-3 relative on heat-map logits, arg-max pixel exact."""
+import pytest
+import torch
+
+import golden_util as G
+from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOGIT_RTOL = 1e-3
+
+
+def build(case, synth_sd):
+    from ccvpe_amd import models
+    c = G.FORWARD_CASES[case] if isinstance(case, str) else case
+    if c["kind"] == "kitti":
+        net = models.CVM_KITTI("cuda")
+    elif c["ori_noise"] is None:
+        net = models.CVM_VIGOR("cuda", c["circular"])
+    else:
+        net = models.CVM_VIGOR_ori_prior("cuda", c["ori_noise"], c["circular"])
+    net.load_state_dict(synth_sd(c["kind"], c["wseed"]), strict=True)
+    return net.to("cuda:0").eval()
+
+
+def rel_err(got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    return ((got - want).abs().max() / (want.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name", list(G.FORWARD_CASES))
+def test_forward_vs_reference_golden(name, synth_sd):
+    c = G.FORWARD_CASES[name]
+    want = G.load("fwd_" + name)
+    net = build(name, synth_sd)
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    out = net(grd.cuda(), sat.cuda())
+    torch.cuda.synchronize()
+    got = G.summarize_forward([t.cpu() for t in out])
+    scale = abs(want["logits_s4"]).max()
+    assert (got["top4_idx"][:, 0] == want["top4_idx"][:, 0]).all(), "arg-max pixel differs"
+    G.assert_close(got["logits_s4"], want["logits_s4"], 0, LOGIT_RTOL * scale, "logits")
+    G.assert_close(got["top4_val"], want["top4_val"], 0, LOGIT_RTOL * scale, "top4")
+    G.assert_close(got["heat_sum"], want["heat_sum"], 1e-4, 0, "heatmap sums to 1")
+    G.assert_close(got["heat_at_top4"], want["heat_at_top4"], 5e-3, 0, "heatmap@top4")
+    G.assert_close(got["ori_at_argmax"], want["ori_at_argmax"], 0, 5e-3, "ori@argmax")
+    for i in range(1, 7):
+        assert got["score%d" % i].shape == want["score%d" % i].shape
+        s = abs(want["score%d" % i]).max()
+        G.assert_close(got["score%d" % i], want["score%d" % i], 0, 1e-3 * s, "score%d" % i)
+        G.assert_close(got["score%d_mean" % i], want["score%d_mean" % i], 0, 1e-3 * s, "score mean")
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="vigor", ori_noise=None, circular=True, wseed=0, grd="vigor"),
+    dict(kind="vigor", ori_noise=72, circular=False, wseed=0, grd="vigor_fov180"),
+    dict(kind="kitti", ori_noise=None, circular=False, wseed=1, grd="kitti"),
+])
+def test_forward_vs_oracle_batch2(case, synth_sd):
+    """B=2 on fresh inputs: every output tensor in full against the oracle."""
+    net = build(case, synth_sd)
+    grd, sat = synth.synthetic_pair(2, case["grd"], 991)
+    out = net(grd.cuda(), sat.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.forward(synth_sd(case["kind"], case["wseed"]), grd, sat, case["kind"], case["circular"],
+                        case["ori_noise"])
+    assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
+    assert rel_err(out[0], ref[0]) < LOGIT_RTOL
+    assert torch.equal(out[0].argmax(1).cpu(), ref[0].argmax(1)), "arg-max pixel differs"
+    assert rel_err(out[1], ref[1]) < 5e-3
+    for a, b in zip(out[3:], ref[3:]):
+        assert rel_err(a, b) < 1e-3
+    # orientation: compare where the un-normalised vector is not degenerate -> angle error
+    cos = (out[2].cpu() * ref[2]).sum(1).clamp(-1, 1)
+    frac_bad = (cos < 0.9999).float().mean().item()
+    assert frac_bad < 1e-3, "orientation field differs on %.4f of pixels" % frac_bad
+    # orientation bin at the arg-max pixel (north_star: bin exact)
+    idx = ref[0].argmax(1)
+    for b in range(2):
+        o_g = out[2].cpu().reshape(2, 2, -1)[b, :, idx[b]]
+        o_r = ref[2].reshape(2, 2, -1)[b, :, idx[b]]
+        ang = lambda v: torch.atan2(v[1], v[0]) * 180 / 3.14159265
+        assert int(ang(o_g) % 360 // 18) == int(ang(o_r) % 360 // 18)
+
+
+def test_weights_repacked_after_update(synth_sd):
+    """load_state_dict after the first forward must invalidate the packed weights."""
+    net = build("vigor_prior0", synth_sd)
+    grd, sat = synth.synthetic_pair(1, "vigor", 3)
+    a = net(grd.cuda(), sat.cuda())[0].clone()
+    sd2 = {k: v.clone() for k, v in synth_sd("vigor", 0).items()}
+    sd2["conv1.2.bias"] = sd2["conv1.2.bias"] + 1.0
+    net.load_state_dict(sd2, strict=True)
+    b = net(grd.cuda(), sat.cuda())[0]
+    assert torch.allclose(b, a + 1.0, atol=1e-5)
+
+
+def test_train_mode_raises(synth_sd):
+    net = build("vigor_prior0", synth_sd).train()
+    grd, sat = synth.synthetic_pair(1, "vigor", 3)
+    with pytest.raises(NotImplementedError):
+        net(grd.cuda(), sat.cuda())

@@ -1,0 +1,288 @@
+"""Per-operator parity on the MI355X: every call goes through the C ABI (ccvpe_amd.ops ->
+libccvpe_hip.so) and is compared with the CPU oracle / a torch fp32 CPU restatement of the same
+op on identical seeded inputs.  fp32 everywhere; tolerances are round-off class
+(1e-4 relative to the tensor's scale unless noted; north_star allows 1e-3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as G
+from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available(), "gpu tests need the MI355X"
+    from ccvpe_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def close(got, want, tol=1e-4, what=""):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e)" % (what, err, scale, err / scale)
+
+
+def pack_conv(w):
+    from ccvpe_amd.models import _pack_conv
+    return _pack_conv(w)
+
+
+# ------------------------------------------------------------------------------------------
+# implicit GEMM
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout", [(16, 96), (24, 144), (40, 240), (80, 480), (112, 672), (192, 1152),
+                                      (96, 24), (144, 40), (480, 112), (320, 1280), (32, 16), (672, 192),
+                                      (1152, 320), (240, 80), (64, 64), (8, 160)])
+def test_igemm_1x1_all_tile_configs(ops, cin, cout):
+    b, h, w = 2, 9, 13                                   # M = 234: exercises the M tail
+    x = synth.normal((b, cin, h, w), 100 + cin)
+    wt = synth.normal((cout, cin, 1, 1), 200 + cout, (1.0 / cin) ** 0.5)
+    sc = synth.uniform((cout,), 300, 0.5, 1.5)
+    sh = synth.normal((cout,), 301, 0.1)
+    want = O.swish(F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, batch=b, in_h=h, in_w=w,
+                         scale=dev(sc), shift=dev(sh), act=ops.ACT_SWISH)
+    close(nchw(got), want, 1e-4, "1x1 %d->%d" % (cin, cout))
+
+
+def test_igemm_gate_and_residual(ops):
+    b, h, w, cin, cout = 3, 7, 10, 96, 24
+    x = synth.normal((b, cin, h, w), 1)
+    gate = synth.uniform((b, cin), 2)
+    res = synth.normal((b, cout, h, w), 3)
+    wt = synth.normal((cout, cin, 1, 1), 4, 0.1)
+    sc = synth.uniform((cout,), 5, 0.5, 1.5)
+    sh = synth.normal((cout,), 6, 0.1)
+    want = F.conv2d(x * gate.view(b, cin, 1, 1), wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1) + res
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, batch=b, in_h=h, in_w=w,
+                         gate=dev(gate), scale=dev(sc), shift=dev(sh), residual=dev(nhwc(res)))
+    close(nchw(got), want, 1e-4, "gate+residual")
+
+
+@pytest.mark.parametrize("c0,c1,cout,hw", [(40, 16, 40, 12), (80, 24, 80, 9), (16, 0, 16, 17), (320, 112, 320, 6),
+                                           (1024, 320, 640, 4)])
+def test_igemm_3x3_two_sources(ops, c0, c1, cout, hw):
+    b = 2
+    a = synth.normal((b, c0, hw, hw), 10 + c0)
+    s = synth.normal((b, c1, hw, hw), 11 + c1) if c1 else None
+    wt = synth.normal((cout, c0 + c1, 3, 3), 12, (1.0 / (9 * (c0 + c1))) ** 0.5)
+    bias = synth.normal((cout,), 13, 0.1)
+    xin = torch.cat([a, s], 1) if c1 else a
+    want = F.relu(F.conv2d(xin, wt, bias, padding=1))
+    got = ops.conv_igemm(dev(nhwc(a)), c0, dev(pack_conv(wt)), cout, batch=b, in_h=hw, in_w=hw, kh=3, kw=3, pad=1,
+                         src1=dev(nhwc(s)) if c1 else None, c1=c1, shift=dev(bias), act=ops.ACT_RELU)
+    close(nchw(got), want, 1e-4, "3x3 %d+%d->%d" % (c0, c1, cout))
+
+
+def test_igemm_2x2_stride2_linear_patches(ops):
+    """models.py:173-184: Linear over flattened (c,h,w) 2x2 patches."""
+    b, c, n = 2, 64, 48
+    vol = synth.normal((b, c, 8, 8), 20)
+    wl = synth.normal((n, c * 4), 21, 0.05)
+    bias = synth.normal((n,), 22, 0.1)
+    want = F.conv2d(vol, wl.view(n, c, 2, 2), bias, stride=2)
+    got = ops.conv_igemm(dev(nhwc(vol)), c, dev(pack_conv(wl.view(n, c, 2, 2))), n, batch=b, in_h=8, in_w=8,
+                         kh=2, kw=2, stride=2, shift=dev(bias))
+    close(nchw(got), want, 1e-4, "2x2s2")
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(48, 16, 9), (168, 40, 5), (648, 320, 3)])
+def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
+    from ccvpe_amd.models import _pack_deconv
+    b = 2
+    x = synth.normal((b, cin, hw, hw), 30 + cin)
+    wt = synth.normal((cin, cout, 2, 2), 31, (1.0 / cin) ** 0.5)
+    bias = synth.normal((cout,), 32, 0.1)
+    want = F.conv_transpose2d(x, wt, bias, stride=2)
+    wp, b4 = _pack_deconv(wt, bias, [(0, 0, cin)], cin)
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(wp), 4 * cout, batch=b, in_h=hw, in_w=hw, shift=dev(b4),
+                         out_mode=ops.OUT_DECONV2X)
+    close(nchw(got), want, 1e-4, "deconv")
+
+
+# ------------------------------------------------------------------------------------------
+# EfficientNet pieces
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("circ", [True, False])
+def test_stem_golden(ops, circ, synth_sd):
+    from ccvpe_amd.models import _fold_bn
+    want = G.load("effnet_modules_" + ("circ" if circ else "zero"))["stem"]
+    sd = synth_sd("vigor", 0)
+    pfx = "grd_efficientnet" if circ else "sat_efficientnet"
+    x = synth.normal((2, 3, 32, 48), 4242)
+    sc, sh = _fold_bn(sd, pfx + "._bn0")
+    got = ops.stem_conv(dev(x), dev(sd[pfx + "._conv_stem.weight"].permute(2, 3, 1, 0)), dev(sc), dev(sh), circ)
+    close(nchw(got), torch.from_numpy(want), 1e-4, "stem")
+
+
+@pytest.mark.parametrize("k,s,c,h,w,circ", [(3, 1, 32, 9, 12, False), (3, 2, 96, 10, 14, True), (5, 2, 144, 8, 12, True),
+                                            (5, 1, 480, 6, 7, False), (5, 1, 1152, 5, 9, True), (3, 2, 240, 7, 9, False),
+                                            (5, 2, 672, 9, 11, False), (3, 1, 1152, 4, 6, True)])
+def test_dwconv_and_squeeze(ops, k, s, c, h, w, circ):
+    b = 2
+    x = synth.normal((b, c, h, w), 40 + c)
+    wt = synth.normal((c, 1, k, k), 41, 1.0 / k)
+    sc = synth.uniform((c,), 42, 0.5, 1.5)
+    sh = synth.normal((c,), 43, 0.1)
+    sched = 224                                        # even schedule size: pads (k-1)/2 or (0,1)/(1,2)
+    y = O.same_conv(x, wt, k, s, sched, circ, groups=c)
+    want = O.swish(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got, part = ops.dwconv(dev(nhwc(x)), dev(wt.reshape(c, k, k).permute(1, 2, 0)), dev(sc), dev(sh), k, s, circ)
+    close(nchw(got), want, 1e-4, "dwconv k%d s%d" % (k, s))
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials")
+
+
+def test_se_gate(ops):
+    b, c, cs, nblk = 3, 240, 10, 7
+    part = synth.normal((b, nblk, c), 50)
+    w1 = synth.normal((cs, c), 51, 0.1)
+    b1 = synth.normal((cs,), 52, 0.1)
+    w2 = synth.normal((c, cs), 53, 0.3)
+    b2 = synth.normal((c,), 54, 0.1)
+    mean = part.sum(1) / 35.0
+    z = O.swish(mean @ w1.t() + b1)
+    want = torch.sigmoid(z @ w2.t() + b2)
+    got = ops.se_gate(dev(part), 35, dev(w1), dev(b1), dev(w2), dev(b2))
+    close(got, want, 1e-5, "se gate")
+
+
+@pytest.mark.parametrize("circ", [True, False])
+def test_mbconv_blocks_golden(ops, circ, synth_sd):
+    """Every MBConv block of the reference (golden from its own modules) via the HIP ops."""
+    from ccvpe_amd.models import _pack_encoder
+    want = G.load("effnet_modules_" + ("circ" if circ else "zero"))
+    sd = {k: v.cuda() for k, v in synth_sd("vigor", 0).items() if "efficientnet" in k}
+    pfx = "grd_efficientnet" if circ else "sat_efficientnet"
+    e = _pack_encoder(sd, pfx)
+    for i, blk in enumerate(e.blocks):
+        if "block%d" % i not in want:
+            continue
+        xin = synth.normal((2, blk.cin) + G.BLOCK_HW, 5000 + i)
+        x = dev(nhwc(xin))
+        b, h, w, _ = x.shape
+        t = x
+        if blk.expand:
+            t = ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w, scale=blk.s0, shift=blk.b0,
+                               act=ops.ACT_SWISH)
+        u, part = ops.dwconv(t, blk.w_dw, blk.s1, blk.b1, blk.k, blk.s, circ)
+        gate = ops.se_gate(part, u.shape[1] * u.shape[2], blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        y = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=u.shape[1], in_w=u.shape[2], gate=gate,
+                           scale=blk.s2, shift=blk.b2, residual=x if blk.skip else None)
+        close(nchw(y), torch.from_numpy(want["block%d" % i]), 1e-4, "block%d" % i)
+
+
+# ------------------------------------------------------------------------------------------
+# descriptors / matching / heads
+# ------------------------------------------------------------------------------------------
+def test_ground_descriptor(ops):
+    b, h, w = 2, 10, 20
+    cd = (64, 32, 16, 8, 4, 2)
+    y1 = synth.normal((b, h, w, 128), 60)
+    wh = synth.normal((6, h), 61, 0.3)
+    bh = synth.normal((6,), 62, 0.1)
+    got = ops.ground_descriptor(dev(y1), dev(wh), dev(bh), cd)
+    off, outs = 0, []
+    for l in range(6):
+        d = torch.einsum("bhwc,h->bwc", y1[..., off:off + cd[l]], wh[l]) + bh[l]
+        outs.append(d.reshape(b, -1))
+        off += cd[l]
+    close(got, torch.cat(outs, 1), 1e-5, "ground descriptor")
+
+
+@pytest.mark.parametrize("C,L,stride,hw,shifts,n_max,n_tail", [
+    (1280, 1280, 64, 8, list(range(20)), 20, 20),                    # VIGOR level 1 (train model)
+    (1280, 1280, 64, 8, [0] + list(range(20)), 1, 20),               # ori_prior(0) level 1
+    (1280, 640, 64, 8, list(range(-10, 11)) + list(range(20)), 21, 20),   # ori_prior(180), FoV 180
+    (640, 640, 32, 16, list(range(20)), 20, 0),                      # level 2
+    (40, 40, 2, 20, list(range(20)), 20, 0),                         # level 6 (stride 2 -> 8-byte path)
+    (40, 20, 2, 20, list(range(-10, 11)), 21, 0),                    # level 6, FoV 180
+    (160, 160, 8, 23, [0], 1, 0),                                    # N_rot = 1, ragged pixel count
+    (2048, 512, 128, 8, list(range(16)), 16, 16),                    # KITTI level 1
+    (128, 32, 8, 16, list(range(16)), 16, 0),                        # KITTI level 5 (wrapping duplicates)
+    (32, 32, 8, 32, list(range(16)), 16, 0),                         # KITTI level 6
+    (80, 80, 4, 16, list(range(-3, 4)), 7, 0),                       # ori_prior(54) level 5
+])
+def test_match_level(ops, C, L, stride, hw, shifts, n_max, n_tail):
+    b = 2
+    x = synth.normal((b, C, hw, hw), 70 + C)
+    g = synth.normal((b, L + 5), 71 + L)          # wider row: exercises ldg
+    ldo = (C + 1 + n_tail + 7) // 8 * 8
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g)[:, :L], L, shifts, n_max, n_tail, stride, ldo)
+    want = O.rotational_matching(x, g[:, :L], shifts, stride)
+    close(sc, want, 2e-5, "scores")
+    catc = nchw(cat).cpu()
+    close(catc[:, :C], F.normalize(x, p=2, dim=1), 1e-5, "normalised features")
+    close(catc[:, C], want[:, :n_max].max(dim=1)[0], 2e-5, "max over rotations")
+    if n_tail:
+        close(catc[:, C + 1:C + 1 + n_tail], want[:, len(shifts) - n_tail:], 2e-5, "tail scores")
+    assert (catc[:, C + 1 + n_tail:] == 0).all()
+
+
+def test_match_level_zero_window_gives_nonfinite_like_reference(ops):
+    """models.py:196 has no eps: a zero-norm window divides by zero.  Reproduced, not 'fixed'."""
+    b, C, hw = 1, 40, 8
+    x = synth.normal((b, C, hw, hw), 90)
+    x[:, :, 0, 0] = 0.0
+    g = synth.normal((b, C), 91)
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g), C, [0, 1], 2, 0, 2, 48)
+    want = O.rotational_matching(x, g, [0, 1], 2)
+    assert not torch.isfinite(sc[0, :, 0, 0]).any() and not torch.isfinite(want[0, :, 0, 0]).any()
+    assert (nchw(cat)[0, :C, 0, 0] == 0).all()          # F.normalize eps path
+
+
+@pytest.mark.parametrize("cout", [1, 2])
+def test_head_conv(ops, cout):
+    b, hw = 2, 21
+    x = synth.normal((b, 16, hw, hw), 80)
+    wt = synth.normal((cout, 16, 3, 3), 81, 0.1)
+    bias = synth.normal((cout,), 82, 0.1)
+    want = F.conv2d(x, wt, bias, padding=1)
+    if cout == 2:
+        want = F.normalize(want, p=2, dim=1)
+    got = ops.head_conv3x3(dev(nhwc(x)), dev(wt.permute(0, 2, 3, 1)), dev(bias), cout, cout == 2)
+    close(got, want, 1e-5, "head conv")
+
+
+def test_softmax_rows(ops):
+    lg = synth.normal((3, 262144), 85, 2.0)
+    got = ops.softmax_rows(dev(lg))
+    want = torch.softmax(lg, dim=1)
+    close(got, want, 1e-5, "softmax")
+    assert torch.equal(got.argmax(1).cpu(), want.argmax(1))
+
+
+def test_losses_golden(ops):
+    want = G.load("losses")
+    for n_cols in (1280, 20480):
+        sc = synth.uniform((3, n_cols), 8000 + n_cols, -1.0, 1.0)
+        lab = synth.uniform((3, n_cols), 8100 + n_cols) ** 6
+        got = ops.infonce_loss(dev(sc), dev(lab)).item()
+        G.assert_close(got, want["infonce_%d" % n_cols], 1e-4, 0, "infonce")
+    lg = synth.normal((3, 262144), 8200, 2.0)
+    lab = synth.uniform((3, 262144), 8201) ** 20
+    lab = lab / lab.sum(1, keepdim=True)
+    G.assert_close(ops.cross_entropy_loss(dev(lg), dev(lab)).item(), want["ce"], 1e-4, 0, "ce")
+    ori = F.normalize(synth.normal((3, 2, 512, 512), 8300), dim=1)
+    gto = F.normalize(synth.normal((3, 2, 512, 512), 8301), dim=1)
+    got = ops.orientation_loss(dev(ori), dev(gto), dev(lab.reshape(3, 1, 512, 512))).item()
+    G.assert_close(got, want["ori"], 1e-4, 0, "ori loss")
