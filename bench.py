@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — CCVPE dense cross-view matching forward on MI355X.
+
+Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under
+torch.distributed.run (one rank per GPU, RCCL).  A "step" is ONE forward pass of the hot path
+over one batch of synthetic image pairs resident in HBM.
+
+Workload at N=1 = BASELINE.json configs[1] ("C1"): CVM_VIGOR_ori_prior(ori_noise=0)
+(N_rot=1 in the localisation branch, 20 in the orientation branch), batch 64 per GPU, fp32,
+ground 3x320x640 + aerial 3x512x512, synthetic inputs and seeded random-init weights (no network).
+Inference shards by sample: N>1 runs N replicas with NO data-path collective ("weak" scaling);
+the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
+
+One JSON line on rank 0 with, besides the contract fields:
+  roofline     — for the dominant kernel (the fp32-MFMA implicit-GEMM instantiation with the
+                 largest share of the step): achieved = algorithmic FLOPs of its launches in the
+                 timed region / their HIP-event durations; peak = 157.3 TF fp32 matrix
+                 (MI355X_MICROARCH.md); traffic = PMC HBM bytes per launch if a profiles/ pass
+                 recorded them, else null.
+  cpu_baseline — the CPU oracle (oracle/ccvpe_oracle.py, kind "port") on the host cores, bounded
+                 sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+HBM_PEAK_GBS = 8000.0
+GFLOP_PER_PAIR = {"vigor": 56.37}    # BASELINE.md §3 (N_rot=20); reported in config for reference
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket igemm launches with HIP events in the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(sd, batch=8, reps=3):
+    """Oracle forward on the host cores: bounded sample (~10-30 s).  The thread count is capped:
+    the per-op work of a B=8 forward does not feed more than a few dozen cores (256 threads ran
+    50x SLOWER than 32 in a first measurement); `cores` reports the threads actually used."""
+    import torch
+    from ccvpe_amd import synth
+    from oracle import ccvpe_oracle as O
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    grd, sat = synth.synthetic_pair(batch, "vigor", 1234)
+    times = []
+    with torch.no_grad():
+        O.forward(sd, grd, sat, "vigor", True, ori_noise=0)          # warm-up
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            O.forward(sd, grd, sat, "vigor", True, ori_noise=0)
+            times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return dict(value=batch / med, unit="img-pairs/s", cores=cores, kind="port",
+                sample="oracle forward, CVM_VIGOR_ori_prior(0), B=%d fp32, 1 warm-up + median of %d" % (batch, reps))
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # RCCL
+
+    from ccvpe_amd import models, ops, synth, _lib
+    _lib.load()                                             # fails loudly if the HIP library is missing
+
+    sd = synth.synthetic_state_dict("vigor", 0)             # identical on every rank
+    net = models.CVM_VIGOR_ori_prior(dev, 0, True)
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev).eval()
+    grd, sat = synth.synthetic_pair(args.batch, "vigor", 1234 + rank)
+    grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = net(grd, sat)
+    rec = None
+    if not args.no_kernel_events:
+        rec = ops.LaunchRecorder()
+    barrier()
+    ops.set_recorder(rec)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(grd, sat)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.set_recorder(None)
+
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        pairs = args.batch * world * args.steps
+        value = pairs / elapsed
+        line = {
+            "metric": "image-pairs/sec", "value": round(value, 2), "unit": "img-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C1: CVM_VIGOR_ori_prior(ori_noise=0) eval forward, "
+                                   "grd 3x320x640 + sat 3x512x512, N_rot=1 loc / 20 ori",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "replicas x%d (no data-path collective)" % world,
+                       "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
+        }
+        roof = None
+        if rec is not None:
+            summ = rec.summary()
+            tot_ms = sum(d["ms"] for d in summ.values())
+            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.isfile(tpath):
+                try:
+                    traffic = json.load(open(tpath)).get(name)
+                except Exception:
+                    traffic = None
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                    "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": d["calls"] // args.steps,
+                    "avg_launch_ms": round(d["ms"] / d["calls"], 4),
+                    "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
+                    "share_of_igemm_time": round(d["ms"] / tot_ms, 3),
+                    "all_igemm": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
+                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                      "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                      "launches_per_step": v["calls"] // args.steps}
+                                  for k, v in sorted(summ.items())}}
+        line["roofline"] = roof
+        if rec is not None and args.per_layer:
+            agg = {}
+            for name, tag, flops, nbytes, e0, e1 in rec.items:
+                d = agg.setdefault((name, tag), [0, 0.0, 0.0, 0.0])
+                d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += flops; d[3] += nbytes
+            print("%-28s %-28s %5s %9s %8s %8s" % ("kernel", "shape", "n/st", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
+            for (name, tag), d in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print("%-28s %-28s %5d %9.3f %8.1f %8.0f" % (name, tag, d[0] // args.steps, d[1] / args.steps,
+                      d[2] / d[1] / 1e9, d[3] / d[1] / 1e6), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(sd)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

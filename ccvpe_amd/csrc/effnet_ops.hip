@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, float* __restrict__ y,
                                                      float* __restrict__ se_partial, int H, int W, int C, int Ho,
-                                                     int Wo, int cgx, int P, int nblk, int circular) {
+                                                     int Wo, int cgx, int P, int nblk, int circular, int RB,
+                                                     int ychunks, int total_blocks) {
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;  // pad before (224-schedule SAME)
   constexpr int NCOL = (DW_TW - 1) * S + K;
   extern __shared__ __attribute__((aligned(16))) float red[];  // [P][cgx] float4
@@ -92,14 +93,26 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
   const int tid = threadIdx.x;
   const int cgl = tid % cgx;
   const int pl = tid / cgx;
-  const int b = blockIdx.z;
-  const int cg = blockIdx.y * cgx + cgl;
+  // XCD-aware order: workgroup ids round-robin over the 8 XCDs; give each XCD a contiguous run of
+  // logical blocks (= neighbouring strips/rows of the same sample) so the k-row halo that adjacent
+  // strips share is served by ONE L2 instead of being fetched from HBM by several.
+  int lb;
+  {
+    const int q = total_blocks / 8, r = total_blocks % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int bx = lb % nblk;
+  const int by = (lb / nblk) % ychunks;
+  const int b = lb / (nblk * ychunks);
+  const int cg = by * cgx + cgl;
   const int c = cg * 4;
   const int sxn = (Wo + DW_TW - 1) / DW_TW;
-  const int strip = blockIdx.x * P + pl;
-  const bool active = pl < P && strip < Ho * sxn && c < C;
 
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int rb = 0; rb < RB; ++rb) {
+  const int strip = (bx * RB + rb) * P + pl;
+  const bool active = pl < P && strip < Ho * sxn && c < C;
   if (active) {
     const int oy = strip / sxn;
     const int ox0 = (strip - oy * sxn) * DW_TW;
@@ -147,6 +160,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
       }
     }
   }
+  }
   // block reduction over the P strips, fixed order
   f32x4* red4 = reinterpret_cast<f32x4*>(red);
   if (pl < P) red4[pl * cgx + cgl] = sum;
@@ -154,12 +168,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
   if (pl == 0 && c < C) {
     f32x4 tot = red4[cgl];
     for (int q = 1; q < P; ++q) tot += red4[q * cgx + cgl];
-    *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * nblk + blockIdx.x) * C + c) = tot;
+    *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * nblk + bx) * C + c) = tot;
   }
 }
 
 static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* ychunks, int* nblk, int* Ho, int* Wo,
-                        int k) {
+                        int k, int* RB) {
   const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
   *Ho = (H + total_pad - k) / stride + 1;
   *Wo = (W + total_pad - k) / stride + 1;
@@ -171,7 +185,13 @@ static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* 
   *P = 256 / *cgx;
   const int sxn = (*Wo + DW_TW - 1) / DW_TW;
   const int strips = *Ho * sxn;
-  *nblk = (strips + *P - 1) / *P;
+  const int groups = (strips + *P - 1) / *P;
+  // RB strip-groups per workgroup: fewer SE partial rows, still >= ~32 workgroups per sample
+  int rb = groups / 32;
+  if (rb < 1) rb = 1;
+  if (rb > 8) rb = 8;
+  *RB = rb;
+  *nblk = (groups + rb - 1) / rb;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -181,18 +201,32 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int Cs) {
-  extern __shared__ float sm[];  // mean[C] | z[Cs]
+  extern __shared__ float sm[];  // mean[C] | z[Cs] | red[256]
   float* mean = sm;
   float* z = sm + C;
+  float* red = z + Cs;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  for (int c = tid; c < C; c += 256) {
-    const float* p = part + (size_t)b * nblk * C + c;
+  // partial rows are summed by R thread-rows in parallel (fixed assignment => deterministic)
+  const int cw = C < 256 ? C : 256;
+  const int R = 256 / cw;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int cl = tid % cw, rr = tid / cw;
+    const int c = c0 + cl;
     float s = 0.f;
-    for (int q = 0; q < nblk; ++q) s += p[(size_t)q * C];
-    mean[c] = s * inv_hw;
+    if (rr < R && c < C) {
+      const float* p = part + (size_t)b * nblk * C + c;
+      for (int q = rr; q < nblk; q += R) s += p[(size_t)q * C];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rr == 0 && c < C) {
+      float t = red[cl];
+      for (int j = 1; j < R; ++j) t += red[j * cw + cl];
+      mean[c] = t * inv_hw;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int lane = tid & 63, wave = tid >> 6;
   for (int j = wave; j < Cs; j += 4) {
     float s = 0.f;
@@ -228,9 +262,9 @@ extern "C" int ccvpe_stem_conv_f32(const float* x, const float* w, const float* 
 
 extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
   // nblk does not depend on k for the SAME schedule (Ho = ceil-like of H/stride for both k)
-  int cgx, P, yc, nblk, Ho, Wo;
+  int cgx, P, yc, nblk, Ho, Wo, RB;
   if (C <= 0 || C % 4) return CCVPE_EINVAL;
-  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, 3);
+  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, 3, &RB);
   return nblk;
 }
 
@@ -242,15 +276,17 @@ extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* sca
   if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(se_partial) || !aligned16(scale) ||
       !aligned16(shift))
     return fail(CCVPE_EINVAL, "dwconv: pointers must be 16-byte aligned");
-  int cgx, P, yc, nblk, Ho, Wo;
-  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k);
+  int cgx, P, yc, nblk, Ho, Wo, RB;
+  dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k, &RB);
   if (circular && (k / 2 + 1 > W)) return fail(CCVPE_EINVAL, "dwconv: W too small for circular wrap");
-  dim3 grid(nblk, yc, B);
+  const long total = (long)nblk * yc * B;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "dwconv: grid too large");
+  dim3 grid((unsigned)total);
   const size_t smem = (size_t)P * cgx * 16;
   hipStream_t st = (hipStream_t)stream;
 #define DW_LAUNCH(K_, S_)                                                                                         \
   hipLaunchKernelGGL((dwconv_kernel<K_, S_>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
-                     C, Ho, Wo, cgx, P, nblk, circular)
+                     C, Ho, Wo, cgx, P, nblk, circular, RB, yc, (int)total)
   if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
   else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);
   else if (k == 5 && stride == 1) DW_LAUNCH(5, 1);
@@ -262,7 +298,7 @@ extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* sca
 extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, const float* w1, const float* b1,
                                  const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
   if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
-  const size_t smem = (size_t)(C + Cs) * sizeof(float);
+  const size_t smem = (size_t)(C + Cs + 256) * sizeof(float);
   hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, part, nblk, inv_hw, w1, b1, w2, b2,
                      gate, C, Cs);
   return check_launch("se_gate_kernel");

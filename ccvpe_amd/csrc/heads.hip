@@ -47,9 +47,18 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
   __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 16];
   for (int i = threadIdx.x; i < COUT * 9 * 16; i += 256) ws[i] = w[i];
   __syncthreads();
-  const int b = blockIdx.z;
-  const int oy = blockIdx.y;
-  const int ox = blockIdx.x * 256 + threadIdx.x;
+  // XCD-aware order (see dwconv_kernel): neighbouring rows of a sample go to the same XCD's L2.
+  const int nxb = (W + 255) / 256;
+  const int total = gridDim.x;
+  int lb;
+  {
+    const int q = total / 8, r = total % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int ox = (lb % nxb) * 256 + threadIdx.x;
+  const int oy = (lb / nxb) % H;
+  const int b = lb / (nxb * H);
   if (ox >= W) return;
   float acc[COUT];
 #pragma unroll
@@ -256,7 +265,7 @@ extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float*
 extern "C" int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, int B, int H,
                                       int W, int cout, int normalize, void* stream) {
   if (!aligned16(x)) return fail(CCVPE_EINVAL, "head_conv: x must be 16-byte aligned");
-  dim3 grid((W + 255) / 256, H, B);
+  dim3 grid(((W + 255) / 256) * H * B);
   if (cout == 1)
     hipLaunchKernelGGL(head_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, 0);
   else if (cout == 2)

@@ -175,11 +175,12 @@ def _pack_model(sd, kind, n_tail):
         if j == 0:
             c6 = dc_in - n_rot
             ov.k = pk.loc[0].ldo
+            ov.k_algo = dc_in
             # reference order [scores(n_rot), X]; ours [X, max, scores, pad]
             ov.up_w, ov.up_b = _pack_deconv(sd["deconv6_ori.weight"], sd["deconv6_ori.bias"],
                                             [(0, n_rot, c6), (c6 + 1, 0, n_rot)], pk.loc[0].ldo)
         else:
-            ov.k = dc_in
+            ov.k = ov.k_algo = dc_in
             ov.up_w, ov.up_b = _pack_deconv(sd["deconv%d_ori.weight" % lvl], sd["deconv%d_ori.bias" % lvl],
                                             [(0, 0, dc_in)], dc_in)
         ov.up_n = 4 * dc_out
@@ -334,7 +335,7 @@ class _CVMBase(nn.Module):
                 else:
                     scores_out.append(sc)
                 up = ops.conv_igemm(cat, lv.ldo, lv.up_w, lv.up_n, batch=batch, in_h=hw, in_w=hw,
-                                    shift=lv.up_b, out_mode=ops.OUT_DECONV2X)
+                                    shift=lv.up_b, out_mode=ops.OUT_DECONV2X, algo_k=lv.c + 1)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
                 y = _double_conv(lv, up, skip, batch, 2 * hw)
                 if j < 5:
@@ -351,7 +352,7 @@ class _CVMBase(nn.Module):
                 ov = pk.ori[j]
                 hw = xo.shape[1]
                 up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
-                                    shift=ov.up_b, out_mode=ops.OUT_DECONV2X)
+                                    shift=ov.up_b, out_mode=ops.OUT_DECONV2X, algo_k=ov.k_algo)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
                 y = _double_conv(ov, up, skip, batch, 2 * hw)
                 if j < 5:

@@ -14,6 +14,58 @@ from ._lib import ConvDesc, check
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
 OUT_NHWC, OUT_DECONV2X = 0, 1
 
+# Optional launch recorder (bench.py): when set, every library call is bracketed by HIP events on
+# the launching stream and reported as (kernel family, tag, algorithmic flops, algorithmic bytes).
+_recorder = None
+
+
+def set_recorder(rec):
+    global _recorder
+    _recorder = rec
+
+
+class LaunchRecorder(object):
+    """Collects (name, tag, flops, bytes, start_event, end_event) per library call."""
+
+    def __init__(self):
+        self.items = []
+
+    def begin(self):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        return ev
+
+    def end(self, name, tag, flops, nbytes, ev0):
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev1.record(torch.cuda.current_stream())
+        self.items.append((name, tag, flops, nbytes, ev0, ev1))
+
+    def summary(self):
+        """name -> dict(calls, ms, flops, bytes); call after torch.cuda.synchronize()."""
+        out = {}
+        for name, tag, flops, nbytes, e0, e1 in self.items:
+            d = out.setdefault(name, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+            d["calls"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["flops"] += flops
+            d["bytes"] += nbytes
+        return out
+
+
+def igemm_tile(n):
+    """Mirror of pick_cfg() in csrc/conv_igemm.hip: (BM, BN) chosen for a GEMM N (reporting only)."""
+    npad = (n + 15) // 16 * 16
+    cfgs = [(4, 5, 2), (4, 4, 2), (4, 3, 2), (4, 2, 2), (4, 1, 2), (4, 5, 1), (4, 3, 1), (4, 1, 1), (2, 7, 1)]
+    best, best_cost = None, None
+    for mt, nt, wn in cfgs:
+        bn = 16 * nt * wn
+        tiles = (npad + bn - 1) // bn
+        cost = tiles * bn * 1000 + (1000 - bn)
+        if best_cost is None or cost < best_cost:
+            best, best_cost = (mt, nt, wn), cost
+    mt, nt, wn = best
+    return "igemm_f32_kernel<%d,%d,%d>" % (mt, nt, wn)
+
 
 def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -35,7 +87,7 @@ def _chk(t, name):
 
 def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0,
                src1=None, c1=0, gate=None, scale=None, shift=None, residual=None, act=ACT_NONE,
-               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None):
+               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None, algo_k=None):
     """Implicit-GEMM conv / deconv / linear (ccvpe_conv_igemm_f32).  src tensors are NHWC."""
     lib = _lib.load()
     for t, nm in ((src0, "src0"), (src1, "src1"), (gate, "gate"), (w_packed, "w"), (scale, "scale"),
@@ -66,7 +118,17 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     d.ldd = ldd
     d.ldres = residual.shape[-1] if residual is not None else 0
     d.act, d.out_mode = act, out_mode
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
     check(lib.ccvpe_conv_igemm_f32(ctypes.byref(d), _stream()), "ccvpe_conv_igemm_f32")
+    if rec is not None:
+        m = batch * ho * wo
+        k_alg = algo_k if algo_k is not None else kh * kw * (c0 + c1)
+        flops = 2.0 * m * n * k_alg
+        # algorithmic bytes: input read once, output written once, weights once
+        nbytes = 4.0 * (batch * in_h * in_w * (c0 + c1) + m * n + n * k_alg
+                        + (m * n if residual is not None else 0))
+        rec.end(igemm_tile(n), "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
     return dst
 
 

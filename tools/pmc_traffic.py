@@ -1,0 +1,53 @@
+"""Turn two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; CSV output) into
+profiles/pmc_traffic.json: kernel family -> HBM bytes per launch.
+
+Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950
+FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced read, which is how
+every kernel here loads, so the read side is doubled.  WRITE_SIZE is taken as is (uncalibrated).
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+"""
+import csv
+import json
+import re
+import sys
+from collections import defaultdict
+
+
+def family(name):
+    m = re.search(r"(igemm_f32_kernel)<(\d+), *(\d+), *(\d+)>", name)
+    if m:
+        return "%s<%s,%s,%s>" % m.groups()
+    m = re.search(r"ccvpe::(\w+?)(<[^>]*>)?\(", name) or re.search(r"ccvpe::(\w+)", name)
+    return m.group(1) if m else None
+
+
+def collect(path, counter):
+    tot, cnt = defaultdict(float), defaultdict(int)
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row.get("Counter_Name") != counter:
+                continue
+            fam = family(row["Kernel_Name"])
+            if fam is None:
+                continue
+            tot[fam] += float(row["Counter_Value"])
+            cnt[fam] += 1
+    return {k: tot[k] / cnt[k] for k in tot}, cnt
+
+
+def main():
+    fetch, n1 = collect(sys.argv[1], "FETCH_SIZE")
+    write, n2 = collect(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in sorted(set(fetch) | set(write)):
+        rd = 2.0 * fetch.get(k, 0.0) * 1024.0
+        wr = write.get(k, 0.0) * 1024.0
+        out[k] = round(rd + wr)
+        out[k + "#detail"] = {"read_bytes_corrected_x2": round(rd), "write_bytes": round(wr),
+                              "launches_sampled": int(n1.get(k, 0))}
+    json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
+    print("wrote", sys.argv[3])
+
+
+if __name__ == "__main__":
+    main()
