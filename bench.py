@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket igemm launches with HIP events in the timed region")
@@ -98,29 +99,26 @@ def main():
     grd, sat = synth.synthetic_pair(args.batch, "vigor", 1234 + rank)
     grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    from ccvpe_amd import harness
+    if args.graph:
+        from ccvpe_amd.graph import GraphedForward
+        fwd = GraphedForward(net, grd, sat)
+        args.no_kernel_events = True            # events cannot be recorded inside a replayed graph
+    else:
+        fwd = net
+    rec = None if args.no_kernel_events else ops.LaunchRecorder()
+    state = {"n": 0}
 
-    for _ in range(args.warmup):
-        out = net(grd, sat)
-    rec = None
-    if not args.no_kernel_events:
-        rec = ops.LaunchRecorder()
-    barrier()
-    ops.set_recorder(rec)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = net(grd, sat)
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def step():
+        # the recorder is switched on after the warm-up steps so that it brackets exactly the
+        # igemm launches of the timed region
+        if state["n"] == args.warmup:
+            ops.set_recorder(rec)
+        state["n"] += 1
+        fwd(grd, sat)
+
+    elapsed = harness.timed_steps(step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=dev)
     ops.set_recorder(None)
-
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         pairs = args.batch * world * args.steps
@@ -135,6 +133,7 @@ def main():
                                    "grd 3x320x640 + sat 3x512x512, N_rot=1 loc / 20 ori",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
+                       "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per kernel)",
                        "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
         }
         roof = None

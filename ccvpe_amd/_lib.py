@@ -51,6 +51,7 @@ PROTOTYPES = {
                                       c_int, c_int, c_void_p]),
     "ccvpe_head_conv3x3_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "ccvpe_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ccvpe_eval_postprocess_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ccvpe_infonce_loss_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_cross_entropy_loss_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_orientation_loss_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),

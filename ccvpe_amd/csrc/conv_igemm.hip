@@ -2,22 +2,31 @@
 //
 //   out[m, n] = act((sum_k A[m, k] * Wp[n, k]) * scale[n] + shift[n]) (+ residual[m, n])
 //
-// m = output pixel (b, oy, ox); k = (tap, concat channel) walked in 8-channel chunks so that a
-// K-stage of 16 floats may straddle a tap or the boundary between the two concatenated sources.
-// Replaces F.conv2d / F.conv_transpose2d / nn.Linear call sites of the reference:
+// m = output pixel (b, oy, ox); k = (tap, concat channel).  Replaces the F.conv2d /
+// F.conv_transpose2d / nn.Linear call sites of the reference:
 // efficientnet_pytorch/model.py:104-106,121-130,299 ; models.py:42-47,57-97,102-148,173-184.
 //
-// Tile: 256 threads = 4 waves laid out WM x WN; each wave owns (16*MT) x (16*NT) outputs as MT*NT
-// accumulators of the 16x16x4 MFMA.  A and W stages ([rows][16 k] fp32) go global -> VGPR -> LDS
-// (register staging: the gather needs per-row predication, zero fill and the SE gate multiply,
-// which a lane-linear LDS-DMA cannot do) and are double buffered: the loads of stage s+1 are
-// issued before the MFMAs of stage s, the LDS writes after them, one barrier per stage.
+// Two kernels share the tile machinery:
+//   igemm_f32_kernel   — generic gather (1x1, 2x2/s2, deconv-as-GEMM): A and W stages
+//                        ([rows][16 k] fp32) go global -> VGPR -> LDS, double buffered.
+//   conv3x3_f32_kernel — 3x3 stride 1 pad 1 (double_conv, models.py:42-47): the input HALO tile
+//                        ((TH+2) x 18 pixels x 16 channels) is staged in LDS ONCE per channel chunk
+//                        and the 9 taps read their A fragments from it at shifted addresses, so the
+//                        activation is fetched from L2 once instead of 9 times (the per-tap re-read
+//                        made the N<=40 layers L2-bound in the first profile); only the W stage
+//                        changes per tap.  Reads cat[deconv_out, skip] as two sources.
+//
+// Tile: 256 threads = 4 waves laid out WM x WN; each wave owns (16*MT) pixels x (16*NT) channels as
+// MT*NT accumulators.  Operand roles are SWAPPED (W fragment is the MFMA "A" operand, the pixel
+// fragment the "B" operand) so that the C layout gives each lane 4 CONSECUTIVE OUTPUT CHANNELS of
+// one pixel: the epilogue is one dwordx4 store (and dwordx4 residual load) per accumulator instead
+// of four scalar ones — the HBM-bound 1x1 layers were store-issue bound before.
 // K permutation: lane group q = lane>>4 consumes k in {4q..4q+3} over the 4 MFMAs of a stage, so
-// each operand fragment is ONE ds_read_b128; A and W use the same map, so the sum is unchanged.
+// each operand fragment is ONE ds_read_b128; both operands use the same map.
 // LDS rows are padded 16 -> 20 floats (80 B: 16-byte aligned, breaks the 64 B power-of-two stride).
 //
-// The fp32 MFMA runs at the fp32 vector rate (157 TF peak); it is a bitwise k-ordered fmaf
-// chain, i.e. this kernel is exact fp32 (no TF32-like shortcut exists on gfx950).
+// The fp32 MFMA runs at the fp32 vector rate (157 TF peak) and is a bitwise k-ordered fmaf chain:
+// these kernels are exact fp32 (gfx950 has no TF32-like shortcut).
 #include "common.h"
 
 namespace ccvpe {
@@ -41,9 +50,43 @@ struct IgemmParams {
   int ldd, ldres, act, out_mode, cout;
   int M;
   int tiles_n, tiles_total;
+  int tiles_x, tiles_y;  // conv3x3: spatial tiles per sample
 };
 
 constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad)
+
+// XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
+// contiguous run of tiles (n fastest): the N-tiles that re-read one A panel, and spatially
+// adjacent tiles that share a halo, hit the same L2.
+__device__ __forceinline__ int xcd_tile(int bid, int total) {
+  const int q = total / 8, r = total % 8;
+  const int xcd = bid % 8, loc = bid / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// Epilogue for one accumulator: 4 consecutive channels n..n+3 of one pixel.
+__device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, size_t obase, size_t rbase,
+                                       const float* sc, const float* sh) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    float t = v[r] * sc[r] + sh[r];
+    if (p.act == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
+    else if (p.act == CCVPE_ACT_SWISH) t = t / (1.0f + expf(-t));
+    v[r] = t;
+  }
+  if (n + 3 < p.N) {
+    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + rbase + n);
+    *reinterpret_cast<f32x4*>(p.dst + obase) = v;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < p.N) {
+        float t = v[r];
+        if (p.residual) t += p.residual[rbase + n + r];
+        p.dst[obase + r] = t;
+      }
+  }
+}
 
 template <int MT, int NT, int WN>
 __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
@@ -62,16 +105,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
   const int wm = wave / WN;
   const int wn = wave % WN;
 
-  // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD
-  // a contiguous run of tiles (n fastest): the N-tiles that re-read one A panel share an L2.
-  int tile;
-  {
-    const int bid = blockIdx.x;
-    const int nx = 8;
-    const int q = p.tiles_total / nx, r = p.tiles_total % nx;
-    const int xcd = bid % nx, loc = bid / nx;
-    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-  }
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
   const int tm = tile / p.tiles_n;
   const int tn = tile % p.tiles_n;
   const int m0 = tm * BM;
@@ -102,7 +136,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
   // chunk cursor of this thread: kc = 2*stage + chunk_in_stage, decoded as (ky, kx, r)
   int kc = chunk_in_stage;
   int r = chunk_in_stage, ky = 0, kx = 0;
-  while (r >= p.cpt) {  // cpt may be 1 (never for our shapes, but keep it correct)
+  while (r >= p.cpt) {
     r -= p.cpt;
     if (++kx == p.kw) { kx = 0; ++ky; }
   }
@@ -110,7 +144,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
   f32x4 a_reg[A_IT], b_reg[B_IT];
 
   auto load_stage = [&](int s) {
-    // A operand
     const bool kvalid = kc < p.total_chunks;
     const bool from0 = r < p.cpt0;
     const float* base = from0 ? p.src0 : p.src1;
@@ -132,7 +165,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
       }
       a_reg[it] = v;
     }
-    // W operand
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
@@ -141,7 +173,6 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
         v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(n0 + nrow) * p.Kpad + s * 16 + ssub * 4);
       b_reg[it] = v;
     }
-    // advance the chunk cursor by one stage (2 chunks)
     kc += 2;
     r += 2;
     while (r >= p.cpt) {
@@ -192,59 +223,230 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
       for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
 
     if (more) store_stage(buf ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue: C layout of the 16x16 MFMA: col = lane&15, row = (lane>>4)*4 + reg -----------
-  const int ecol = lane & 15;
-  const int erow = (lane >> 4) * 4;
-  float sc[NT], sh[NT];
-  int ncol[NT];
+  // ---- epilogue: swapped roles => D rows = channels ((lane>>4)*4 + reg), D cols = pixels (lane&15)
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
+  float sc[NT][4], sh[NT][4];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + (wn * NT + j) * 16 + ecol;
-    ncol[j] = n;
-    const bool ok = n < p.N;
-    sc[j] = (ok && p.scale) ? p.scale[n] : 1.0f;
-    sh[j] = (ok && p.shift) ? p.shift[n] : 0.0f;
-  }
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + (wn * NT + j) * 16 + en + q;
+      const bool ok = n < p.N;
+      sc[j][q] = (ok && p.scale) ? p.scale[n] : 1.0f;
+      sh[j][q] = (ok && p.shift) ? p.shift[n] : 0.0f;
+    }
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
+    const int m = m0 + (wm * MT + i) * 16 + epix;
+    if (m >= p.M) continue;
+    size_t pbase = 0;
+    if (p.out_mode == CCVPE_OUT_DECONV2X) {
+      const int hw = p.Ho * p.Wo;
+      const int b = m / hw;
+      const int rem = m - b * hw;
+      const int y = rem / p.Wo;
+      const int x = rem - y * p.Wo;
+      pbase = ((size_t)(b * 2 * p.Ho + 2 * y) * (2 * p.Wo) + 2 * x) * p.ldd;
+    }
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const int m = m0 + (wm * MT + i) * 16 + erow + rg;
-      if (m >= p.M) continue;
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + (wn * NT + j) * 16 + en;
+      if (n >= p.N) continue;
       size_t obase;
       if (p.out_mode == CCVPE_OUT_NHWC) {
-        obase = (size_t)m * p.ldd;
+        obase = (size_t)m * p.ldd + n;
       } else {
-        const int hw = p.Ho * p.Wo;
-        const int b = m / hw;
-        const int rem = m - b * hw;
-        const int y = rem / p.Wo;
-        const int x = rem - y * p.Wo;
-        obase = ((size_t)(b * 2 * p.Ho + 2 * y) * (2 * p.Wo) + 2 * x) * p.ldd;
+        const int quad = n / p.cout;
+        const int co = n - quad * p.cout;
+        obase = pbase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
       }
+      store4(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// 3x3, stride 1, pad 1, two concatenated sources, halo tile in LDS.
+// Pixel tile = TH rows x 16 columns (one MFMA tile = 16 consecutive x of one row), TH = BM/16.
+// Stage s = (chunk, tap): chunk = 16 consecutive concat channels, tap = ky*3+kx.
+// ---------------------------------------------------------------------------------------------
+template <int MT, int NT, int WN>
+__global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NT * WN;
+  constexpr int TH = BM / 16;
+  constexpr int HR = TH + 2;                       // halo rows
+  constexpr int HC = 18;                           // halo columns
+  constexpr int HPX = HR * HC;
+  constexpr int H_IT = (HPX * 4 + 255) / 256;      // float4 loads per thread per chunk (halo)
+  constexpr int B_IT = (BN + 63) / 64;
+
+  // halo is single-buffered (one extra barrier per 9 stages) to keep LDS <= ~40 KB -> 3-4 blocks/CU
+  __shared__ __attribute__((aligned(16))) float Hs[HPX][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
+  const int tn = tile % p.tiles_n;
+  const int ts = tile / p.tiles_n;                 // spatial tile id: x fastest, then y, then sample
+  const int tx = ts % p.tiles_x;
+  const int ty = (ts / p.tiles_x) % p.tiles_y;
+  const int b = ts / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = tn * BN;
+  const int ctot = p.c0 + p.c1;
+  const int nchunks = (ctot + 15) >> 4;
+  const int nstages = nchunks * 9;
+
+  // halo staging coordinates (fixed per thread)
+  int h_off[H_IT];     // LDS float offset, -1 if this slot is unused
+  int h_pix[H_IT];     // global pixel index (b*H+iy)*W+ix, -1 if outside the image
+  int h_sub[H_IT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int n = ncol[j];
-        if (n >= p.N) continue;
-        float v = acc[i][j][rg] * sc[j] + sh[j];
-        if (p.act == CCVPE_ACT_RELU) v = fmaxf(v, 0.0f);
-        else if (p.act == CCVPE_ACT_SWISH) v = v / (1.0f + expf(-v));
-        if (p.out_mode == CCVPE_OUT_NHWC) {
-          if (p.residual) v += p.residual[(size_t)m * p.ldres + n];
-          p.dst[obase + n] = v;
-        } else {
-          const int quad = n / p.cout;
-          const int co = n - quad * p.cout;
-          const size_t o = obase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
-          p.dst[o] = v;
-        }
+  for (int it = 0; it < H_IT; ++it) {
+    const int idx = tid + 256 * it;
+    const int px = idx >> 2, sub = idx & 3;
+    h_sub[it] = sub;
+    if (px < HPX) {
+      const int hy = px / HC, hx = px - hy * HC;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      h_off[it] = px * LDS_LD + sub * 4;
+      h_pix[it] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (b * p.H + iy) * p.W + ix : -1;
+    } else {
+      h_off[it] = -1;
+      h_pix[it] = -1;
+    }
+  }
+  const int srow = tid >> 2, ssub = tid & 3;
+
+  f32x4 h_reg[H_IT], b_reg[B_IT];
+
+  auto load_halo = [&](int chunk) {
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      const int ch = chunk * 16 + h_sub[it] * 4;
+      if (h_pix[it] >= 0 && ch < ctot) {
+        const bool from0 = ch < p.c0;
+        const float* base = from0 ? p.src0 : p.src1;
+        const size_t off = (size_t)h_pix[it] * (from0 ? p.ld0 : p.ld1) + (from0 ? ch : ch - p.c0);
+        v = *reinterpret_cast<const f32x4*>(base + off);
       }
+      h_reg[it] = v;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it)
+      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Hs[0][0] + h_off[it]) = h_reg[it];
+  };
+  auto load_w = [&](int chunk, int tap) {
+    const int ch = chunk * 16 + ssub * 4;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = srow + 64 * it;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
+        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
+      b_reg[it] = v;
+    }
+  };
+  auto store_w = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = srow + 64 * it;
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 4;
+
+  load_halo(0);
+  load_w(0, 0);
+  store_halo();
+  store_w(0);
+  __syncthreads();
+
+  int chunk = 0, tap = 0;
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    int nchunk = chunk, ntap = tap + 1;
+    if (ntap == 9) { ntap = 0; ++nchunk; }
+    const bool next_halo = (tap == 0) && (chunk + 1 < nchunks);
+    if (more) load_w(nchunk, ntap);
+    if (next_halo) load_halo(chunk + 1);
+
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const float* hb = &Hs[0][0];
+    f32x4 af[MT], bf[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      af[i] = *reinterpret_cast<const f32x4*>(hb + (((wm * MT + i) + ky) * HC + frow + kx) * LDS_LD + fk);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][fk]);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+
+    if (more) store_w((s + 1) & 1);
+    __syncthreads();
+    if (tap == 8 && more) {   // chunk boundary: every wave is done reading the halo -> overwrite it
+      store_halo();
+      __syncthreads();
+    }
+    chunk = nchunk;
+    tap = ntap;
+  }
+
+  // ---- epilogue ---------------------------------------------------------------------------------
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
+  float sc[NT][4], sh[NT][4];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int n = n0 + (wn * NT + j) * 16 + en + q;
+      const bool ok = n < p.N;
+      sc[j][q] = (ok && p.scale) ? p.scale[n] : 1.0f;
+      sh[j][q] = (ok && p.shift) ? p.shift[n] : 0.0f;
+    }
+  const int ox = x0 + epix;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int oy = y0 + wm * MT + i;
+    if (oy >= p.H || ox >= p.W) continue;
+    const size_t m = (size_t)(b * p.H + oy) * p.W + ox;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + (wn * NT + j) * 16 + en;
+      if (n >= p.N) continue;
+      store4(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc[j], sh[j]);
     }
   }
 }
@@ -262,6 +464,23 @@ static int launch(const IgemmParams& p0, hipStream_t stream) {
   return check_launch("igemm_f32_kernel");
 }
 
+template <int MT, int NT, int WN>
+static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NT * WN;
+  constexpr int TH = BM / 16;
+  IgemmParams p = p0;
+  p.tiles_x = (p.W + 15) / 16;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  p.tiles_n = (p.Npad + BN - 1) / BN;
+  const long total = (long)p.tiles_x * p.tiles_y * batch * p.tiles_n;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv3x3: grid too large");
+  p.tiles_total = (int)total;
+  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
+  return check_launch("conv3x3_f32_kernel");
+}
+
 // Pick the N tile that wastes the fewest MFMA columns, then the widest.
 struct TileCfg { int mt, nt, wn; };
 static const TileCfg kCfgs[] = {
@@ -276,7 +495,6 @@ static int pick_cfg(int npad16) {
   for (int i = 0; i < (int)(sizeof(kCfgs) / sizeof(kCfgs[0])); ++i) {
     const int bn = 16 * kCfgs[i].nt * kCfgs[i].wn;
     const int tiles = (npad16 + bn - 1) / bn;
-    // cost: padded columns first, then prefer wide tiles (fewer A re-reads)
     const long cost = (long)tiles * bn * 1000 + (1000 - bn);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best = i; }
   }
@@ -292,10 +510,10 @@ extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   if (d->c0 <= 0 || d->c0 % 8 || d->c1 < 0 || d->c1 % 8)
     return fail(CCVPE_EINVAL, "conv_igemm: c0/c1 must be multiples of 8 (got %d,%d)", d->c0, d->c1);
   if (d->c1 > 0 && !d->src1) return fail(CCVPE_EINVAL, "conv_igemm: c1>0 but src1 null");
-  if (d->ld0 % 4 || (d->c1 && d->ld1 % 4) || d->kpad % 16)
-    return fail(CCVPE_EINVAL, "conv_igemm: ld0/ld1 %% 4, kpad %% 16 required");
+  if (d->ld0 % 4 || (d->c1 && d->ld1 % 4) || d->kpad % 16 || d->ldd % 4 || (d->residual && d->ldres % 4))
+    return fail(CCVPE_EINVAL, "conv_igemm: ld0/ld1/ldd/ldres %% 4, kpad %% 16 required");
   if (!aligned16(d->src0) || (d->src1 && !aligned16(d->src1)) || !aligned16(d->w) ||
-      (d->gate && !aligned16(d->gate)))
+      (d->gate && !aligned16(d->gate)) || !aligned16(d->dst) || (d->residual && !aligned16(d->residual)))
     return fail(CCVPE_EINVAL, "conv_igemm: pointers must be 16-byte aligned");
   if (d->gate && (d->kh != 1 || d->c1 != 0)) return fail(CCVPE_EINVAL, "conv_igemm: gate only for 1x1 single-source");
   if (d->stride < 1 || d->kh < 1 || d->kw < 1) return fail(CCVPE_EINVAL, "conv_igemm: bad kernel/stride");
@@ -314,16 +532,22 @@ extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   p.stages = (p.total_chunks + 1) / 2;
   p.ldd = d->ldd; p.ldres = d->ldres; p.act = d->act; p.out_mode = d->out_mode;
   p.cout = (d->out_mode == CCVPE_OUT_DECONV2X) ? d->n / 4 : d->n;
-  if (d->out_mode == CCVPE_OUT_DECONV2X && (d->n % 4 || d->residual))
-    return fail(CCVPE_EINVAL, "conv_igemm: deconv mode needs n%%4==0 and no residual");
+  if (d->out_mode == CCVPE_OUT_DECONV2X && (d->n % 16 || d->residual))
+    return fail(CCVPE_EINVAL, "conv_igemm: deconv mode needs cout%%4==0 and no residual");
   const long M = (long)d->batch * p.Ho * p.Wo;
   if (M <= 0 || M > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv_igemm: bad M");
+  if ((long)d->batch * d->in_h * d->in_w > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv_igemm: too many pixels");
   p.M = (int)M;
-  p.tiles_n = p.tiles_total = 0;
+  p.tiles_n = p.tiles_total = p.tiles_x = p.tiles_y = 0;
   hipStream_t st = (hipStream_t)stream;
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
-#define CCVPE_CASE(MT_, NT_, WN_) \
-  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) return launch<MT_, NT_, WN_>(p, st);
+  const bool is3x3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
+                     d->out_mode == CCVPE_OUT_NHWC && !d->gate;
+#define CCVPE_CASE(MT_, NT_, WN_)                                    \
+  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                   \
+    if (is3x3) return launch3x3<MT_, NT_, WN_>(p, d->batch, st);     \
+    return launch<MT_, NT_, WN_>(p, st);                             \
+  }
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)
   CCVPE_CASE(4, 5, 1) CCVPE_CASE(4, 3, 1) CCVPE_CASE(4, 1, 1) CCVPE_CASE(2, 7, 1)
 #undef CCVPE_CASE

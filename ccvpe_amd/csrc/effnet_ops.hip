@@ -240,7 +240,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float s = b2[c];
-    for (int j = 0; j < Cs; ++j) s = fmaf(w2[(size_t)c * Cs + j], z[j], s);
+    for (int j = 0; j < Cs; ++j) s = fmaf(w2[(size_t)j * C + c], z[j], s);   // w2 is [Cs][C]: coalesced over c
     gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
   }
 }

@@ -223,6 +223,46 @@ __global__ __launch_bounds__(1024) void ori_rows_kernel(const float* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Eval post-processing (train_VIGOR.py:294-324): arg-max pixel (first maximum), orientation there,
+// acos-based angle.  One workgroup per sample; ties resolve to the smallest index like numpy.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void eval_post_kernel(const float* __restrict__ heat, const float* __restrict__ ori,
+                                                         float* __restrict__ out, int h, int w) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  const int n = h * w;
+  const float* r = heat + (size_t)blockIdx.x * n;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float v = r[i];
+    if (v > best) { best = v; bi = i; }          // strided scan keeps the smallest index per thread
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+  }
+  if ((threadIdx.x & 63) == 0) { sv[threadIdx.x >> 6] = best; si[threadIdx.x >> 6] = bi; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < (int)(blockDim.x >> 6); ++k)
+      if (sv[k] > best || (sv[k] == best && si[k] < bi)) { best = sv[k]; bi = si[k]; }
+    if (bi == 0x7fffffff) bi = 0;
+    const float c = ori[((size_t)blockIdx.x * 2 + 0) * n + bi];
+    const float s = ori[((size_t)blockIdx.x * 2 + 1) * n + bi];
+    float ang = NAN;
+    if (fabsf(c) <= 1.0f && fabsf(s) <= 1.0f) {
+      const float a = acosf(c) * 57.29577951308232f;
+      ang = (s < 0.0f) ? fmodf(360.0f - a, 360.0f) : a;   // degrees(-a) % 360 in Python
+    }
+    float* o = out + (size_t)blockIdx.x * 6;
+    o[0] = (float)(bi / w); o[1] = (float)(bi % w); o[2] = c; o[3] = s; o[4] = ang; o[5] = best;
+  }
+}
+
 // mode 0: -sum(num)/sum(den) ; mode 1: -sum(num)/B ; mode 2: +sum(num)/B
 __global__ void loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, int B, int mode) {
   float num = 0.f, den = 0.f;
@@ -280,6 +320,13 @@ extern "C" int ccvpe_softmax_rows_f32(const float* in, float* out, int rows, int
   if (!aligned16(in) || !aligned16(out) || (n % 4)) return fail(CCVPE_EINVAL, "softmax: 16-byte aligned rows required");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, in, out, n);
   return check_launch("softmax_rows_kernel");
+}
+
+extern "C" int ccvpe_eval_postprocess_f32(const float* heatmap, const float* ori, float* out, int B, int h, int w,
+                                          void* stream) {
+  if (B <= 0 || h <= 0 || w <= 0) return fail(CCVPE_EINVAL, "eval_postprocess: bad shape");
+  hipLaunchKernelGGL(eval_post_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, heatmap, ori, out, h, w);
+  return check_launch("eval_post_kernel");
 }
 
 extern "C" int ccvpe_infonce_loss_f32(const float* scores, const float* labels, float temperature, float* loss,

@@ -99,7 +99,7 @@ def _pack_encoder(sd, p):
         b.s1, b.b1 = _fold_bn(sd, bp + "._bn1")
         b.se_w1 = sd[bp + "._se_reduce.weight"].reshape(-1, b.mid).contiguous()
         b.se_b1 = sd[bp + "._se_reduce.bias"].contiguous()
-        b.se_w2 = sd[bp + "._se_expand.weight"].reshape(b.mid, -1).contiguous()
+        b.se_w2 = sd[bp + "._se_expand.weight"].reshape(b.mid, -1).t().contiguous()      # [Cs][C]
         b.se_b2 = sd[bp + "._se_expand.bias"].contiguous()
         b.w_proj = _pack_conv(sd[bp + "._project_conv.weight"])
         b.s2, b.b2 = _fold_bn(sd, bp + "._bn2")

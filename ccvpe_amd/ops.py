@@ -52,7 +52,7 @@ class LaunchRecorder(object):
         return out
 
 
-def igemm_tile(n):
+def igemm_tile(n, is3x3=False):
     """Mirror of pick_cfg() in csrc/conv_igemm.hip: (BM, BN) chosen for a GEMM N (reporting only)."""
     npad = (n + 15) // 16 * 16
     cfgs = [(4, 5, 2), (4, 4, 2), (4, 3, 2), (4, 2, 2), (4, 1, 2), (4, 5, 1), (4, 3, 1), (4, 1, 1), (2, 7, 1)]
@@ -64,7 +64,7 @@ def igemm_tile(n):
         if best_cost is None or cost < best_cost:
             best, best_cost = (mt, nt, wn), cost
     mt, nt, wn = best
-    return "igemm_f32_kernel<%d,%d,%d>" % (mt, nt, wn)
+    return "%s<%d,%d,%d>" % ("conv3x3_f32_kernel" if is3x3 else "igemm_f32_kernel", mt, nt, wn)
 
 
 def _stream():
@@ -128,7 +128,8 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         # algorithmic bytes: input read once, output written once, weights once
         nbytes = 4.0 * (batch * in_h * in_w * (c0 + c1) + m * n + n * k_alg
                         + (m * n if residual is not None else 0))
-        rec.end(igemm_tile(n), "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
+        is3x3 = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and out_mode == OUT_NHWC and gate is None)
+        rec.end(igemm_tile(n, is3x3), "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
     return dst
 
 
@@ -226,6 +227,18 @@ def softmax_rows(logits):
     rows, n = logits.shape
     out = torch.empty_like(logits)
     check(lib.ccvpe_softmax_rows_f32(_ptr(logits), _ptr(out), rows, n, _stream()), "ccvpe_softmax_rows_f32")
+    return out
+
+
+def eval_postprocess(heatmap, ori):
+    """train_VIGOR.py:294-324 on the device: returns [B,6] = (y, x, cos, sin, angle_deg, prob)."""
+    lib = _lib.load()
+    _chk(heatmap, "heatmap")
+    _chk(ori, "ori")
+    b, _, h, w = heatmap.shape
+    out = torch.empty((b, 6), device=heatmap.device, dtype=torch.float32)
+    check(lib.ccvpe_eval_postprocess_f32(_ptr(heatmap), _ptr(ori), _ptr(out), b, h, w, _stream()),
+          "ccvpe_eval_postprocess_f32")
     return out
 
 

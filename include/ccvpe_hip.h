@@ -108,7 +108,7 @@ int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const f
                      int circular, void* stream);
 
 /* Squeeze-excite gate: mean -> 1x1 (C->Cs) + swish -> 1x1 (Cs->C) -> sigmoid.
- * efficientnet_pytorch/model.py:113-118.  w1 [Cs][C], w2 [C][Cs], gate [B][C]. */
+ * efficientnet_pytorch/model.py:113-118.  w1 [Cs][C], w2 TRANSPOSED [Cs][C], gate [B][C]. */
 int ccvpe_se_gate_f32(const float* se_partial, int nblk, float inv_hw, const float* w1, const float* b1,
                       const float* w2, const float* b2, float* gate, int batch, int channels,
                       int squeezed, void* stream);
@@ -148,6 +148,16 @@ int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, fl
 
 /* Row softmax over n columns (models.py:319-320: Softmax over the 262144 flattened logits). */
 int ccvpe_softmax_rows_f32(const float* logits, float* out, int rows, int n, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * Evaluation post-processing on the device (train_VIGOR.py:294-324, train_KITTI.py:304-343): per
+ * sample the arg-max pixel of the heat-map (first maximum, as numpy.argmax), the orientation
+ * vector there and the acos-based angle in degrees — 6 floats per sample instead of a 3 MB D2H
+ * copy of the full maps:   out[b] = { y, x, cos, sin, angle_deg (NaN if |cos|>1 or |sin|>1), prob }.
+ *   heatmap [B,h*w], ori [B,2,h*w] (NCHW), out [B,6]
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_eval_postprocess_f32(const float* heatmap, const float* ori, float* out, int batch, int h, int w,
+                               void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Losses (losses.py:4-29), device scalars out.  `acc` is caller-provided scratch.

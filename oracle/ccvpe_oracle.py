@@ -265,3 +265,25 @@ def cross_entropy_loss(logits, labels):
 def orientation_loss(ori, gt_orientation, gt):
     """losses.py:28-29."""
     return (((gt_orientation - ori) ** 2).sum(dim=1, keepdim=True) * gt).sum() / ori.shape[0]
+
+
+# ----------------------------------------------------------------------------------------
+# evaluation post-processing
+# ----------------------------------------------------------------------------------------
+def eval_postprocess(heatmap, ori):
+    """train_VIGOR.py:294-324 (train_KITTI.py:304-343 is the same): per sample the arg-max pixel
+    of the heat-map (numpy argmax = first maximum), (cos, sin) there and the acos-based angle.
+    Returns [B,6] = (y, x, cos, sin, angle_deg or NaN, prob)."""
+    B, _, H, W = heatmap.shape
+    out = torch.empty((B, 6), dtype=torch.float32)
+    for b in range(B):
+        flat = heatmap[b].reshape(-1)
+        idx = int(flat.numpy().argmax())
+        y, x = idx // W, idx % W
+        c, s = float(ori[b, 0, y, x]), float(ori[b, 1, y, x])
+        ang = float("nan")
+        if abs(c) <= 1 and abs(s) <= 1:
+            a = math.acos(c)
+            ang = math.degrees(-a) % 360 if s < 0 else math.degrees(a)
+        out[b] = torch.tensor([y, x, c, s, ang, float(flat[idx])])
+    return out

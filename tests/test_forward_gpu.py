@@ -104,3 +104,24 @@ def test_train_mode_raises(synth_sd):
     grd, sat = synth.synthetic_pair(1, "vigor", 3)
     with pytest.raises(NotImplementedError):
         net(grd.cuda(), sat.cuda())
+
+
+def test_hipgraph_replay_is_bit_identical(synth_sd):
+    """BASELINE C4: hipGraph-captured inference.  Same kernels, same order => identical bits."""
+    from ccvpe_amd.graph import GraphedForward
+    case = dict(kind="vigor", ori_noise=180, circular=False, wseed=0, grd="vigor_fov180")
+    net = build(case, synth_sd)
+    grd, sat = synth.synthetic_pair(2, "vigor_fov180", 17)
+    grd, sat = grd.cuda(), sat.cuda()
+    eager = [t.clone() for t in net(grd, sat)]
+    g = GraphedForward(net, grd, sat)
+    out = g(grd, sat)
+    torch.cuda.synchronize()
+    for a, b in zip(out, eager):
+        assert torch.equal(a, b)
+    # new inputs through the same graph
+    grd2, sat2 = synth.synthetic_pair(2, "vigor_fov180", 18)
+    out2 = [t.clone() for t in g(grd2.cuda(), sat2.cuda())]
+    eager2 = net(grd2.cuda(), sat2.cuda())
+    for a, b in zip(out2, eager2):
+        assert torch.equal(a, b)

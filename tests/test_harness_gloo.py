@@ -1,0 +1,57 @@
+"""N>1 path on CPU: two processes over gloo exercise the replica harness bench.py uses
+(barrier-bracketed timing, MAX over ranks, whole-job aggregation, sample sharding)."""
+import os
+import socket
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccvpe_amd import harness
+    import time
+    calls = []
+
+    def step():
+        calls.append(1)
+        time.sleep(0.02 * (rank + 1))         # rank 1 is the slow one
+
+    elapsed = harness.timed_steps(step, steps=5, warmup=2)
+    thr = harness.aggregate_throughput(4, 5, elapsed)
+    shard = harness.shard_indices(11, world, rank)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (len(calls), elapsed, thr, shard))
+    if rank == 0:
+        torch.save(gathered, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_replica_harness(tmp_path):
+    out = str(tmp_path / "res.pt")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=False)
+    (c0, e0, t0, s0), (c1, e1, t1, s1) = res
+    assert c0 == c1 == 7                                  # 2 warm-up + exactly 5 timed steps each
+    assert abs(e0 - e1) < 1e-9                            # both ranks hold the MAX
+    assert e0 >= 5 * 0.04 * 0.9                           # ... which is the slow rank's time
+    assert abs(t0 - 4 * 2 * 5 / e0) < 1e-9                # whole-job units / slowest time
+    assert sorted(s0 + s1) == list(range(11)) and not set(s0) & set(s1)
+    assert len(s0) == 6 and len(s1) == 5

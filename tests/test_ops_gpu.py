@@ -162,7 +162,7 @@ def test_se_gate(ops):
     mean = part.sum(1) / 35.0
     z = O.swish(mean @ w1.t() + b1)
     want = torch.sigmoid(z @ w2.t() + b2)
-    got = ops.se_gate(dev(part), 35, dev(w1), dev(b1), dev(w2), dev(b2))
+    got = ops.se_gate(dev(part), 35, dev(w1), dev(b1), dev(w2.t()), dev(b2))
     close(got, want, 1e-5, "se gate")
 
 
@@ -286,3 +286,18 @@ def test_losses_golden(ops):
     gto = F.normalize(synth.normal((3, 2, 512, 512), 8301), dim=1)
     got = ops.orientation_loss(dev(ori), dev(gto), dev(lab.reshape(3, 1, 512, 512))).item()
     G.assert_close(got, want["ori"], 1e-4, 0, "ori loss")
+
+
+def test_eval_postprocess(ops):
+    b = 4
+    heat = torch.softmax(synth.normal((b, 512 * 512), 95, 3.0), dim=1).reshape(b, 1, 512, 512)
+    heat[1, 0, 100, 7] = heat[1].max() + 0.1          # clear peak
+    heat[2, 0, 5, 9] = 0.5; heat[2, 0, 300, 300] = 0.5   # tie -> first index wins (numpy.argmax)
+    ori = F.normalize(synth.normal((b, 2, 512, 512), 96), dim=1)
+    got = ops.eval_postprocess(dev(heat), dev(ori)).cpu()
+    want = O.eval_postprocess(heat, ori)
+    assert torch.equal(got[:, :2], want[:, :2])
+    assert got[2, 0] == 5 and got[2, 1] == 9
+    close(got[:, 2:4], want[:, 2:4], 1e-6, "cos/sin")
+    assert (got[:, 4] - want[:, 4]).abs().max() < 1e-2   # degrees (acosf vs libm acos in fp64)
+    close(got[:, 5], want[:, 5], 1e-6, "prob")

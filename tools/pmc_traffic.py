@@ -14,7 +14,7 @@ from collections import defaultdict
 
 
 def family(name):
-    m = re.search(r"(igemm_f32_kernel)<(\d+), *(\d+), *(\d+)>", name)
+    m = re.search(r"(igemm_f32_kernel|conv3x3_f32_kernel)<(\d+), *(\d+), *(\d+)>", name)
     if m:
         return "%s<%s,%s,%s>" % m.groups()
     m = re.search(r"ccvpe::(\w+?)(<[^>]*>)?\(", name) or re.search(r"ccvpe::(\w+)", name)
