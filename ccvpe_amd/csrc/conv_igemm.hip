@@ -71,7 +71,7 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
   for (int r = 0; r < 4; ++r) {
     float t = v[r] * sc[r] + sh[r];
     if (p.act == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
-    else if (p.act == CCVPE_ACT_SWISH) t = t / (1.0f + expf(-t));
+    else if (p.act == CCVPE_ACT_SWISH) t = swishf(t);
     v[r] = t;
   }
   if (n + 3 < p.N) {

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) {
       const int c = c4 * 4 + j;
       const float v = acc[c] * ssc[c] + ssh[c];
-      o[j] = v / (1.0f + expf(-v));
+      o[j] = swishf(v);
     }
     out[c4] = o;
   }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
       if (ox < Wo) {
         f32x4 v = acc[t] * sc + sh;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = v[j] / (1.0f + expf(-v[j]));
+        for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
         *reinterpret_cast<f32x4*>(yb + (size_t)ox * C) = v;
         sum += v;
       }
@@ -195,8 +195,12 @@ static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* 
 }
 
 // ---------------------------------------------------------------------------------------------
-// SE gate (model.py:113-118): one workgroup per sample.
+// SE gate (model.py:113-118): gate = sigmoid(W2 . swish(W1 . mean + b1) + b2).
+// Latency-bound (a few 100 KFLOP per sample), so the work is spread over G workgroups per sample:
+// each recomputes the cheap squeeze (mean) and FC1 and owns a 128-channel slice of FC2.
 // ---------------------------------------------------------------------------------------------
+constexpr int SE_SLICE = 128;
+
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int nblk, float inv_hw,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   float* mean = sm;
   float* z = sm + C;
   float* red = z + Cs;
-  const int b = blockIdx.x;
+  const int b = blockIdx.y;
   const int tid = threadIdx.x;
   // partial rows are summed by R thread-rows in parallel (fixed assignment => deterministic)
   const int cw = C < 256 ? C : 256;
@@ -213,12 +217,19 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   for (int c0 = 0; c0 < C; c0 += cw) {
     const int cl = tid % cw, rr = tid / cw;
     const int c = c0 + cl;
-    float s = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (rr < R && c < C) {
       const float* p = part + (size_t)b * nblk * C + c;
-      for (int q = rr; q < nblk; q += R) s += p[(size_t)q * C];
+      int q = rr;
+      for (; q + 3 * R < nblk; q += 4 * R) {     // 4 independent loads in flight
+        s0 += p[(size_t)q * C];
+        s1 += p[(size_t)(q + R) * C];
+        s2 += p[(size_t)(q + 2 * R) * C];
+        s3 += p[(size_t)(q + 3 * R) * C];
+      }
+      for (; q < nblk; q += R) s0 += p[(size_t)q * C];
     }
-    red[tid] = s;
+    red[tid] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (rr == 0 && c < C) {
       float t = red[cl];
@@ -232,17 +243,18 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)j * C + c], mean[c], s);
     s = wave_sum(s);
-    if (lane == 0) {
-      const float v = s + b1[j];
-      z[j] = v / (1.0f + expf(-v));
-    }
+    if (lane == 0) z[j] = swishf(s + b1[j]);
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float s = b2[c];
-    for (int j = 0; j < Cs; ++j) s = fmaf(w2[(size_t)j * C + c], z[j], s);   // w2 is [Cs][C]: coalesced over c
-    gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
-  }
+  // FC2 slice: 2 threads per channel split the Cs sum (w2 is [Cs][C]: coalesced over c)
+  const int c = blockIdx.x * SE_SLICE + (tid & (SE_SLICE - 1));
+  const int hsel = tid >> 7;                 // 0 or 1
+  float s = 0.f;
+  if (c < C)
+    for (int j = hsel; j < Cs; j += 2) s = fmaf(w2[(size_t)j * C + c], z[j], s);
+  red[tid] = s;
+  __syncthreads();
+  if (hsel == 0 && c < C) gate[(size_t)b * C + c] = sigmoidf(red[tid] + red[tid + SE_SLICE] + b2[c]);
 }
 
 }  // namespace ccvpe
@@ -299,7 +311,7 @@ extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, cons
                                  const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
   if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
   const size_t smem = (size_t)(C + Cs + 256) * sizeof(float);
-  hipLaunchKernelGGL(se_gate_kernel, dim3(B), dim3(256), smem, (hipStream_t)stream, part, nblk, inv_hw, w1, b1, w2, b2,
-                     gate, C, Cs);
+  hipLaunchKernelGGL(se_gate_kernel, dim3((C + SE_SLICE - 1) / SE_SLICE, B), dim3(256), smem, (hipStream_t)stream, part,
+                     nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs);
   return check_launch("se_gate_kernel");
 }

@@ -1,0 +1,265 @@
+// Fused MBConv front half: expand 1x1 + BN0 + swish -> depthwise KxK (stride S) + BN1 + swish, plus
+// the SE squeeze partial sums.  efficientnet_pytorch/model.py:102-110,114.
+//
+// Why: the 6x-expanded tensor is the largest in the network (25 MB fp32 per aerial sample at block 1)
+// and the unfused path writes it and reads it back (about half of all encoder HBM bytes).  Here it
+// lives only in LDS.
+//
+// Mapping: a workgroup owns (sample b, 16-channel chunk of `mid`, band of RB output rows).
+//   * expand phase: one FULL-WIDTH input row at a time.  Wave w takes 16-pixel tiles w, w+4, ...;
+//     the x fragment is loaded straight from HBM in MFMA operand layout (lane = pixel l&15, k group
+//     l>>4 -> one dwordx4 of 4 consecutive input channels; 16 pixels x 64 B contiguous), the 16xCin
+//     weight fragment stays in registers, v_mfma_f32_16x16x4_f32 accumulates, BN0+swish, and the
+//     result is written as one ds_write_b128 per lane into a ring of K rows [W][16] in LDS.
+//     Rows outside the image are ZERO rows (the depthwise conv pads the EXPANDED tensor).
+//   * depthwise phase: thread = (4 channels, pixel); KxK taps read the ring (horizontal circular
+//     padding is an index wrap because the ring holds full rows; no halo recompute), BN1+swish,
+//     dwordx4 store, running per-channel sum for the squeeze.
+// Vertical overlap between bands costs (K-S)/(RB*S) extra expand rows.
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MbFrontParams {
+  const float* x;
+  const float* w_exp;
+  const float* s0;
+  const float* b0;
+  const float* w_dw;
+  const float* s1;
+  const float* b1;
+  float* y;
+  float* se_partial;
+  int H, W, Cin, kpad, mid, Ho, Wo, circular;
+  int rb, nbands, nchunks, total_blocks;
+};
+
+constexpr int MBF_MAX_KK = 3;   // Cin <= 48
+constexpr int MBF_MAXT = 5;     // 16-pixel tiles per wave per row: W <= 320
+// The kernel is instantiated per (tiles per wave T, k-chunks NKK) so that the register-resident row
+// costs T*NKK dwordx4 only: narrow rows keep their occupancy (a fixed T=5 needed 199 VGPRs).
+
+template <int K, int S, int T, int NKK>
+__global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;   // pad before (224-schedule SAME)
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* ring = sm;                                  // [K][W][16]
+  float* wdw = ring + max(K * p.W * 16, 1024);       // [K*K][16] (ring region >= 1024 floats: red aliases it)
+  float* red = ring;                                 // [256][4], aliases the ring after the last row
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  int lb;
+  {
+    const int q = p.total_blocks / 8, r = p.total_blocks % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int chunk = lb % p.nchunks;                  // chunk fastest: neighbours re-read the same x rows
+  const int band = (lb / p.nchunks) % p.nbands;
+  const int b = lb / (p.nchunks * p.nbands);
+  const int c0 = chunk * 16;
+  const int oy0 = band * p.rb;
+  const int oy1 = min(oy0 + p.rb, p.Ho);
+  const int r_begin = oy0 * S - PB;
+
+  // depthwise weights of this chunk -> LDS
+  for (int i = tid; i < K * K * 16; i += 256) wdw[i] = p.w_dw[(size_t)(i >> 4) * p.mid + c0 + (i & 15)];
+
+  // expand weights (MFMA A operand: row n = lane&15, k group = lane>>4) and BN0 in registers
+  const int q4 = (lane >> 4) * 4;
+  constexpr int nkk = NKK;
+  f32x4 wf[NKK];
+#pragma unroll
+  for (int kk = 0; kk < NKK; ++kk) {
+    wf[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (kk < nkk) wf[kk] = *reinterpret_cast<const f32x4*>(p.w_exp + (size_t)(c0 + (lane & 15)) * p.kpad + kk * 16 + q4);
+  }
+  const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.s0 + c0 + q4);
+  const f32x4 sh0 = *reinterpret_cast<const f32x4*>(p.b0 + c0 + q4);
+
+  const int ntile = (p.W + 15) >> 4;
+  const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+  const int last_needed = (oy1 - 1) * S - PB + K - 1;
+
+  // Register-resident x fragments of ONE input row for this wave's tiles (<= MBF_MAXT tiles x
+  // <= 3 k-chunks).  The loads of row r+1 are issued right after the MFMAs of row r consumed the
+  // registers, so they are in flight during row r's swish/LDS epilogue and the depthwise phase
+  // (a first version loaded per tile and exposed ~130 HBM latencies per workgroup).
+  f32x4 xv[T][NKK];
+  auto prefetch_row = [&](int iy) {
+    const bool rowok = (unsigned)iy < (unsigned)p.H && iy <= last_needed;
+    const float* xr = xb + (size_t)(rowok ? iy : 0) * p.W * p.Cin;
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+      const int px = (wave + 4 * ti) * 16 + (lane & 15);
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int ch = kk * 16 + q4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (rowok && kk < nkk && px < p.W && ch < p.Cin) v = *reinterpret_cast<const f32x4*>(xr + (size_t)px * p.Cin + ch);
+        xv[ti][kk] = v;
+      }
+    }
+  };
+
+  auto produce_row = [&](int iy) {
+    float* dst = ring + (size_t)((iy - r_begin) % K) * p.W * 16;
+    if ((unsigned)iy >= (unsigned)p.H) {
+      for (int i = tid; i < p.W * 4; i += 256) *reinterpret_cast<f32x4*>(dst + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if ((unsigned)(iy + 1) < (unsigned)p.H) prefetch_row(iy + 1);     // top padding row -> first real row
+      return;
+    }
+    f32x4 acc[T];
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+      acc[ti] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (wave + 4 * ti < ntile) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk)
+          if (kk < nkk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xv[ti][kk][r], acc[ti], 0, 0, 0);
+          }
+      }
+    }
+    prefetch_row(iy + 1);
+    // D: row = channel 4*(lane>>4)+reg, col = pixel lane&15
+#pragma unroll
+    for (int ti = 0; ti < T; ++ti) {
+      const int px = (wave + 4 * ti) * 16 + (lane & 15);
+      if (wave + 4 * ti < ntile && px < p.W) {
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = swishf(acc[ti][r] * sc0[r] + sh0[r]);
+        *reinterpret_cast<f32x4*>(dst + (size_t)px * 16 + q4) = o;
+      }
+    }
+  };
+  prefetch_row(r_begin);   // no-op (zeros) when r_begin is a padding row; produce_row chains from there
+
+  // depthwise coordinates
+  const int cg = tid & 3;
+  const int pxl = tid >> 2;
+  const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.s1 + c0 + cg * 4);
+  const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.b1 + c0 + cg * 4);
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+
+  int next_row = r_begin;
+  for (int oy = oy0; oy < oy1; ++oy) {
+    const int need = oy * S - PB + K - 1;
+    while (next_row <= need) {
+      produce_row(next_row);
+      ++next_row;
+    }
+    __syncthreads();
+    for (int ox = pxl; ox < p.Wo; ox += 64) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ky = 0; ky < K; ++ky) {
+        const int iy = oy * S - PB + ky;
+        const float* rrow = ring + (size_t)((iy - r_begin) % K) * p.W * 16 + cg * 4;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          int ix = ox * S - PB + kx;
+          if (p.circular) {
+            if (ix < 0) ix += p.W;
+            else if (ix >= p.W) ix -= p.W;
+          }
+          if ((unsigned)ix < (unsigned)p.W) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rrow + (size_t)ix * 16);
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (ky * K + kx) * 16 + cg * 4);
+            acc += v * wv;
+          }
+        }
+      }
+      f32x4 o = acc * sc1 + sh1;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = swishf(o[r]);
+      *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.mid + c0 + cg * 4) = o;
+      sum += o;
+    }
+    __syncthreads();
+  }
+
+  // squeeze partial of this (band, chunk): fixed-order reduction over the 64 pixel lanes
+  *reinterpret_cast<f32x4*>(red + tid * 4) = sum;   // safe: the loop ended with a barrier, ring is dead
+  __syncthreads();
+  if (tid < 4) {
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 64; ++i) t += *reinterpret_cast<const f32x4*>(red + (i * 4 + tid) * 4);
+    *reinterpret_cast<f32x4*>(p.se_partial + ((size_t)b * p.nbands + band) * p.mid + c0 + tid * 4) = t;
+  }
+}
+
+constexpr int MBF_RB = 16;
+
+static bool mbf_supported(int W, int cin, int mid, int k) {
+  return cin % 8 == 0 && cin <= 16 * MBF_MAX_KK && mid % 16 == 0 && W >= 1 &&
+         W <= 64 * MBF_MAXT && (size_t)((k * W * 16 > 1024 ? k * W * 16 : 1024) + k * k * 16) * 4 <= 64 * 1024;
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+extern "C" int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int k, int stride) {
+  if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return CCVPE_EINVAL;
+  if (!mbf_supported(in_w, cin, mid, k)) return 0;           // 0 => use the unfused kernels
+  const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
+  const int Ho = (in_h + total_pad - k) / stride + 1;
+  return (Ho + MBF_RB - 1) / MBF_RB;
+}
+
+extern "C" int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kpad, const float* s0, const float* b0,
+                                      const float* w_dw, const float* s1, const float* b1, float* y,
+                                      float* se_partial, int B, int H, int W, int cin, int mid, int k, int stride,
+                                      int circular, void* stream) {
+  if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "mbconv_front: k/stride unsupported");
+  if (!mbf_supported(W, cin, mid, k)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
+  if (kpad % 16 || kpad < cin) return fail(CCVPE_EINVAL, "mbconv_front: bad kpad");
+  if (!aligned16(x) || !aligned16(w_exp) || !aligned16(s0) || !aligned16(b0) || !aligned16(s1) || !aligned16(b1) ||
+      !aligned16(y) || !aligned16(se_partial))
+    return fail(CCVPE_EINVAL, "mbconv_front: pointers must be 16-byte aligned");
+  MbFrontParams p;
+  p.x = x; p.w_exp = w_exp; p.s0 = s0; p.b0 = b0; p.w_dw = w_dw; p.s1 = s1; p.b1 = b1; p.y = y; p.se_partial = se_partial;
+  p.H = H; p.W = W; p.Cin = cin; p.kpad = kpad; p.mid = mid; p.circular = circular;
+  const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
+  p.Ho = (H + total_pad - k) / stride + 1;
+  p.Wo = (W + total_pad - k) / stride + 1;
+  p.rb = MBF_RB;
+  p.nbands = (p.Ho + MBF_RB - 1) / MBF_RB;
+  p.nchunks = mid / 16;
+  const long total = (long)p.nbands * p.nchunks * B;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "mbconv_front: grid too large");
+  p.total_blocks = (int)total;
+  const size_t smem = (size_t)((k * W * 16 > 1024 ? k * W * 16 : 1024) + k * k * 16) * sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  const int tneed = ((W + 15) / 16 + 3) / 4;          // 16-pixel tiles per wave per row
+  const int tsel = tneed <= 1 ? 1 : (tneed <= 2 ? 2 : (tneed <= 3 ? 3 : 5));
+  const int nkk = (cin + 15) / 16;
+#define MBF_LAUNCH(K_, S_, T_, N_) \
+  hipLaunchKernelGGL((mbconv_front_kernel<K_, S_, T_, N_>), dim3(p.total_blocks), dim3(256), smem, st, p)
+#define MBF_N(K_, S_, T_)                    \
+  if (nkk == 1) MBF_LAUNCH(K_, S_, T_, 1);   \
+  else if (nkk == 2) MBF_LAUNCH(K_, S_, T_, 2); \
+  else MBF_LAUNCH(K_, S_, T_, 3)
+#define MBF_T(K_, S_)                        \
+  if (tsel == 1) { MBF_N(K_, S_, 1); }       \
+  else if (tsel == 2) { MBF_N(K_, S_, 2); }  \
+  else if (tsel == 3) { MBF_N(K_, S_, 3); }  \
+  else { MBF_N(K_, S_, 5); }
+  if (k == 3 && stride == 1) { MBF_T(3, 1) }
+  else if (k == 3 && stride == 2) { MBF_T(3, 2) }
+  else if (k == 5 && stride == 1) { MBF_T(5, 1) }
+  else { MBF_T(5, 2) }
+#undef MBF_T
+#undef MBF_N
+#undef MBF_LAUNCH
+  return check_launch("mbconv_front_kernel");
+}

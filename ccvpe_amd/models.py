@@ -207,11 +207,16 @@ def _run_encoder(e, img, circular, multiscale):
     feats = []
     for blk in e.blocks:
         b, h, w, _ = x.shape
-        t = x
-        if blk.expand:
-            t = ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w,
-                               scale=blk.s0, shift=blk.b0, act=ops.ACT_SWISH)
-        u, part = ops.dwconv(t, blk.w_dw, blk.s1, blk.b1, blk.k, blk.s, circular)
+        if blk.expand and ops.mbconv_front_supported(h, w, blk.cin, blk.mid, blk.k, blk.s):
+            # early blocks: the 6x-expanded tensor stays in LDS (csrc/mbconv_front.hip)
+            u, part = ops.mbconv_front(x, blk.w_exp, blk.s0, blk.b0, blk.w_dw, blk.s1, blk.b1, blk.mid,
+                                       blk.k, blk.s, circular)
+        else:
+            t = x
+            if blk.expand:
+                t = ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w,
+                                   scale=blk.s0, shift=blk.b0, act=ops.ACT_SWISH)
+            u, part = ops.dwconv(t, blk.w_dw, blk.s1, blk.b1, blk.k, blk.s, circular)
         ho, wo = u.shape[1], u.shape[2]
         gate = ops.se_gate(part, ho * wo, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
         x = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate,

@@ -165,6 +165,38 @@ def dwconv(x, w, scale, shift, k, stride, circular):
     return y, part
 
 
+def mbconv_front_supported(in_h, in_w, cin, mid, k, stride):
+    n = _lib.load().ccvpe_mbconv_front_nblk(in_h, in_w, cin, mid, k, stride)
+    if n < 0:
+        raise _lib.CcvpeError("ccvpe_mbconv_front_nblk rejected k=%d stride=%d" % (k, stride))
+    return n
+
+
+def mbconv_front(x, w_exp, s0, b0, w_dw, s1, b1, mid, k, stride, circular):
+    """Fused expand + depthwise (+BN+swish each) + SE squeeze partials; returns (y, se_partial)."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w_exp, "w_exp"), (s0, "s0"), (b0, "b0"), (w_dw, "w_dw"), (s1, "s1"), (b1, "b1")):
+        _chk(t, nm)
+    b, h, wd, cin = x.shape
+    nblk = mbconv_front_supported(h, wd, cin, mid, k, stride)
+    if nblk == 0:
+        raise _lib.CcvpeError("mbconv_front: unsupported shape %s" % (tuple(x.shape),))
+    tot = (k - 1) if stride == 1 else (k - 2)
+    ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
+    y = torch.empty((b, ho, wo, mid), device=x.device, dtype=torch.float32)
+    part = torch.empty((b, nblk, mid), device=x.device, dtype=torch.float32)
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
+    check(lib.ccvpe_mbconv_front_f32(_ptr(x), _ptr(w_exp), w_exp.shape[1], _ptr(s0), _ptr(b0), _ptr(w_dw), _ptr(s1),
+                                     _ptr(b1), _ptr(y), _ptr(part), b, h, wd, cin, mid, k, stride,
+                                     int(bool(circular)), _stream()), "ccvpe_mbconv_front_f32")
+    if rec is not None:
+        flops = 2.0 * b * h * wd * cin * mid + 2.0 * b * ho * wo * mid * k * k
+        nbytes = 4.0 * (b * h * wd * cin + b * ho * wo * mid)
+        rec.end("mbconv_front_kernel<%d,%d>" % (k, stride), "in %dx%dx%d mid %d" % (h, wd, cin, mid), flops, nbytes, ev0)
+    return y, part
+
+
 def se_gate(part, hw, w1, b1, w2, b2):
     lib = _lib.load()
     for t, nm in ((part, "part"), (w1, "w1"), (b1, "b1"), (w2, "w2"), (b2, "b2")):

@@ -107,6 +107,21 @@ int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const f
                      float* se_partial, int batch, int in_h, int in_w, int channels, int k, int stride,
                      int circular, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * Fused MBConv front half for the early (large) blocks: expand 1x1 + BN0 + swish -> depthwise kxk +
+ * BN1 + swish + SE squeeze partials, with the 6x-expanded tensor kept in LDS
+ * (efficientnet_pytorch/model.py:102-110,114).  Same results as ccvpe_conv_igemm_f32 followed by
+ * ccvpe_dwconv_f32.  w_exp is the igemm-packed expand weight [mid^16][kpad].
+ * ccvpe_mbconv_front_nblk() returns the number of SE partial rows per sample, 0 if the shape is
+ * not supported (then use the two unfused calls), <0 on bad arguments.
+ *   x [B,H,W,cin], y [B,Ho,Wo,mid], se_partial [B][nblk][mid]
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int k, int stride);
+int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kpad, const float* s0, const float* b0,
+                           const float* w_dw, const float* s1, const float* b1, float* y, float* se_partial,
+                           int batch, int in_h, int in_w, int cin, int mid, int k, int stride, int circular,
+                           void* stream);
+
 /* Squeeze-excite gate: mean -> 1x1 (C->Cs) + swish -> 1x1 (Cs->C) -> sigmoid.
  * efficientnet_pytorch/model.py:113-118.  w1 [Cs][C], w2 TRANSPOSED [Cs][C], gate [B][C]. */
 int ccvpe_se_gate_f32(const float* se_partial, int nblk, float inv_hw, const float* w1, const float* b1,

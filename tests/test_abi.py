@@ -30,6 +30,27 @@ def test_library_exports_every_declared_symbol():
     assert lib.ccvpe_abi_version() == 1
 
 
+def test_ctypes_prototypes_match_header_signatures():
+    """Arity and pointer/int/float kind of every ctypes prototype vs the C declaration."""
+    import ctypes
+    src = open(os.path.join(ROOT, "include", "ccvpe_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = re.findall(r"\b(?:int|const char\*)\s+(ccvpe_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src)
+    assert len(decls) == len(_lib.PROTOTYPES)
+    for name, params in decls:
+        params = [q.strip() for q in params.split(",") if q.strip() and q.strip() != "void"]
+        argtypes = _lib.PROTOTYPES[name][1]
+        assert len(params) == len(argtypes), "%s: header has %d params, ctypes %d" % (name, len(params), len(argtypes))
+        for q, a in zip(params, argtypes):
+            is_ptr = "*" in q
+            if is_ptr:
+                assert a is ctypes.c_void_p or issubclass(a, ctypes._Pointer), (name, q, a)
+            elif q.startswith("float"):
+                assert a is ctypes.c_float, (name, q, a)
+            else:
+                assert a is ctypes.c_int, (name, q, a)
+
+
 def test_conv_desc_matches_header_field_order():
     src = open(os.path.join(ROOT, "include", "ccvpe_hip.h")).read()
     body = src[src.index("typedef struct ccvpe_conv_desc"):src.index("} ccvpe_conv_desc;")]

@@ -191,6 +191,51 @@ def test_mbconv_blocks_golden(ops, circ, synth_sd):
         close(nchw(y), torch.from_numpy(want["block%d" % i]), 1e-4, "block%d" % i)
 
 
+@pytest.mark.parametrize("k,s,cin,h,w,circ", [(3, 2, 16, 40, 72, False), (3, 1, 24, 36, 40, True), (5, 2, 24, 34, 48, True),
+                                              (5, 1, 40, 20, 24, False), (3, 2, 40, 18, 80, True), (5, 2, 24, 33, 21, False),
+                                              (5, 1, 48, 17, 16, True)])
+def test_mbconv_front_fused(ops, k, s, cin, h, w, circ):
+    """Fused expand+depthwise (expanded tensor in LDS) == unfused oracle; several row bands."""
+    from ccvpe_amd.models import _pack_conv
+    b, mid = 2, 6 * cin
+    x = synth.normal((b, cin, h, w), 300 + cin)
+    w_exp = synth.normal((mid, cin, 1, 1), 301, (2.0 / cin) ** 0.5)
+    s0, b0 = synth.uniform((mid,), 302, 0.5, 1.5), synth.normal((mid,), 303, 0.2)
+    w_dw = synth.normal((mid, 1, k, k), 304, 1.0 / k)
+    s1, b1 = synth.uniform((mid,), 305, 0.5, 1.5), synth.normal((mid,), 306, 0.2)
+    t = O.swish(F.conv2d(x, w_exp) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    want = O.swish(O.same_conv(t, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    assert ops.mbconv_front_supported(h, w, cin, mid, k, s) > 0
+    got, part = ops.mbconv_front(dev(nhwc(x)), dev(_pack_conv(w_exp)), dev(s0), dev(b0),
+                                 dev(w_dw.reshape(mid, k, k).permute(1, 2, 0)), dev(s1), dev(b1), mid, k, s, circ)
+    close(nchw(got), want, 1e-4, "fused front k%d s%d" % (k, s))
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials")
+
+
+@pytest.mark.parametrize("circ", [True, False])
+def test_mbconv_blocks_golden_fused_front(ops, circ, synth_sd):
+    """Blocks 1-5 through the fused front kernel against the reference-module goldens."""
+    from ccvpe_amd.models import _pack_encoder
+    want = G.load("effnet_modules_" + ("circ" if circ else "zero"))
+    sd = {k: v.cuda() for k, v in synth_sd("vigor", 0).items() if "efficientnet" in k}
+    e = _pack_encoder(sd, "grd_efficientnet" if circ else "sat_efficientnet")
+    n = 0
+    for i, blk in enumerate(e.blocks):
+        if "block%d" % i not in want or not blk.expand:
+            continue
+        h, w = G.BLOCK_HW
+        if not ops.mbconv_front_supported(h, w, blk.cin, blk.mid, blk.k, blk.s):
+            continue
+        x = dev(nhwc(synth.normal((2, blk.cin) + G.BLOCK_HW, 5000 + i)))
+        u, part = ops.mbconv_front(x, blk.w_exp, blk.s0, blk.b0, blk.w_dw, blk.s1, blk.b1, blk.mid, blk.k, blk.s, circ)
+        gate = ops.se_gate(part, u.shape[1] * u.shape[2], blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        y = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=2, in_h=u.shape[1], in_w=u.shape[2], gate=gate,
+                           scale=blk.s2, shift=blk.b2, residual=x if blk.skip else None)
+        close(nchw(y), torch.from_numpy(want["block%d" % i]), 1e-4, "block%d" % i)
+        n += 1
+    assert n >= 3
+
+
 # ------------------------------------------------------------------------------------------
 # descriptors / matching / heads
 # ------------------------------------------------------------------------------------------
