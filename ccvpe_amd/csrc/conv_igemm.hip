@@ -405,6 +405,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][fk]);
+    __builtin_amdgcn_s_setprio(1);   // co-resident workgroups are at other phases: favour the MFMA issuer
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
 
     if (more) store_w((s + 1) & 1);
     __syncthreads();
@@ -423,30 +425,28 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
     tap = ntap;
   }
 
-  // ---- epilogue ---------------------------------------------------------------------------------
+  // ---- epilogue (scale/shift are loaded per column group, not hoisted: keeping the kernel under
+  // 128 VGPRs lets 4 workgroups share a CU, which is what keeps the MFMA pipe fed) ---------------
   const int epix = lane & 15;
   const int en = (lane >> 4) * 4;
-  float sc[NT][4], sh[NT][4];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int n = n0 + (wn * NT + j) * 16 + en + q;
-      const bool ok = n < p.N;
-      sc[j][q] = (ok && p.scale) ? p.scale[n] : 1.0f;
-      sh[j][q] = (ok && p.shift) ? p.shift[n] : 0.0f;
-    }
   const int ox = x0 + epix;
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int oy = y0 + wm * MT + i;
-    if (oy >= p.H || ox >= p.W) continue;
-    const size_t m = (size_t)(b * p.H + oy) * p.W + ox;
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + (wn * NT + j) * 16 + en;
+    if (n >= p.N) continue;
+    float sc[4], sh[4];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + (wn * NT + j) * 16 + en;
-      if (n >= p.N) continue;
-      store4(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc[j], sh[j]);
+    for (int q = 0; q < 4; ++q) {
+      const bool ok = n + q < p.N;
+      sc[q] = (ok && p.scale) ? p.scale[n + q] : 1.0f;
+      sh[q] = (ok && p.shift) ? p.shift[n + q] : 0.0f;
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int oy = y0 + wm * MT + i;
+      if (oy >= p.H || ox >= p.W) continue;
+      const size_t m = (size_t)(b * p.H + oy) * p.W + ox;
+      store4(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc, sh);
     }
   }
 }
