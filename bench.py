@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--batch", type=int, default=64, help="image pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
+    ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
+                    help="fp32 = BASELINE C1 (default, the headline); bf16 = the C2/C4 storage path")
+    ap.add_argument("--model", choices=["prior0", "vigor20", "prior180_fov180", "kitti"], default="prior0",
+                    help="prior0 = C1 (default); vigor20 = C2 (N_rot=20); prior180_fov180 = C4; kitti = C3 forward")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket igemm launches with HIP events in the timed region")
@@ -92,11 +96,19 @@ def main():
     from ccvpe_amd import models, ops, synth, _lib
     _lib.load()                                             # fails loudly if the HIP library is missing
 
-    sd = synth.synthetic_state_dict("vigor", 0)             # identical on every rank
-    net = models.CVM_VIGOR_ori_prior(dev, 0, True)
+    kind = "kitti" if args.model == "kitti" else "vigor"
+    sd = synth.synthetic_state_dict(kind, 0)                # identical on every rank
+    if args.model == "prior0":
+        net, gshape = models.CVM_VIGOR_ori_prior(dev, 0, True), "vigor"
+    elif args.model == "vigor20":
+        net, gshape = models.CVM_VIGOR(dev, True), "vigor"
+    elif args.model == "prior180_fov180":
+        net, gshape = models.CVM_VIGOR_ori_prior(dev, 180, False), "vigor_fov180"
+    else:
+        net, gshape = models.CVM_KITTI(dev), "kitti"
     net.load_state_dict(sd, strict=True)
-    net = net.to(dev).eval()
-    grd, sat = synth.synthetic_pair(args.batch, "vigor", 1234 + rank)
+    net = net.to(dev).eval().set_precision(args.precision)
+    grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank)
     grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
 
     from ccvpe_amd import harness
@@ -128,9 +140,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C1: CVM_VIGOR_ori_prior(ori_noise=0) eval forward, "
-                                   "grd 3x320x640 + sat 3x512x512, N_rot=1 loc / 20 ori",
+            "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
+            "config": {"workload": {"prior0": "C1: CVM_VIGOR_ori_prior(ori_noise=0) eval forward, "
+                                              "grd 3x320x640 + sat 3x512x512, N_rot=1 loc / 20 ori",
+                                    "vigor20": "C2: CVM_VIGOR eval forward, N_rot=20, grd 3x320x640 + sat 3x512x512",
+                                    "prior180_fov180": "C4: CVM_VIGOR_ori_prior(180, circular_padding=False) eval "
+                                                       "forward, FoV 180: grd 3x320x320 + sat 3x512x512",
+                                    "kitti": "C3 (forward only): CVM_KITTI eval forward, grd 3x256x1024 + sat "
+                                             "3x512x512"}[args.model],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
                        "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per kernel)",
@@ -149,9 +166,17 @@ def main():
                     traffic = json.load(open(tpath)).get(name)
                 except Exception:
                     traffic = None
-            roof = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
-                    "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic,
+            if args.precision == "bf16":
+                # bf16 storage: every kernel is HBM-bound (MFMA is 16x faster than fp32) -> price the
+                # dominant kernel against HBM with its ALGORITHMIC bytes (input + output + weights once)
+                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+                roof_head = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
+            else:
+                roof_head = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
+                             "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic}
+            roof = {**roof_head,
                     "launches_per_step": d["calls"] // args.steps,
                     "avg_launch_ms": round(d["ms"] / d["calls"], 4),
                     "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
@@ -171,7 +196,7 @@ def main():
             for (name, tag), d in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print("%-28s %-28s %5d %9.3f %8.1f %8.0f" % (name, tag, d[0] // args.steps, d[1] / args.steps,
                       d[2] / d[1] / 1e9, d[3] / d[1] / 1e6), file=sys.stderr)
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.model == "prior0":
             line["cpu_baseline"] = cpu_baseline(sd)
         else:
             line["cpu_baseline"] = None

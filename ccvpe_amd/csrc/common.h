@@ -46,4 +46,25 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+typedef float cc_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cc_bf16;
+typedef __bf16 cc_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cc_bf16x8 __attribute__((ext_vector_type(8)));
+
+// 4 consecutive channels <-> fp32 registers, for fp32 (16 B) or bf16 (8 B, RNE on store) storage
+template <typename T> __device__ __forceinline__ cc_f32x4 ld4(const T* p);
+template <> __device__ __forceinline__ cc_f32x4 ld4<float>(const float* p) { return *reinterpret_cast<const cc_f32x4*>(p); }
+template <> __device__ __forceinline__ cc_f32x4 ld4<cc_bf16>(const cc_bf16* p) {
+  const cc_bf16x4 v = *reinterpret_cast<const cc_bf16x4*>(p);
+  return (cc_f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+template <typename T> __device__ __forceinline__ void st4(T* p, cc_f32x4 v);
+template <> __device__ __forceinline__ void st4<float>(float* p, cc_f32x4 v) { *reinterpret_cast<cc_f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void st4<cc_bf16>(cc_bf16* p, cc_f32x4 v) {
+  cc_bf16x4 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (cc_bf16)v[i];
+  *reinterpret_cast<cc_bf16x4*>(p) = o;
+}
+
 }  // namespace ccvpe

@@ -26,22 +26,70 @@
 // LDS rows are padded 16 -> 20 floats (80 B: 16-byte aligned, breaks the 64 B power-of-two stride).
 //
 // The fp32 MFMA runs at the fp32 vector rate (157 TF peak) and is a bitwise k-ordered fmaf chain:
-// these kernels are exact fp32 (gfx950 has no TF32-like shortcut).
+// the fp32 instantiations are exact fp32 (gfx950 has no TF32-like shortcut).
+//
+// Element type T: both kernels are instantiated for float and for bf16 storage (BASELINE configs
+// C2/C4).  The LDS BYTE geometry is identical: a stage row is 64 bytes = 16 fp32 or 32 bf16 channels,
+// a fragment is one ds_read_b128 = 4 fp32 (4 x v_mfma_f32_16x16x4_f32) or 8 bf16
+// (1 x v_mfma_f32_16x16x32_bf16, fp32 accumulate).  bf16 stores round-to-nearest-even
+// (v_cvt_pk_bf16_f32); scale/shift/gate and all accumulation stay fp32.
 #include "common.h"
 
 namespace ccvpe {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> { static constexpr int E = 4; };    // elements per 16 bytes
+template <> struct ElemTraits<bf16_t> { static constexpr int E = 8; };
+
+// one K-stage (64 bytes of K per row) of MFMAs for one (W fragment, pixel fragment) pair
+template <typename T>
+__device__ __forceinline__ f32x4 mfma_stage(f32x4 wfrag, f32x4 afrag, f32x4 acc);
+template <>
+__device__ __forceinline__ f32x4 mfma_stage<float>(f32x4 wfrag, f32x4 afrag, f32x4 acc) {
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wfrag[kk], afrag[kk], acc, 0, 0, 0);
+  return acc;
+}
+template <>
+__device__ __forceinline__ f32x4 mfma_stage<bf16_t>(f32x4 wfrag, f32x4 afrag, f32x4 acc) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wfrag), __builtin_bit_cast(bf16x8, afrag),
+                                                 acc, 0, 0, 0);
+}
+
+// SE gate on 16 raw bytes of activations (gate is fp32, per channel)
+template <typename T>
+__device__ __forceinline__ f32x4 apply_gate(f32x4 raw, const float* g);
+template <>
+__device__ __forceinline__ f32x4 apply_gate<float>(f32x4 raw, const float* g) {
+  return raw * *reinterpret_cast<const f32x4*>(g);
+}
+template <>
+__device__ __forceinline__ f32x4 apply_gate<bf16_t>(f32x4 raw, const float* g) {
+  bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(g), g1 = *reinterpret_cast<const f32x4*>(g + 4);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = (bf16_t)((float)v[i] * g0[i]);
+    v[i + 4] = (bf16_t)((float)v[i + 4] * g1[i]);
+  }
+  return __builtin_bit_cast(f32x4, v);
+}
 
 struct IgemmParams {
-  const float* src0;
-  const float* src1;
+  const void* src0;
+  const void* src1;
   const float* gate;
-  const float* w;
+  const void* w;
   const float* scale;
   const float* shift;
-  const float* residual;
-  float* dst;
+  const void* residual;
+  void* dst;
+  int out_f32;       // bf16 kernels only: write fp32 instead of bf16 (final tensors handed to fp32 consumers)
   int c0, ld0, c1, ld1;
   int H, W, Ho, Wo;
   int kw, stride, pad;
@@ -65,6 +113,7 @@ __device__ __forceinline__ int xcd_tile(int bid, int total) {
 }
 
 // Epilogue for one accumulator: 4 consecutive channels n..n+3 of one pixel.
+template <typename T>
 __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, size_t obase, size_t rbase,
                                        const float* sc, const float* sh) {
 #pragma unroll
@@ -74,22 +123,43 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
     else if (p.act == CCVPE_ACT_SWISH) t = swishf(t);
     v[r] = t;
   }
+  const T* res = reinterpret_cast<const T*>(p.residual);
+  const bool f32out = sizeof(T) == 4 || p.out_f32;
   if (n + 3 < p.N) {
-    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + rbase + n);
-    *reinterpret_cast<f32x4*>(p.dst + obase) = v;
+    if (res) {
+      if (sizeof(T) == 4) {
+        v += *reinterpret_cast<const f32x4*>(res + rbase + n);
+      } else {
+        const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + rbase + n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+      }
+    }
+    if (f32out) {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + obase) = v;
+    } else {
+      bf16x4 o;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = (bf16_t)v[r];
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.dst) + obase) = o;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (n + r < p.N) {
         float t = v[r];
-        if (p.residual) t += p.residual[rbase + n + r];
-        p.dst[obase + r] = t;
+        if (res) t += (float)res[rbase + n + r];
+        if (f32out) reinterpret_cast<float*>(p.dst)[obase + r] = t;
+        else reinterpret_cast<bf16_t*>(p.dst)[obase + r] = (bf16_t)t;
       }
   }
 }
 
-template <int MT, int NT, int WN>
-__global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int E = ElemTraits<T>::E;      // elements per 16-byte load
+  constexpr int SK = 4 * E;                // K elements per stage row (64 bytes)
+  constexpr int CPS = SK / 8;              // 8-channel chunks per stage: 2 (fp32) or 4 (bf16)
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
@@ -113,9 +183,12 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
 
   // ---- per-thread staging coordinates -------------------------------------------------------
   const int srow = tid >> 2;   // 0..63
-  const int ssub = tid & 3;    // which float4 of the 16-float stage row
-  const int chunk_in_stage = ssub >> 1;
-  const int half = ssub & 1;
+  const int ssub = tid & 3;    // which 16-byte piece of the 64-byte stage row
+  const int chunk_in_stage = (ssub * E) >> 3;      // fp32: ssub>>1, bf16: ssub
+  const int half = (ssub * E) & 7;                 // channel offset inside the 8-chunk: fp32 0|4, bf16 0
+  const T* src0 = reinterpret_cast<const T*>(p.src0);
+  const T* src1 = reinterpret_cast<const T*>(p.src1);
+  const T* wp = reinterpret_cast<const T*>(p.w);
 
   int a_b[A_IT], a_y[A_IT], a_x[A_IT];
   bool a_ok[A_IT];
@@ -133,7 +206,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
     a_y[it] = oy * p.stride - p.pad;
     a_x[it] = ox * p.stride - p.pad;
   }
-  // chunk cursor of this thread: kc = 2*stage + chunk_in_stage, decoded as (ky, kx, r)
+  // chunk cursor of this thread: kc = CPS*stage + chunk_in_stage, decoded as (ky, kx, r)
   int kc = chunk_in_stage;
   int r = chunk_in_stage, ky = 0, kx = 0;
   while (r >= p.cpt) {
@@ -146,9 +219,9 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
   auto load_stage = [&](int s) {
     const bool kvalid = kc < p.total_chunks;
     const bool from0 = r < p.cpt0;
-    const float* base = from0 ? p.src0 : p.src1;
+    const T* base = from0 ? src0 : src1;
     const int ld = from0 ? p.ld0 : p.ld1;
-    const int ch = (from0 ? r : r - p.cpt0) * 8 + half * 4;
+    const int ch = (from0 ? r : r - p.cpt0) * 8 + half;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int iy = a_y[it] + ky;
@@ -158,10 +231,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
       if (ok) {
         const size_t off = ((size_t)(a_b[it] * p.H + iy) * p.W + ix) * ld + ch;
         v = *reinterpret_cast<const f32x4*>(base + off);
-        if (p.gate != nullptr && from0) {
-          const f32x4 gv = *reinterpret_cast<const f32x4*>(p.gate + (size_t)a_b[it] * p.c0 + ch);
-          v *= gv;
-        }
+        if (p.gate != nullptr && from0) v = apply_gate<T>(v, p.gate + (size_t)a_b[it] * p.c0 + ch);
       }
       a_reg[it] = v;
     }
@@ -170,11 +240,11 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
       const int nrow = srow + 64 * it;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (nrow < BN && n0 + nrow < p.Npad)
-        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(n0 + nrow) * p.Kpad + s * 16 + ssub * 4);
+        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + s * SK + ssub * E);
       b_reg[it] = v;
     }
-    kc += 2;
-    r += 2;
+    kc += CPS;
+    r += CPS;
     while (r >= p.cpt) {
       r -= p.cpt;
       if (++kx == p.kw) { kx = 0; ++ky; }
@@ -217,13 +287,20 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       bf[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * NT + j) * 16 + frow][fk]);
+    if (sizeof(T) == 4) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
+    }
 
     if (more) store_stage(buf ^ 1);
     __syncthreads();
@@ -267,7 +344,7 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
         const int co = n - quad * p.cout;
         obase = pbase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
       }
-      store4(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
+      store4<T>(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
     }
   }
 }
@@ -277,8 +354,10 @@ __global__ __launch_bounds__(256) void igemm_f32_kernel(const IgemmParams p) {
 // Pixel tile = TH rows x 16 columns (one MFMA tile = 16 consecutive x of one row), TH = BM/16.
 // Stage s = (chunk, tap): chunk = 16 consecutive concat channels, tap = ky*3+kx.
 // ---------------------------------------------------------------------------------------------
-template <int MT, int NT, int WN>
-__global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256) void conv3x3_kernel(const IgemmParams p) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;                        // channels per chunk: 16 (fp32) or 32 (bf16)
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
@@ -308,8 +387,11 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
   const int y0 = ty * TH, x0 = tx * 16;
   const int n0 = tn * BN;
   const int ctot = p.c0 + p.c1;
-  const int nchunks = (ctot + 15) >> 4;
+  const int nchunks = (ctot + SK - 1) / SK;
   const int nstages = nchunks * 9;
+  const T* src0 = reinterpret_cast<const T*>(p.src0);
+  const T* src1 = reinterpret_cast<const T*>(p.src1);
+  const T* wp = reinterpret_cast<const T*>(p.w);
 
   // halo staging coordinates (fixed per thread)
   int h_off[H_IT];     // LDS float offset, -1 if this slot is unused
@@ -338,10 +420,10 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      const int ch = chunk * 16 + h_sub[it] * 4;
+      const int ch = chunk * SK + h_sub[it] * E;
       if (h_pix[it] >= 0 && ch < ctot) {
         const bool from0 = ch < p.c0;
-        const float* base = from0 ? p.src0 : p.src1;
+        const T* base = from0 ? src0 : src1;
         const size_t off = (size_t)h_pix[it] * (from0 ? p.ld0 : p.ld1) + (from0 ? ch : ch - p.c0);
         v = *reinterpret_cast<const f32x4*>(base + off);
       }
@@ -354,13 +436,13 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
       if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Hs[0][0] + h_off[it]) = h_reg[it];
   };
   auto load_w = [&](int chunk, int tap) {
-    const int ch = chunk * 16 + ssub * 4;
+    const int ch = chunk * SK + ssub * E;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
-        v = *reinterpret_cast<const f32x4*>(p.w + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
+        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
       b_reg[it] = v;
     }
   };
@@ -405,15 +487,20 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][fk]);
-    __builtin_amdgcn_s_setprio(1);   // co-resident workgroups are at other phases: favour the MFMA issuer
+    if (sizeof(T) == 4) {
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
+    }
 
     if (more) store_w((s + 1) & 1);
     __syncthreads();
@@ -446,12 +533,12 @@ __global__ __launch_bounds__(256) void conv3x3_f32_kernel(const IgemmParams p) {
       const int oy = y0 + wm * MT + i;
       if (oy >= p.H || ox >= p.W) continue;
       const size_t m = (size_t)(b * p.H + oy) * p.W + ox;
-      store4(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc, sh);
+      store4<T>(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc, sh);
     }
   }
 }
 
-template <int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN>
 static int launch(const IgemmParams& p0, hipStream_t stream) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
@@ -460,11 +547,11 @@ static int launch(const IgemmParams& p0, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Npad + BN - 1) / BN;
   p.tiles_total = tiles_m * p.tiles_n;
-  hipLaunchKernelGGL((igemm_f32_kernel<MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
-  return check_launch("igemm_f32_kernel");
+  hipLaunchKernelGGL((igemm_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
+  return check_launch("igemm_kernel");
 }
 
-template <int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN>
 static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
@@ -477,8 +564,8 @@ static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
   const long total = (long)p.tiles_x * p.tiles_y * batch * p.tiles_n;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv3x3: grid too large");
   p.tiles_total = (int)total;
-  hipLaunchKernelGGL((conv3x3_f32_kernel<MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
-  return check_launch("conv3x3_f32_kernel");
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
+  return check_launch("conv3x3_kernel");
 }
 
 // Pick the N tile that wastes the fewest MFMA columns, then the widest.
@@ -505,13 +592,16 @@ static int pick_cfg(int npad16) {
 
 using namespace ccvpe;
 
-extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
+template <typename T>
+static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;
   if (!d) return fail(CCVPE_EINVAL, "conv_igemm: null desc");
   if (d->c0 <= 0 || d->c0 % 8 || d->c1 < 0 || d->c1 % 8)
     return fail(CCVPE_EINVAL, "conv_igemm: c0/c1 must be multiples of 8 (got %d,%d)", d->c0, d->c1);
   if (d->c1 > 0 && !d->src1) return fail(CCVPE_EINVAL, "conv_igemm: c1>0 but src1 null");
-  if (d->ld0 % 4 || (d->c1 && d->ld1 % 4) || d->kpad % 16 || d->ldd % 4 || (d->residual && d->ldres % 4))
-    return fail(CCVPE_EINVAL, "conv_igemm: ld0/ld1/ldd/ldres %% 4, kpad %% 16 required");
+  if (d->ld0 % E || (d->c1 && d->ld1 % E) || d->kpad % SK || d->ldd % 4 || (d->residual && d->ldres % 4))
+    return fail(CCVPE_EINVAL, "conv_igemm: ld0/ld1 %% %d, kpad %% %d, ldd/ldres %% 4 required", E, SK);
   if (!aligned16(d->src0) || (d->src1 && !aligned16(d->src1)) || !aligned16(d->w) ||
       (d->gate && !aligned16(d->gate)) || !aligned16(d->dst) || (d->residual && !aligned16(d->residual)))
     return fail(CCVPE_EINVAL, "conv_igemm: pointers must be 16-byte aligned");
@@ -520,6 +610,7 @@ extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   IgemmParams p;
   p.src0 = d->src0; p.src1 = d->src1; p.gate = d->gate; p.w = d->w;
   p.scale = d->scale; p.shift = d->shift; p.residual = d->residual; p.dst = d->dst;
+  p.out_f32 = out_f32;
   p.c0 = d->c0; p.ld0 = d->ld0; p.c1 = d->c1; p.ld1 = d->ld1;
   p.H = d->in_h; p.W = d->in_w;
   p.Ho = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
@@ -529,7 +620,8 @@ extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   p.cpt0 = d->c0 / 8; p.cpt = (d->c0 + d->c1) / 8;
   p.total_chunks = p.cpt * d->kh * d->kw;
   if (p.total_chunks * 8 > p.Kpad) return fail(CCVPE_EINVAL, "conv_igemm: kpad %d < K %d", p.Kpad, p.total_chunks * 8);
-  p.stages = (p.total_chunks + 1) / 2;
+  constexpr int CPS = SK / 8;
+  p.stages = (p.total_chunks + CPS - 1) / CPS;
   p.ldd = d->ldd; p.ldres = d->ldres; p.act = d->act; p.out_mode = d->out_mode;
   p.cout = (d->out_mode == CCVPE_OUT_DECONV2X) ? d->n / 4 : d->n;
   if (d->out_mode == CCVPE_OUT_DECONV2X && (d->n % 16 || d->residual))
@@ -543,13 +635,21 @@ extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
   const bool is3x3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
                      d->out_mode == CCVPE_OUT_NHWC && !d->gate;
-#define CCVPE_CASE(MT_, NT_, WN_)                                    \
-  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                   \
-    if (is3x3) return launch3x3<MT_, NT_, WN_>(p, d->batch, st);     \
-    return launch<MT_, NT_, WN_>(p, st);                             \
+#define CCVPE_CASE(MT_, NT_, WN_)                                       \
+  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                      \
+    if (is3x3) return launch3x3<T, MT_, NT_, WN_>(p, d->batch, st);     \
+    return launch<T, MT_, NT_, WN_>(p, st);                             \
   }
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)
   CCVPE_CASE(4, 5, 1) CCVPE_CASE(4, 3, 1) CCVPE_CASE(4, 1, 1) CCVPE_CASE(2, 7, 1)
 #undef CCVPE_CASE
   return fail(CCVPE_EINVAL, "conv_igemm: no tile config");
+}
+
+extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
+  return conv_igemm_any<float>(d, stream, 1);
+}
+
+extern "C" int ccvpe_conv_igemm_bf16(const ccvpe_conv_desc* d, int out_f32, void* stream) {
+  return conv_igemm_any<bf16_t>(d, stream, out_f32 ? 1 : 0);
 }

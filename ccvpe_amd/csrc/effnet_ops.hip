@@ -12,9 +12,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // efficientnet_pytorch/model.py:181-182,289 ; padding utils.py:265-277 (zero), :341-353 (circular W)
 // One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
 // ---------------------------------------------------------------------------------------------
+template <typename T>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, float* __restrict__ y,
+                                                        const float* __restrict__ shift, T* __restrict__ y,
                                                         int B, int H, int W, int Ho, int Wo, int circular) {
   __shared__ __attribute__((aligned(16))) float ws[27 * 32];
   __shared__ float ssc[32], ssh[32];
@@ -55,7 +56,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       }
     }
   }
-  f32x4* out = reinterpret_cast<f32x4*>(y + (size_t)idx * 32);
+  T* out = y + (size_t)idx * 32;
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) {
     f32x4 o;
@@ -65,7 +66,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       const float v = acc[c] * ssc[c] + ssh[c];
       o[j] = swishf(v);
     }
-    out[c4] = o;
+    st4<T>(out + c4 * 4, o);
   }
 }
 
@@ -79,10 +80,10 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int DW_TW = 4;
 
-template <int K, int S>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, float* __restrict__ y,
+                                                     const float* __restrict__ shift, T* __restrict__ y,
                                                      float* __restrict__ se_partial, int H, int W, int C, int Ho,
                                                      int Wo, int cgx, int P, int nblk, int circular, int RB,
                                                      int ychunks, int total_blocks) {
@@ -119,7 +120,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     f32x4 acc[DW_TW];
 #pragma unroll
     for (int t = 0; t < DW_TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* xb = x + (size_t)b * H * W * C + c;
+    const T* xb = x + (size_t)b * H * W * C + c;
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S - PB + ky;
@@ -136,7 +137,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         } else {
           ok = (unsigned)ix < (unsigned)W;
         }
-        col[j] = ok ? *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        col[j] = ok ? ld4<T>(xb + ((size_t)iy * W + ix) * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     }
     const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
     const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-    float* yb = y + ((size_t)(b * Ho + oy) * Wo) * C + c;
+    T* yb = y + ((size_t)(b * Ho + oy) * Wo) * C + c;
 #pragma unroll
     for (int t = 0; t < DW_TW; ++t) {
       const int ox = ox0 + t;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
         f32x4 v = acc[t] * sc + sh;
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
-        *reinterpret_cast<f32x4*>(yb + (size_t)ox * C) = v;
+        st4<T>(yb + (size_t)ox * C, v);
         sum += v;
       }
     }
@@ -261,15 +262,25 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 
 using namespace ccvpe;
 
-extern "C" int ccvpe_stem_conv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                                   int B, int H, int W, int circular, void* stream) {
+template <typename T>
+static int stem_any(const float* x, const float* w, const float* scale, const float* shift, T* y, int B, int H, int W,
+                    int circular, void* stream) {
   if (B <= 0 || H < 3 || W < 3) return fail(CCVPE_EINVAL, "stem: bad shape");
   if (!aligned16(y)) return fail(CCVPE_EINVAL, "stem: y must be 16-byte aligned");
   const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
   const long total = (long)B * Ho * Wo;
-  hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, w,
-                     scale, shift, y, B, H, W, Ho, Wo, circular);
+  hipLaunchKernelGGL(stem_conv_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     w, scale, shift, y, B, H, W, Ho, Wo, circular);
   return check_launch("stem_conv_kernel");
+}
+
+extern "C" int ccvpe_stem_conv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                   int B, int H, int W, int circular, void* stream) {
+  return stem_any<float>(x, w, scale, shift, y, B, H, W, circular, stream);
+}
+extern "C" int ccvpe_stem_conv_bf16(const float* x, const float* w, const float* scale, const float* shift, void* y,
+                                    int B, int H, int W, int circular, void* stream) {
+  return stem_any<cc_bf16>(x, w, scale, shift, reinterpret_cast<cc_bf16*>(y), B, H, W, circular, stream);
 }
 
 extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
@@ -280,9 +291,9 @@ extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
   return nblk;
 }
 
-extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
-                                float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,
-                                void* stream) {
+template <typename T>
+static int dwconv_any(const T* x, const float* w, const float* scale, const float* shift, T* y, float* se_partial, int B,
+                      int H, int W, int C, int k, int stride, int circular, void* stream) {
   if (C <= 0 || C % 4) return fail(CCVPE_EINVAL, "dwconv: C %% 4 != 0");
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "dwconv: k/stride unsupported");
   if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(se_partial) || !aligned16(scale) ||
@@ -297,7 +308,7 @@ extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* sca
   const size_t smem = (size_t)P * cgx * 16;
   hipStream_t st = (hipStream_t)stream;
 #define DW_LAUNCH(K_, S_)                                                                                         \
-  hipLaunchKernelGGL((dwconv_kernel<K_, S_>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
+  hipLaunchKernelGGL((dwconv_kernel<T, K_, S_>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
                      C, Ho, Wo, cgx, P, nblk, circular, RB, yc, (int)total)
   if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
   else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);
@@ -305,6 +316,18 @@ extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* sca
   else DW_LAUNCH(5, 2);
 #undef DW_LAUNCH
   return check_launch("dwconv_kernel");
+}
+
+extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                                float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,
+                                void* stream) {
+  return dwconv_any<float>(x, w, scale, shift, y, se_partial, B, H, W, C, k, stride, circular, stream);
+}
+extern "C" int ccvpe_dwconv_bf16(const void* x, const float* w, const float* scale, const float* shift, void* y,
+                                 float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,
+                                 void* stream) {
+  return dwconv_any<cc_bf16>(reinterpret_cast<const cc_bf16*>(x), w, scale, shift, reinterpret_cast<cc_bf16*>(y),
+                             se_partial, B, H, W, C, k, stride, circular, stream);
 }
 
 extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, const float* w1, const float* b1,

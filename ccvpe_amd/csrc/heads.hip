@@ -40,8 +40,8 @@ __global__ __launch_bounds__(256) void gdesc_kernel(const float* __restrict__ y1
 // models.py:125-127 (conv1.2), :146-148 + :341 (conv1_ori.2 + F.normalize)
 // HBM-bound: 64 B read, 4-8 B written per pixel.  One thread per pixel, lanes along W.
 // ---------------------------------------------------------------------------------------------
-template <int COUT>
-__global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <typename TX, int COUT>
+__global__ __launch_bounds__(256) void head_conv_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int H, int W, int normalize) {
   __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 16];
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
   float acc[COUT];
 #pragma unroll
   for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
-  const float* xb = x + (size_t)b * H * W * 16;
+  const TX* xb = x + (size_t)b * H * W * 16;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
     const int iy = oy + ky - 1;
@@ -72,10 +72,10 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const float* __restrict_
     for (int kx = 0; kx < 3; ++kx) {
       const int ix = ox + kx - 1;
       if ((unsigned)ix >= (unsigned)W) continue;
-      const f32x4* px = reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * 16);
+      const TX* px = xb + ((size_t)iy * W + ix) * 16;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = px[q];
+        const f32x4 v = ld4<TX>(px + q * 4);
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[((o * 3 + ky) * 3 + kx) * 16 + q * 4]);
@@ -302,17 +302,27 @@ extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float*
   return check_launch("gdesc_kernel");
 }
 
-extern "C" int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, int B, int H,
-                                      int W, int cout, int normalize, void* stream) {
+template <typename TX>
+static int head_any(const TX* x, const float* w, const float* bias, float* out, int B, int H, int W, int cout,
+                    int normalize, void* stream) {
   if (!aligned16(x)) return fail(CCVPE_EINVAL, "head_conv: x must be 16-byte aligned");
   dim3 grid(((W + 255) / 256) * H * B);
   if (cout == 1)
-    hipLaunchKernelGGL(head_conv_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, 0);
+    hipLaunchKernelGGL((head_conv_kernel<TX, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, 0);
   else if (cout == 2)
-    hipLaunchKernelGGL(head_conv_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, normalize);
+    hipLaunchKernelGGL((head_conv_kernel<TX, 2>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, normalize);
   else
     return fail(CCVPE_EINVAL, "head_conv: cout must be 1 or 2");
   return check_launch("head_conv_kernel");
+}
+
+extern "C" int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, float* out, int B, int H,
+                                      int W, int cout, int normalize, void* stream) {
+  return head_any<float>(x, w, bias, out, B, H, W, cout, normalize, stream);
+}
+extern "C" int ccvpe_head_conv3x3_bf16(const void* x, const float* w, const float* bias, float* out, int B, int H,
+                                       int W, int cout, int normalize, void* stream) {
+  return head_any<cc_bf16>(reinterpret_cast<const cc_bf16*>(x), w, bias, out, B, H, W, cout, normalize, stream);
 }
 
 extern "C" int ccvpe_softmax_rows_f32(const float* in, float* out, int rows, int n, void* stream) {

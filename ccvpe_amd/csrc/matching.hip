@@ -32,11 +32,12 @@ struct MatchOffsets {
 
 constexpr int MCK = 32;  // channels per staged tile
 
-template <int NPAD, bool PARTIAL, int VEC>
-__global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+// TX = storage type of X and of the concat output (float or bf16); scores, g and all math are fp32.
+template <typename TX, int NPAD, bool PARTIAL, int VEC>
+__global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, int ldx, const float* __restrict__ g,
                                                     int ldg, int L, const MatchOffsets mo, int n_shifts, int n_max,
                                                     int n_tail, float* __restrict__ scores,
-                                                    float* __restrict__ dstx, int ldo, int hw, int C) {
+                                                    TX* __restrict__ dstx, int ldo, int hw, int C) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int TPB = blockDim.x;
   const int XLD = TPB + 1;
@@ -51,7 +52,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
   const int p0 = blockIdx.x * TPB;
   const int p = p0 + tid;
   const bool pvalid = p < hw;
-  const float* xb = x + (size_t)b * hw * ldx;
+  const TX* xb = x + (size_t)b * hw * ldx;
 
   // descriptor tables + ||g||
   float gsq = 0.f;
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
       const int pp = idx / f4_per_row;
       const int cq = (idx - pp * f4_per_row) * 4;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p0 + pp < hw && cq < ck) v = *reinterpret_cast<const f32x4*>(xb + (size_t)(p0 + pp) * ldx + c0 + cq);
+      if (p0 + pp < hw && cq < ck) v = ld4<TX>(xb + (size_t)(p0 + pp) * ldx + c0 + cq);
       xs[(cq + 0) * XLD + pp] = v[0];
       xs[(cq + 1) * XLD + pp] = v[1];
       xs[(cq + 2) * XLD + pp] = v[2];
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
   // scores, max (NaN-propagating like torch.max), extras
   float mx = 0.f;
   if (pvalid) {
-    float* drow = dstx + ((size_t)b * hw + p) * ldo;
+    TX* drow = dstx + ((size_t)b * hw + p) * ldo;
     const int tail0 = n_shifts - n_tail;
 #pragma unroll
     for (int i = 0; i < NPAD; ++i) {
@@ -144,11 +145,11 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
         scores[((size_t)b * n_shifts + i) * hw + p] = s;
         if (i == 0) mx = s;
         else if (i < n_max && (s > mx || s != s)) mx = s;
-        if (i >= tail0) drow[C + 1 + (i - tail0)] = s;
+        if (i >= tail0) drow[C + 1 + (i - tail0)] = (TX)s;
       }
     }
-    drow[C] = mx;
-    for (int c = C + 1 + n_tail; c < ldo; ++c) drow[c] = 0.f;
+    drow[C] = (TX)mx;
+    for (int c = C + 1 + n_tail; c < ldo; ++c) drow[c] = (TX)0.f;
   }
   inv_s[tid] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   __syncthreads();
@@ -159,9 +160,9 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
   for (int idx = tid; idx < npx * c4n; idx += TPB) {
     const int pp = idx / c4n;
     const int c4 = (idx - pp * c4n) * 4;
-    f32x4 v = *reinterpret_cast<const f32x4*>(xb + (size_t)(p0 + pp) * ldx + c4);
+    f32x4 v = ld4<TX>(xb + (size_t)(p0 + pp) * ldx + c4);
     v *= inv_s[pp];
-    *reinterpret_cast<f32x4*>(dstx + ((size_t)b * hw + p0 + pp) * ldo + c4) = v;
+    st4<TX>(dstx + ((size_t)b * hw + p0 + pp) * ldo + c4, v);
   }
 }
 
@@ -169,14 +170,14 @@ __global__ __launch_bounds__(256) void match_kernel(const float* __restrict__ x,
 
 using namespace ccvpe;
 
-template <int NPAD, bool PARTIAL, int VEC>
-static int launch_match(const float* x, int ldx, const float* g, int ldg, int L, const MatchOffsets& mo, int n_shifts,
-                        int n_max, int n_tail, float* scores, float* dstx, int ldo, int B, int hw, int C,
+template <typename TX, int NPAD, bool PARTIAL, int VEC>
+static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, const MatchOffsets& mo, int n_shifts,
+                        int n_max, int n_tail, float* scores, TX* dstx, int ldo, int B, int hw, int C,
                         hipStream_t st) {
   const int tpb = hw >= 256 ? 256 : ((hw + 63) / 64) * 64;
   const size_t smem = sizeof(float) * ((size_t)2 * C * (PARTIAL ? 2 : 1) + (size_t)MCK * (tpb + 1) + tpb + 4);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level: C=%d needs %zu B of LDS", C, smem);
-  auto kern = match_kernel<NPAD, PARTIAL, VEC>;
+  auto kern = match_kernel<TX, NPAD, PARTIAL, VEC>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "match_level: set smem attr: %s", hipGetErrorString(e));
@@ -187,9 +188,9 @@ static int launch_match(const float* x, int ldx, const float* g, int ldg, int L,
   return check_launch("match_kernel");
 }
 
-extern "C" int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                                     int n_shifts, int n_max, int n_tail, int stride, float* scores, float* dstx,
-                                     int ldo, int B, int hw, int C, void* stream) {
+template <typename TX>
+static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts, int n_max,
+                     int n_tail, int stride, float* scores, TX* dstx, int ldo, int B, int hw, int C, void* stream) {
   if (n_shifts < 1 || n_shifts > CCVPE_MAX_SHIFTS) return fail(CCVPE_EINVAL, "match_level: n_shifts %d out of range", n_shifts);
   if (n_max < 1 || n_max > n_shifts || n_tail < 0 || n_tail > n_shifts) return fail(CCVPE_EINVAL, "match_level: bad n_max/n_tail");
   if (C % 8 || ldx % 4 || ldo % 4 || ldo < C + 1 + n_tail) return fail(CCVPE_EINVAL, "match_level: C%%8, ldx%%4, ldo%%4, ldo>=C+1+n_tail required");
@@ -212,14 +213,27 @@ extern "C" int ccvpe_match_level_f32(const float* x, int ldx, const float* g, in
 #define M_DISPATCH(NP)                                              \
   if (n_shifts <= NP) {                                             \
     if (partial) {                                                  \
-      if (vec == 4) return launch_match<NP, true, 4>(M_ARGS);       \
-      return launch_match<NP, true, 2>(M_ARGS);                     \
+      if (vec == 4) return launch_match<TX, NP, true, 4>(M_ARGS);   \
+      return launch_match<TX, NP, true, 2>(M_ARGS);                 \
     }                                                               \
-    if (vec == 4) return launch_match<NP, false, 4>(M_ARGS);        \
-    return launch_match<NP, false, 2>(M_ARGS);                      \
+    if (vec == 4) return launch_match<TX, NP, false, 4>(M_ARGS);    \
+    return launch_match<TX, NP, false, 2>(M_ARGS);                  \
   }
   M_DISPATCH(1) M_DISPATCH(8) M_DISPATCH(16) M_DISPATCH(24) M_DISPATCH(48)
 #undef M_DISPATCH
 #undef M_ARGS
   return fail(CCVPE_EINVAL, "match_level: unreachable");
+}
+
+extern "C" int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
+                                     int n_shifts, int n_max, int n_tail, int stride, float* scores, float* dstx,
+                                     int ldo, int B, int hw, int C, void* stream) {
+  return match_any<float>(x, ldx, g, ldg, L, shifts, n_shifts, n_max, n_tail, stride, scores, dstx, ldo, B, hw, C,
+                          stream);
+}
+extern "C" int ccvpe_match_level_bf16(const void* x, int ldx, const float* g, int ldg, int L, const int* shifts,
+                                      int n_shifts, int n_max, int n_tail, int stride, float* scores, void* dstx,
+                                      int ldo, int B, int hw, int C, void* stream) {
+  return match_any<cc_bf16>(reinterpret_cast<const cc_bf16*>(x), ldx, g, ldg, L, shifts, n_shifts, n_max, n_tail,
+                            stride, scores, reinterpret_cast<cc_bf16*>(dstx), ldo, B, hw, C, stream);
 }

@@ -23,14 +23,14 @@ namespace ccvpe {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MbFrontParams {
-  const float* x;
-  const float* w_exp;
+  const void* x;
+  const void* w_exp;
   const float* s0;
   const float* b0;
   const float* w_dw;
   const float* s1;
   const float* b1;
-  float* y;
+  void* y;
   float* se_partial;
   int H, W, Cin, kpad, mid, Ho, Wo, circular;
   int rb, nbands, nchunks, total_blocks;
@@ -41,8 +41,12 @@ constexpr int MBF_MAXT = 5;     // 16-pixel tiles per wave per row: W <= 320
 // The kernel is instantiated per (tiles per wave T, k-chunks NKK) so that the register-resident row
 // costs T*NKK dwordx4 only: narrow rows keep their occupancy (a fixed T=5 needed 199 VGPRs).
 
-template <int K, int S, int T, int NKK>
+// TE = storage type of x / w_exp / y (float or bf16).  NKK counts 64-byte K pieces: 16 fp32 or 32 bf16
+// input channels each; the ring (expanded tensor) and all depthwise math stay fp32 either way.
+template <typename TE, int K, int S, int T, int NKK>
 __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p) {
+  constexpr int E = 16 / sizeof(TE);
+  constexpr int SK = 4 * E;
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;   // pad before (224-schedule SAME)
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* ring = sm;                                  // [K][W][16]
@@ -77,13 +81,15 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 #pragma unroll
   for (int kk = 0; kk < NKK; ++kk) {
     wf[kk] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (kk < nkk) wf[kk] = *reinterpret_cast<const f32x4*>(p.w_exp + (size_t)(c0 + (lane & 15)) * p.kpad + kk * 16 + q4);
+    if (kk < nkk)
+      wf[kk] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const TE*>(p.w_exp) + (size_t)(c0 + (lane & 15)) * p.kpad +
+                                               kk * SK + (lane >> 4) * E);
   }
   const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.s0 + c0 + q4);
   const f32x4 sh0 = *reinterpret_cast<const f32x4*>(p.b0 + c0 + q4);
 
   const int ntile = (p.W + 15) >> 4;
-  const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+  const TE* xb = reinterpret_cast<const TE*>(p.x) + (size_t)b * p.H * p.W * p.Cin;
   const int last_needed = (oy1 - 1) * S - PB + K - 1;
 
   // Register-resident x fragments of ONE input row for this wave's tiles (<= MBF_MAXT tiles x
@@ -93,13 +99,13 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   f32x4 xv[T][NKK];
   auto prefetch_row = [&](int iy) {
     const bool rowok = (unsigned)iy < (unsigned)p.H && iy <= last_needed;
-    const float* xr = xb + (size_t)(rowok ? iy : 0) * p.W * p.Cin;
+    const TE* xr = xb + (size_t)(rowok ? iy : 0) * p.W * p.Cin;
 #pragma unroll
     for (int ti = 0; ti < T; ++ti) {
       const int px = (wave + 4 * ti) * 16 + (lane & 15);
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
-        const int ch = kk * 16 + q4;
+        const int ch = kk * SK + (lane >> 4) * E;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (rowok && kk < nkk && px < p.W && ch < p.Cin) v = *reinterpret_cast<const f32x4*>(xr + (size_t)px * p.Cin + ch);
         xv[ti][kk] = v;
@@ -122,9 +128,14 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk)
           if (kk < nkk) {
+            if (sizeof(TE) == 4) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-              acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xv[ti][kk][r], acc[ti], 0, 0, 0);
+              for (int r = 0; r < 4; ++r)
+                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xv[ti][kk][r], acc[ti], 0, 0, 0);
+            } else {
+              acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]),
+                                                                __builtin_bit_cast(cc_bf16x8, xv[ti][kk]), acc[ti], 0, 0, 0);
+            }
           }
       }
     }
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
       f32x4 o = acc * sc1 + sh1;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = swishf(o[r]);
-      *reinterpret_cast<f32x4*>(p.y + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.mid + c0 + cg * 4) = o;
+      st4<TE>(reinterpret_cast<TE*>(p.y) + ((size_t)(b * p.Ho + oy) * p.Wo + ox) * p.mid + c0 + cg * 4, o);
       sum += o;
     }
     __syncthreads();
@@ -199,8 +210,8 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 
 constexpr int MBF_RB = 16;
 
-static bool mbf_supported(int W, int cin, int mid, int k) {
-  return cin % 8 == 0 && cin <= 16 * MBF_MAX_KK && mid % 16 == 0 && W >= 1 &&
+static bool mbf_supported(int W, int cin, int mid, int k, int sk = 16) {
+  return cin % 8 == 0 && cin <= sk * MBF_MAX_KK && mid % 16 == 0 && W >= 1 &&
          W <= 64 * MBF_MAXT && (size_t)((k * W * 16 > 1024 ? k * W * 16 : 1024) + k * k * 16) * 4 <= 64 * 1024;
 }
 
@@ -216,13 +227,14 @@ extern "C" int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int
   return (Ho + MBF_RB - 1) / MBF_RB;
 }
 
-extern "C" int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kpad, const float* s0, const float* b0,
-                                      const float* w_dw, const float* s1, const float* b1, float* y,
-                                      float* se_partial, int B, int H, int W, int cin, int mid, int k, int stride,
-                                      int circular, void* stream) {
+template <typename TE>
+static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const float* s0, const float* b0,
+                            const float* w_dw, const float* s1, const float* b1, void* y, float* se_partial, int B,
+                            int H, int W, int cin, int mid, int k, int stride, int circular, void* stream) {
+  constexpr int SK = 4 * (16 / (int)sizeof(TE));
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "mbconv_front: k/stride unsupported");
-  if (!mbf_supported(W, cin, mid, k)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
-  if (kpad % 16 || kpad < cin) return fail(CCVPE_EINVAL, "mbconv_front: bad kpad");
+  if (!mbf_supported(W, cin, mid, k, SK)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
+  if (kpad % SK || kpad < cin) return fail(CCVPE_EINVAL, "mbconv_front: bad kpad");
   if (!aligned16(x) || !aligned16(w_exp) || !aligned16(s0) || !aligned16(b0) || !aligned16(s1) || !aligned16(b1) ||
       !aligned16(y) || !aligned16(se_partial))
     return fail(CCVPE_EINVAL, "mbconv_front: pointers must be 16-byte aligned");
@@ -242,9 +254,9 @@ extern "C" int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kp
   hipStream_t st = (hipStream_t)stream;
   const int tneed = ((W + 15) / 16 + 3) / 4;          // 16-pixel tiles per wave per row
   const int tsel = tneed <= 1 ? 1 : (tneed <= 2 ? 2 : (tneed <= 3 ? 3 : 5));
-  const int nkk = (cin + 15) / 16;
+  const int nkk = (cin + SK - 1) / SK;
 #define MBF_LAUNCH(K_, S_, T_, N_) \
-  hipLaunchKernelGGL((mbconv_front_kernel<K_, S_, T_, N_>), dim3(p.total_blocks), dim3(256), smem, st, p)
+  hipLaunchKernelGGL((mbconv_front_kernel<TE, K_, S_, T_, N_>), dim3(p.total_blocks), dim3(256), smem, st, p)
 #define MBF_N(K_, S_, T_)                    \
   if (nkk == 1) MBF_LAUNCH(K_, S_, T_, 1);   \
   else if (nkk == 2) MBF_LAUNCH(K_, S_, T_, 2); \
@@ -262,4 +274,19 @@ extern "C" int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kp
 #undef MBF_N
 #undef MBF_LAUNCH
   return check_launch("mbconv_front_kernel");
+}
+
+extern "C" int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kpad, const float* s0, const float* b0,
+                                      const float* w_dw, const float* s1, const float* b1, float* y,
+                                      float* se_partial, int B, int H, int W, int cin, int mid, int k, int stride,
+                                      int circular, void* stream) {
+  return mbconv_front_any<float>(x, w_exp, kpad, s0, b0, w_dw, s1, b1, y, se_partial, B, H, W, cin, mid, k, stride,
+                                 circular, stream);
+}
+extern "C" int ccvpe_mbconv_front_bf16(const void* x, const void* w_exp, int kpad, const float* s0, const float* b0,
+                                       const float* w_dw, const float* s1, const float* b1, void* y,
+                                       float* se_partial, int B, int H, int W, int cin, int mid, int k, int stride,
+                                       int circular, void* stream) {
+  return mbconv_front_any<cc_bf16>(x, w_exp, kpad, s0, b0, w_dw, s1, b1, y, se_partial, B, H, W, cin, mid, k, stride,
+                                   circular, stream);
 }

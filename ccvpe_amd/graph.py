@@ -25,7 +25,7 @@ class GraphedForward(object):
                 net(self.grd, self.sat)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._wkey = net._weights_key()
+        self._wkey = (net.precision,) + net._weights_key()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = net(self.grd, self.sat)
@@ -33,7 +33,7 @@ class GraphedForward(object):
     def __call__(self, grd, sat):
         """Copies the inputs into the captured buffers, replays, returns the captured outputs
         (static tensors: clone them if they must survive the next replay)."""
-        if self.net._weights_key() != self._wkey:
+        if (self.net.precision,) + self.net._weights_key() != self._wkey:
             raise RuntimeError("model weights changed after capture; build a new GraphedForward")
         if grd.shape != self.grd.shape or sat.shape != self.sat.shape:
             raise ValueError("captured for %s / %s" % (tuple(self.grd.shape), tuple(self.sat.shape)))

@@ -60,17 +60,19 @@ def _populate(root, kind, init):
 # ----------------------------------------------------------------------------------------
 # weight re-packing (runs once per weight version, on the device, with torch ops)
 # ----------------------------------------------------------------------------------------
-def _pad2(w, n_mult=16, k_mult=16):
+def _pad2(w, dtype=torch.float32, n_mult=16):
+    """Zero-pad [N,K] to N%16==0 and K to one 64-byte stage row (16 fp32 / 32 bf16), cast to dtype."""
+    k_mult = 16 if dtype == torch.float32 else 32
     n, k = w.shape
     out = w.new_zeros((_round_up(n, n_mult), _round_up(k, k_mult)))
     out[:n, :k] = w
-    return out.contiguous()
+    return out.to(dtype).contiguous()
 
 
-def _pack_conv(w):
-    """OIHW -> [O][kh][kw][I] rows, zero-padded (N to 16, K to 16)."""
+def _pack_conv(w, dtype=torch.float32):
+    """OIHW -> [O][kh][kw][I] rows, zero-padded (N to 16, K to a 64-byte multiple)."""
     o = w.shape[0]
-    return _pad2(w.permute(0, 2, 3, 1).reshape(o, -1))
+    return _pad2(w.permute(0, 2, 3, 1).reshape(o, -1), dtype)
 
 
 def _fold_bn(sd, p):
@@ -83,7 +85,7 @@ class _Obj(object):
     pass
 
 
-def _pack_encoder(sd, p):
+def _pack_encoder(sd, p, dtype=torch.float32):
     e = _Obj()
     e.stem_w = sd[p + "._conv_stem.weight"].permute(2, 3, 1, 0).contiguous()      # [ky][kx][ci][co]
     e.stem_scale, e.stem_shift = _fold_bn(sd, p + "._bn0")
@@ -93,7 +95,7 @@ def _pack_encoder(sd, p):
         bp = "%s._blocks.%d" % (p, i)
         b.k, b.s, b.expand, b.cin, b.cout, b.mid = k, s, ex != 1, cin, cout, cin * ex
         if b.expand:
-            b.w_exp = _pack_conv(sd[bp + "._expand_conv.weight"])
+            b.w_exp = _pack_conv(sd[bp + "._expand_conv.weight"], dtype)
             b.s0, b.b0 = _fold_bn(sd, bp + "._bn0")
         b.w_dw = sd[bp + "._depthwise_conv.weight"].reshape(b.mid, k, k).permute(1, 2, 0).contiguous()
         b.s1, b.b1 = _fold_bn(sd, bp + "._bn1")
@@ -101,16 +103,16 @@ def _pack_encoder(sd, p):
         b.se_b1 = sd[bp + "._se_reduce.bias"].contiguous()
         b.se_w2 = sd[bp + "._se_expand.weight"].reshape(b.mid, -1).t().contiguous()      # [Cs][C]
         b.se_b2 = sd[bp + "._se_expand.bias"].contiguous()
-        b.w_proj = _pack_conv(sd[bp + "._project_conv.weight"])
+        b.w_proj = _pack_conv(sd[bp + "._project_conv.weight"], dtype)
         b.s2, b.b2 = _fold_bn(sd, bp + "._bn2")
         b.skip = (s == 1 and cin == cout)                                          # model.py:126
         e.blocks.append(b)
-    e.w_head = _pack_conv(sd[p + "._conv_head.weight"])
+    e.w_head = _pack_conv(sd[p + "._conv_head.weight"], dtype)
     e.head_scale, e.head_shift = _fold_bn(sd, p + "._bn1")
     return e
 
 
-def _pack_deconv(w, bias, col_map, ldo):
+def _pack_deconv(w, bias, col_map, ldo, dtype=torch.float32):
     """ConvTranspose2d weight [Cin,Cout,2,2] -> GEMM rows n=(dy*2+dx)*Cout+co over this
     implementation's K order.  col_map: list of (dst_start, src_start, length)."""
     cin, cout = w.shape[0], w.shape[1]
@@ -118,14 +120,15 @@ def _pack_deconv(w, bias, col_map, ldo):
     out = w.new_zeros((4 * cout, ldo))
     for d0, s0, n in col_map:
         out[:, d0:d0 + n] = wg[:, s0:s0 + n]
-    return _pad2(out), bias.repeat(4).contiguous()
+    return _pad2(out, dtype), bias.repeat(4).contiguous()
 
 
-def _pack_model(sd, kind, n_tail):
+def _pack_model(sd, kind, n_tail, dtype=torch.float32):
     spec = MODEL_SPECS[kind]
     pk = _Obj()
-    pk.grd = _pack_encoder(sd, "grd_efficientnet")
-    pk.sat = _pack_encoder(sd, "sat_efficientnet")
+    pk.dtype = dtype
+    pk.grd = _pack_encoder(sd, "grd_efficientnet", dtype)
+    pk.sat = _pack_encoder(sd, "sat_efficientnet", dtype)
     # six ground-descriptor heads fused into one 1x1 GEMM (N = sum Cd) + height collapse
     ws, bs, wh, bh = [], [], [], []
     for l in range(1, 7):
@@ -134,14 +137,14 @@ def _pack_model(sd, kind, n_tail):
         bs.append(sd[p + ".0.bias"])
         wh.append(sd[p + ".2.weight"].reshape(-1))
         bh.append(sd[p + ".2.bias"].reshape(-1))
-    pk.gd_w = _pad2(torch.cat(ws, 0))
+    pk.gd_w = _pad2(torch.cat(ws, 0), dtype)
     pk.gd_bias = torch.cat(bs, 0).contiguous()
     pk.gd_n = pk.gd_bias.shape[0]
     pk.gd_wh = torch.stack(wh, 0).contiguous()
     pk.gd_bh = torch.cat(bh, 0).contiguous()
     # aerial descriptor Linear(5120 -> N) == conv 2x2 stride 2 (models.py:102-104,173-184)
     w = sd["sat_feature_to_descriptors.1.weight"]
-    pk.sd_w = _pack_conv(w.view(w.shape[0], 1280, 2, 2))
+    pk.sd_w = _pack_conv(w.view(w.shape[0], 1280, 2, 2), dtype)
     pk.sd_bias = sd["sat_feature_to_descriptors.1.bias"].contiguous()
     pk.sd_n = w.shape[0]
 
@@ -157,13 +160,13 @@ def _pack_model(sd, kind, n_tail):
         lv.c, lv.ldo, lv.up_n = c, ldo, 4 * dc_out
         # reference concat order is [max, X]; ours is [X, max, (tail), pad]
         lv.up_w, lv.up_b = _pack_deconv(sd["deconv%d.weight" % lvl], sd["deconv%d.bias" % lvl],
-                                        [(0, 1, c), (c, 0, 1)], ldo)
+                                        [(0, 1, c), (c, 0, 1)], ldo, dtype)
         lv.c0, lv.c1 = dc_out, c_in - dc_out
-        lv.w_a = _pack_conv(sd["conv%d.0.weight" % lvl])
+        lv.w_a = _pack_conv(sd["conv%d.0.weight" % lvl], dtype)
         lv.b_a = sd["conv%d.0.bias" % lvl].contiguous()
         lv.n_a = c_out
         if lvl != 1:
-            lv.w_b = _pack_conv(sd["conv%d.2.weight" % lvl])
+            lv.w_b = _pack_conv(sd["conv%d.2.weight" % lvl], dtype)
             lv.n_b = c_out
         else:
             lv.w_b = sd["conv1.2.weight"].permute(0, 2, 3, 1).contiguous()      # [1][3][3][16]
@@ -178,18 +181,18 @@ def _pack_model(sd, kind, n_tail):
             ov.k_algo = dc_in
             # reference order [scores(n_rot), X]; ours [X, max, scores, pad]
             ov.up_w, ov.up_b = _pack_deconv(sd["deconv6_ori.weight"], sd["deconv6_ori.bias"],
-                                            [(0, n_rot, c6), (c6 + 1, 0, n_rot)], pk.loc[0].ldo)
+                                            [(0, n_rot, c6), (c6 + 1, 0, n_rot)], pk.loc[0].ldo, dtype)
         else:
             ov.k = ov.k_algo = dc_in
             ov.up_w, ov.up_b = _pack_deconv(sd["deconv%d_ori.weight" % lvl], sd["deconv%d_ori.bias" % lvl],
-                                            [(0, 0, dc_in)], dc_in)
+                                            [(0, 0, dc_in)], dc_in, dtype)
         ov.up_n = 4 * dc_out
         ov.c0, ov.c1 = dc_out, c_in - dc_out
-        ov.w_a = _pack_conv(sd["conv%d_ori.0.weight" % lvl])
+        ov.w_a = _pack_conv(sd["conv%d_ori.0.weight" % lvl], dtype)
         ov.b_a = sd["conv%d_ori.0.bias" % lvl].contiguous()
         ov.n_a = c_out
         if lvl != 1:
-            ov.w_b = _pack_conv(sd["conv%d_ori.2.weight" % lvl])
+            ov.w_b = _pack_conv(sd["conv%d_ori.2.weight" % lvl], dtype)
             ov.n_b = c_out
         else:
             ov.w_b = sd["conv1_ori.2.weight"].permute(0, 2, 3, 1).contiguous()  # [2][3][3][16]
@@ -201,9 +204,9 @@ def _pack_model(sd, kind, n_tail):
 # ----------------------------------------------------------------------------------------
 # forward building blocks (every line below enqueues HIP kernels through the C ABI)
 # ----------------------------------------------------------------------------------------
-def _run_encoder(e, img, circular, multiscale):
+def _run_encoder(e, img, circular, multiscale, dtype=torch.float32):
     """EfficientNet.extract_features[_multiscale] (efficientnet_pytorch/model.py:278-326)."""
-    x = ops.stem_conv(img, e.stem_w, e.stem_scale, e.stem_shift, circular)
+    x = ops.stem_conv(img, e.stem_w, e.stem_scale, e.stem_shift, circular, out_dtype=dtype)
     feats = []
     for blk in e.blocks:
         b, h, w, _ = x.shape
@@ -255,6 +258,16 @@ class _CVMBase(nn.Module):
         _populate(self, self.kind, _INIT_CACHE[self.kind])
         self._pack_cache = None
         self._pack_key = None
+        self.precision = "fp32"
+
+    def set_precision(self, precision):
+        """'fp32' (default: exact fp32 everywhere) or 'bf16' (BASELINE C2/C4: bf16 NHWC activations and
+        packed weights, fp32 accumulation/BN/SE/softmax; scores, logits, heat-map and orientation are
+        returned in fp32 either way)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        return self
 
     # -- weight version tracking -------------------------------------------------------------
     def _weights_key(self):
@@ -264,15 +277,16 @@ class _CVMBase(nn.Module):
         return tuple(key)
 
     def _packed(self):
-        key = self._weights_key()
+        key = (self.precision,) + self._weights_key()
         if self._pack_cache is None or key != self._pack_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device
             if dev.type != "cuda":
                 raise RuntimeError("ccvpe_amd: move the model to the MI355X first (.to('cuda'))")
             n_tail = MODEL_SPECS[self.kind]["n_rot"]
+            dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
             with torch.no_grad():
-                self._pack_cache = _pack_model(sd, self.kind, n_tail)
+                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype)
             self._pack_key = key
         return self._pack_cache
 
@@ -301,15 +315,15 @@ class _CVMBase(nn.Module):
             batch = grd.shape[0]
 
             # encoders + descriptors (models.py:151-184)
-            gfeat, _ = _run_encoder(pk.grd, grd, circular, False)
+            gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
             _, gh, gw, _ = gfeat.shape
             if gh != spec["grd_h"]:
                 raise ValueError("ground feature height %d != %d expected by the descriptor heads"
                                  % (gh, spec["grd_h"]))
             y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw,
-                                shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4))
+                                shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4), out_f32=True)
             gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
-            svol, sfeats = _run_encoder(pk.sat, sat, False, True)
+            svol, sfeats = _run_encoder(pk.sat, sat, False, True, pk.dtype)
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
                                    in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
 

@@ -77,22 +77,34 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
-def _chk(t, name):
+def _chk(t, name, dtype=torch.float32):
     if t is None:
         return
-    if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
-        raise ValueError("%s must be a contiguous fp32 device tensor (got %s %s contiguous=%s)" % (
-            name, t.device, t.dtype, t.is_contiguous()))
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise ValueError("%s must be a contiguous %s device tensor (got %s %s contiguous=%s)" % (
+            name, dtype, t.device, t.dtype, t.is_contiguous()))
+
+
+def _act_dtype(t):
+    """Activation storage type of a call: fp32 or bf16 (selects the _f32 / _bf16 entry point)."""
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("activations must be fp32 or bf16, got %s" % t.dtype)
+    return t.dtype
 
 
 def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0,
                src1=None, c1=0, gate=None, scale=None, shift=None, residual=None, act=ACT_NONE,
-               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None, algo_k=None):
-    """Implicit-GEMM conv / deconv / linear (ccvpe_conv_igemm_f32).  src tensors are NHWC."""
+               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None, algo_k=None, out_f32=False):
+    """Implicit-GEMM conv / deconv / linear (ccvpe_conv_igemm_f32 / _bf16 by src0.dtype).
+    src tensors are NHWC.  out_f32 (bf16 only): write an fp32 result."""
     lib = _lib.load()
-    for t, nm in ((src0, "src0"), (src1, "src1"), (gate, "gate"), (w_packed, "w"), (scale, "scale"),
-                  (shift, "shift"), (residual, "residual"), (dst, "dst")):
+    dt = _act_dtype(src0)
+    odt = torch.float32 if (out_f32 or dt == torch.float32) else dt
+    for t, nm in ((src0, "src0"), (src1, "src1"), (w_packed, "w"), (residual, "residual")):
+        _chk(t, nm, dt)
+    for t, nm in ((gate, "gate"), (scale, "scale"), (shift, "shift")):
         _chk(t, nm)
+    _chk(dst, "dst", odt)
     ld0 = ld0 if ld0 is not None else src0.shape[-1]
     ld1 = ld1 if ld1 is not None else (src1.shape[-1] if src1 is not None else 0)
     ho = (in_h + 2 * pad - kh) // stride + 1
@@ -105,7 +117,7 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         oshape = (batch, ho, wo)
     if dst is None:
         ldd = ldd if ldd is not None else cout
-        dst = torch.empty(oshape + (ldd,), device=src0.device, dtype=torch.float32)
+        dst = torch.empty(oshape + (ldd,), device=src0.device, dtype=odt)
     elif ldd is None:
         ldd = dst.shape[-1]
     d = ConvDesc()
@@ -120,20 +132,27 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     d.act, d.out_mode = act, out_mode
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
-    check(lib.ccvpe_conv_igemm_f32(ctypes.byref(d), _stream()), "ccvpe_conv_igemm_f32")
+    if dt == torch.float32:
+        check(lib.ccvpe_conv_igemm_f32(ctypes.byref(d), _stream()), "ccvpe_conv_igemm_f32")
+    else:
+        check(lib.ccvpe_conv_igemm_bf16(ctypes.byref(d), int(bool(out_f32)), _stream()), "ccvpe_conv_igemm_bf16")
     if rec is not None:
         m = batch * ho * wo
         k_alg = algo_k if algo_k is not None else kh * kw * (c0 + c1)
         flops = 2.0 * m * n * k_alg
         # algorithmic bytes: input read once, output written once, weights once
-        nbytes = 4.0 * (batch * in_h * in_w * (c0 + c1) + m * n + n * k_alg
+        esz = 4.0 if dt == torch.float32 else 2.0
+        nbytes = esz * (batch * in_h * in_w * (c0 + c1) + m * n + n * k_alg
                         + (m * n if residual is not None else 0))
         is3x3 = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and out_mode == OUT_NHWC and gate is None)
-        rec.end(igemm_tile(n, is3x3), "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
+        name = igemm_tile(n, is3x3)
+        if dt != torch.float32:
+            name = name.replace("_f32_kernel<", "_kernel<bf16,")
+        rec.end(name, "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
     return dst
 
 
-def stem_conv(x_nchw, w, scale, shift, circular):
+def stem_conv(x_nchw, w, scale, shift, circular, out_dtype=torch.float32):
     lib = _lib.load()
     for t, nm in ((x_nchw, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):
         _chk(t, nm)
@@ -141,16 +160,19 @@ def stem_conv(x_nchw, w, scale, shift, circular):
     if c != 3:
         raise ValueError("stem expects 3 input channels")
     ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
-    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=torch.float32)
-    check(lib.ccvpe_stem_conv_f32(_ptr(x_nchw), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), b, h, wd,
-                                  int(bool(circular)), _stream()), "ccvpe_stem_conv_f32")
+    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=out_dtype)
+    fn = lib.ccvpe_stem_conv_f32 if out_dtype == torch.float32 else lib.ccvpe_stem_conv_bf16
+    check(fn(_ptr(x_nchw), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), b, h, wd, int(bool(circular)), _stream()),
+          "ccvpe_stem_conv")
     return y
 
 
 def dwconv(x, w, scale, shift, k, stride, circular):
     """Depthwise conv + BN + swish; returns (y, se_partial [B,nblk,C])."""
     lib = _lib.load()
-    for t, nm in ((x, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):
+    dt = _act_dtype(x)
+    _chk(x, "x", dt)
+    for t, nm in ((w, "w"), (scale, "scale"), (shift, "shift")):
         _chk(t, nm)
     b, h, wd, c = x.shape
     tot = (k - 1) if stride == 1 else (k - 2)
@@ -158,10 +180,11 @@ def dwconv(x, w, scale, shift, k, stride, circular):
     nblk = lib.ccvpe_dwconv_nblk(h, wd, c, stride)
     if nblk <= 0:
         raise _lib.CcvpeError("ccvpe_dwconv_nblk rejected shape %s" % (tuple(x.shape),))
-    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=dt)
     part = torch.empty((b, nblk, c), device=x.device, dtype=torch.float32)
-    check(lib.ccvpe_dwconv_f32(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), _ptr(part), b, h, wd, c,
-                               k, stride, int(bool(circular)), _stream()), "ccvpe_dwconv_f32")
+    fn = lib.ccvpe_dwconv_f32 if dt == torch.float32 else lib.ccvpe_dwconv_bf16
+    check(fn(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), _ptr(part), b, h, wd, c, k, stride,
+             int(bool(circular)), _stream()), "ccvpe_dwconv")
     return y, part
 
 
@@ -175,7 +198,10 @@ def mbconv_front_supported(in_h, in_w, cin, mid, k, stride):
 def mbconv_front(x, w_exp, s0, b0, w_dw, s1, b1, mid, k, stride, circular):
     """Fused expand + depthwise (+BN+swish each) + SE squeeze partials; returns (y, se_partial)."""
     lib = _lib.load()
-    for t, nm in ((x, "x"), (w_exp, "w_exp"), (s0, "s0"), (b0, "b0"), (w_dw, "w_dw"), (s1, "s1"), (b1, "b1")):
+    dt = _act_dtype(x)
+    _chk(x, "x", dt)
+    _chk(w_exp, "w_exp", dt)
+    for t, nm in ((s0, "s0"), (b0, "b0"), (w_dw, "w_dw"), (s1, "s1"), (b1, "b1")):
         _chk(t, nm)
     b, h, wd, cin = x.shape
     nblk = mbconv_front_supported(h, wd, cin, mid, k, stride)
@@ -183,16 +209,16 @@ def mbconv_front(x, w_exp, s0, b0, w_dw, s1, b1, mid, k, stride, circular):
         raise _lib.CcvpeError("mbconv_front: unsupported shape %s" % (tuple(x.shape),))
     tot = (k - 1) if stride == 1 else (k - 2)
     ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
-    y = torch.empty((b, ho, wo, mid), device=x.device, dtype=torch.float32)
+    y = torch.empty((b, ho, wo, mid), device=x.device, dtype=dt)
     part = torch.empty((b, nblk, mid), device=x.device, dtype=torch.float32)
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
-    check(lib.ccvpe_mbconv_front_f32(_ptr(x), _ptr(w_exp), w_exp.shape[1], _ptr(s0), _ptr(b0), _ptr(w_dw), _ptr(s1),
-                                     _ptr(b1), _ptr(y), _ptr(part), b, h, wd, cin, mid, k, stride,
-                                     int(bool(circular)), _stream()), "ccvpe_mbconv_front_f32")
+    fn = lib.ccvpe_mbconv_front_f32 if dt == torch.float32 else lib.ccvpe_mbconv_front_bf16
+    check(fn(_ptr(x), _ptr(w_exp), w_exp.shape[1], _ptr(s0), _ptr(b0), _ptr(w_dw), _ptr(s1), _ptr(b1), _ptr(y),
+             _ptr(part), b, h, wd, cin, mid, k, stride, int(bool(circular)), _stream()), "ccvpe_mbconv_front")
     if rec is not None:
         flops = 2.0 * b * h * wd * cin * mid + 2.0 * b * ho * wo * mid * k * k
-        nbytes = 4.0 * (b * h * wd * cin + b * ho * wo * mid)
+        nbytes = (4.0 if dt == torch.float32 else 2.0) * (b * h * wd * cin + b * ho * wo * mid)
         rec.end("mbconv_front_kernel<%d,%d>" % (k, stride), "in %dx%dx%d mid %d" % (h, wd, cin, mid), flops, nbytes, ev0)
     return y, part
 
@@ -225,7 +251,8 @@ def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None):
     """Fused rotational matching.  x [B,H,W,ldx]; g [B,ldg] view with row stride ldg.
     Returns (scores [B,n_shifts,H,W], dstx [B,H,W,ldo])."""
     lib = _lib.load()
-    _chk(x, "x")
+    dt = _act_dtype(x)
+    _chk(x, "x", dt)
     if not g.is_cuda or g.dtype != torch.float32 or g.stride(-1) != 1:
         raise ValueError("g must be an fp32 device tensor with unit inner stride")
     b, h, w, ldx = x.shape
@@ -233,23 +260,26 @@ def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None):
     n = len(shifts)
     sh = (ctypes.c_int * n)(*shifts)
     scores = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
-    dstx = torch.empty((b, h, w, ldo), device=x.device, dtype=torch.float32)
-    check(lib.ccvpe_match_level_f32(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride,
-                                    _ptr(scores), _ptr(dstx), ldo, b, h * w, c, _stream()),
-          "ccvpe_match_level_f32")
+    dstx = torch.empty((b, h, w, ldo), device=x.device, dtype=dt)
+    fn = lib.ccvpe_match_level_f32 if dt == torch.float32 else lib.ccvpe_match_level_bf16
+    check(fn(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, _ptr(scores), _ptr(dstx), ldo, b,
+             h * w, c, _stream()), "ccvpe_match_level")
     return scores, dstx
 
 
 def head_conv3x3(x, w, bias, cout, normalize):
     lib = _lib.load()
-    for t, nm in ((x, "x"), (w, "w"), (bias, "bias")):
+    dt = _act_dtype(x)
+    _chk(x, "x", dt)
+    for t, nm in ((w, "w"), (bias, "bias")):
         _chk(t, nm)
     b, h, wd, c = x.shape
     if c != 16:
         raise ValueError("head conv expects 16 input channels")
     out = torch.empty((b, cout, h, wd), device=x.device, dtype=torch.float32)
-    check(lib.ccvpe_head_conv3x3_f32(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), b, h, wd, cout,
-                                     int(bool(normalize)), _stream()), "ccvpe_head_conv3x3_f32")
+    fn = lib.ccvpe_head_conv3x3_f32 if dt == torch.float32 else lib.ccvpe_head_conv3x3_bf16
+    check(fn(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), b, h, wd, cout, int(bool(normalize)), _stream()),
+          "ccvpe_head_conv3x3")
     return out
 
 

@@ -188,6 +188,31 @@ int ccvpe_cross_entropy_loss_f32(const float* logits, const float* labels, float
 int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const float* gt, float* loss,
                                float* scratch, int batch, int hw, void* stream);
 
+/* -------------------------------------------------------------------------------------------
+ * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
+ * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
+ * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers
+ * typed `void*` address bf16 data; everything else is as in the _f32 entry point of the same name.
+ * In ccvpe_conv_desc src0/src1/w/residual/dst then address bf16 data; `out_f32` != 0 makes the GEMM
+ * write fp32 instead (tensors handed to fp32 consumers: the ground-descriptor collapse).
+ * Matching scores, heat-map logits and the orientation field are always fp32.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_conv_igemm_bf16(const ccvpe_conv_desc* desc, int out_f32, void* stream);
+int ccvpe_stem_conv_bf16(const float* x_nchw, const float* w, const float* scale, const float* shift, void* y,
+                         int batch, int in_h, int in_w, int circular, void* stream);
+int ccvpe_dwconv_bf16(const void* x, const float* w, const float* scale, const float* shift, void* y,
+                      float* se_partial, int batch, int in_h, int in_w, int channels, int k, int stride,
+                      int circular, void* stream);
+int ccvpe_mbconv_front_bf16(const void* x, const void* w_exp, int kpad, const float* s0, const float* b0,
+                            const float* w_dw, const float* s1, const float* b1, void* y, float* se_partial,
+                            int batch, int in_h, int in_w, int cin, int mid, int k, int stride, int circular,
+                            void* stream);
+int ccvpe_match_level_bf16(const void* x, int ldx, const float* g, int ldg, int L, const int* shifts,
+                           int n_shifts, int n_max, int n_tail, int stride, float* scores, void* dstx, int ldo,
+                           int batch, int hw, int channels, void* stream);
+int ccvpe_head_conv3x3_bf16(const void* x, const float* w, const float* bias, float* out_nchw, int batch, int h,
+                            int w_, int cout, int normalize, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

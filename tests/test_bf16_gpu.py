@@ -1,0 +1,227 @@
+"""bf16 storage path (BASELINE configs C2 / C4) on the MI355X.
+
+Operators: inputs and weights are rounded to bf16 first, the expected value is the fp32 oracle op
+on those rounded values, so what is compared is accumulation order + ONE output rounding:
+tolerance 1e-2 of the tensor's scale (bf16 has 8 significand bits: 2^-9 = 2e-3 per rounding).
+Whole forward: ~60 layers of bf16 re-rounding; documented tolerance 5e-2 of the logit range, the
+oracle's arg-max pixel must be within that tolerance of the bf16 maximum, matching scores within
+2e-2 absolute (they are cosines in [-1, 1]).  The fp32 path keeps the 1e-3 / exact-arg-max bar.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    from ccvpe_amd import ops as _ops, _lib
+    _lib.load()
+    return _ops
+
+
+def r(t):
+    """round to bf16 and back (the values the device actually sees)"""
+    return t.to(BF).float()
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def dev(t, dt=BF):
+    return t.to(dt).cuda().contiguous()
+
+
+def close(got, want, tol, what):
+    got, want = got.detach().float().cpu().double(), want.detach().double()
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    scale = want.abs().max().item() + 1e-30
+    err = (got - want).abs().max().item()
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e (rel %.3e)" % (what, err, scale, err / scale)
+
+
+def pack(w):
+    from ccvpe_amd.models import _pack_conv
+    return _pack_conv(w, BF)
+
+
+@pytest.mark.parametrize("cin,cout", [(16, 96), (24, 144), (40, 240), (112, 672), (192, 1152), (96, 24), (480, 112),
+                                      (320, 1280), (32, 16), (1152, 320), (240, 80), (64, 64), (8, 160), (72, 48)])
+def test_igemm_bf16_1x1(ops, cin, cout):
+    b, h, w = 2, 9, 13
+    x = r(synth.normal((b, cin, h, w), 100 + cin))
+    wt = r(synth.normal((cout, cin, 1, 1), 200 + cout, (1.0 / cin) ** 0.5))
+    sc = synth.uniform((cout,), 300, 0.5, 1.5)
+    sh = synth.normal((cout,), 301, 0.1)
+    want = O.swish(F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack(wt)), cout, batch=b, in_h=h, in_w=w,
+                         scale=dev(sc, torch.float32), shift=dev(sh, torch.float32), act=ops.ACT_SWISH)
+    assert got.dtype == BF
+    close(nchw(got), want, 1e-2, "bf16 1x1 %d->%d" % (cin, cout))
+    got32 = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack(wt)), cout, batch=b, in_h=h, in_w=w,
+                           scale=dev(sc, torch.float32), shift=dev(sh, torch.float32), act=ops.ACT_SWISH, out_f32=True)
+    assert got32.dtype == torch.float32
+    close(nchw(got32), want, 2e-3, "bf16 1x1 fp32-out")
+
+
+def test_igemm_bf16_gate_residual(ops):
+    b, h, w, cin, cout = 3, 7, 10, 96, 24
+    x = r(synth.normal((b, cin, h, w), 1))
+    gate = synth.uniform((b, cin), 2)
+    res = r(synth.normal((b, cout, h, w), 3))
+    wt = r(synth.normal((cout, cin, 1, 1), 4, 0.1))
+    xg = r(x * gate.view(b, cin, 1, 1))                    # the kernel re-rounds the gated operand to bf16
+    want = F.conv2d(xg, wt) + res
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack(wt)), cout, batch=b, in_h=h, in_w=w, gate=dev(gate, torch.float32),
+                         residual=dev(nhwc(res)))
+    close(nchw(got), want, 1e-2, "bf16 gate+residual")
+
+
+@pytest.mark.parametrize("c0,c1,cout,hw", [(40, 16, 40, 12), (80, 24, 80, 9), (16, 0, 16, 17), (320, 112, 320, 6),
+                                           (1024, 320, 640, 4), (160, 40, 160, 20)])
+def test_conv3x3_bf16_two_sources(ops, c0, c1, cout, hw):
+    b = 2
+    a = r(synth.normal((b, c0, hw, hw), 10 + c0))
+    s = r(synth.normal((b, c1, hw, hw), 11 + c1)) if c1 else None
+    wt = r(synth.normal((cout, c0 + c1, 3, 3), 12, (1.0 / (9 * (c0 + c1))) ** 0.5))
+    bias = synth.normal((cout,), 13, 0.1)
+    xin = torch.cat([a, s], 1) if c1 else a
+    want = F.relu(F.conv2d(xin, wt, bias, padding=1))
+    got = ops.conv_igemm(dev(nhwc(a)), c0, dev(pack(wt)), cout, batch=b, in_h=hw, in_w=hw, kh=3, kw=3, pad=1,
+                         src1=dev(nhwc(s)) if c1 else None, c1=c1, shift=dev(bias, torch.float32), act=ops.ACT_RELU)
+    close(nchw(got), want, 1e-2, "bf16 3x3 %d+%d->%d" % (c0, c1, cout))
+
+
+def test_igemm_bf16_2x2s2_and_deconv(ops):
+    from ccvpe_amd.models import _pack_deconv
+    b, c, n = 2, 64, 48
+    vol = r(synth.normal((b, c, 8, 8), 20))
+    wl = r(synth.normal((n, c * 4), 21, 0.05))
+    bias = synth.normal((n,), 22, 0.1)
+    want = F.conv2d(vol, wl.view(n, c, 2, 2), bias, stride=2)
+    got = ops.conv_igemm(dev(nhwc(vol)), c, dev(pack(wl.view(n, c, 2, 2))), n, batch=b, in_h=8, in_w=8, kh=2, kw=2,
+                         stride=2, shift=dev(bias, torch.float32))
+    close(nchw(got), want, 1e-2, "bf16 2x2s2")
+    cin, cout, hw = 168, 40, 5
+    x = r(synth.normal((b, cin, hw, hw), 30))
+    wt = r(synth.normal((cin, cout, 2, 2), 31, (1.0 / cin) ** 0.5))
+    bias = synth.normal((cout,), 32, 0.1)
+    want = F.conv_transpose2d(x, wt, bias, stride=2)
+    wp, b4 = _pack_deconv(wt, bias, [(0, 0, cin)], cin, BF)
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(wp), 4 * cout, batch=b, in_h=hw, in_w=hw, shift=dev(b4, torch.float32),
+                         out_mode=ops.OUT_DECONV2X)
+    close(nchw(got), want, 1e-2, "bf16 deconv")
+
+
+@pytest.mark.parametrize("k,s,c,h,w,circ", [(3, 1, 32, 9, 12, False), (5, 2, 144, 8, 12, True), (5, 1, 1152, 5, 9, True),
+                                            (3, 2, 240, 7, 9, False)])
+def test_dwconv_bf16(ops, k, s, c, h, w, circ):
+    b = 2
+    x = r(synth.normal((b, c, h, w), 40 + c))
+    wt = synth.normal((c, 1, k, k), 41, 1.0 / k)
+    sc = synth.uniform((c,), 42, 0.5, 1.5)
+    sh = synth.normal((c,), 43, 0.1)
+    want = O.swish(O.same_conv(x, wt, k, s, 224, circ, groups=c) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got, part = ops.dwconv(dev(nhwc(x)), dev(wt.reshape(c, k, k).permute(1, 2, 0), torch.float32),
+                           dev(sc, torch.float32), dev(sh, torch.float32), k, s, circ)
+    close(nchw(got), want, 1e-2, "bf16 dwconv")
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-2, "squeeze partials (fp32 sums of unrounded outputs)")
+
+
+@pytest.mark.parametrize("k,s,cin,h,w,circ", [(3, 2, 16, 40, 72, False), (3, 1, 24, 36, 40, True), (5, 2, 24, 34, 48, True),
+                                              (5, 1, 40, 20, 24, False)])
+def test_mbconv_front_bf16(ops, k, s, cin, h, w, circ):
+    b, mid = 2, 6 * cin
+    x = r(synth.normal((b, cin, h, w), 300 + cin))
+    w_exp = r(synth.normal((mid, cin, 1, 1), 301, (2.0 / cin) ** 0.5))
+    s0, b0 = synth.uniform((mid,), 302, 0.5, 1.5), synth.normal((mid,), 303, 0.2)
+    w_dw = synth.normal((mid, 1, k, k), 304, 1.0 / k)
+    s1, b1 = synth.uniform((mid,), 305, 0.5, 1.5), synth.normal((mid,), 306, 0.2)
+    t = O.swish(F.conv2d(x, w_exp) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))       # stays fp32 in LDS
+    want = O.swish(O.same_conv(t, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    f32 = torch.float32
+    got, part = ops.mbconv_front(dev(nhwc(x)), dev(pack(w_exp)), dev(s0, f32), dev(b0, f32),
+                                 dev(w_dw.reshape(mid, k, k).permute(1, 2, 0), f32), dev(s1, f32), dev(b1, f32), mid, k, s, circ)
+    assert got.dtype == BF
+    close(nchw(got), want, 1e-2, "bf16 fused front")
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-2, "squeeze partials")
+
+
+@pytest.mark.parametrize("C,L,stride,hw,shifts,n_max,n_tail", [
+    (1280, 1280, 64, 8, list(range(20)), 20, 20),
+    (1280, 640, 64, 8, list(range(-10, 11)) + list(range(20)), 21, 20),
+    (40, 40, 2, 20, list(range(20)), 20, 0),
+    (2048, 512, 128, 8, list(range(16)), 16, 16),
+    (160, 160, 8, 23, [0], 1, 0),
+])
+def test_match_level_bf16(ops, C, L, stride, hw, shifts, n_max, n_tail):
+    b = 2
+    x = r(synth.normal((b, C, hw, hw), 70 + C))
+    g = synth.normal((b, L), 71 + L)
+    ldo = (C + 1 + n_tail + 7) // 8 * 8
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g, torch.float32), L, shifts, n_max, n_tail, stride, ldo)
+    want = O.rotational_matching(x, g, shifts, stride)
+    assert sc.dtype == torch.float32 and cat.dtype == BF
+    close(sc, want, 2e-5 * 50, "scores (fp32 math on bf16 inputs)")
+    catc = nchw(cat).float().cpu()
+    close(catc[:, :C], F.normalize(x, p=2, dim=1), 1e-2, "normalised features")
+    close(catc[:, C], want[:, :n_max].max(dim=1)[0], 1e-2, "max over rotations")
+
+
+def test_stem_and_head_bf16(ops):
+    x = synth.normal((2, 3, 32, 48), 4242)
+    w = synth.normal((32, 3, 3, 3), 5, 0.3)
+    sc, sh = synth.uniform((32,), 6, 0.5, 1.5), synth.normal((32,), 7, 0.1)
+    want = O.swish(O.same_conv(x, w, 3, 2, 224, True) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    f32 = torch.float32
+    got = ops.stem_conv(dev(x, f32), dev(w.permute(2, 3, 1, 0), f32), dev(sc, f32), dev(sh, f32), True, out_dtype=BF)
+    assert got.dtype == BF
+    close(nchw(got), want, 1e-2, "bf16 stem")
+    y = r(synth.normal((2, 16, 21, 21), 80))
+    wt = synth.normal((2, 16, 3, 3), 81, 0.1)
+    bias = synth.normal((2,), 82, 0.1)
+    want = F.normalize(F.conv2d(y, wt, bias, padding=1), p=2, dim=1)
+    got = ops.head_conv3x3(dev(nhwc(y)), dev(wt.permute(0, 2, 3, 1), f32), dev(bias, f32), 2, True)
+    close(got, want, 1e-4, "head conv (bf16 in, fp32 math/out)")
+
+
+@pytest.mark.parametrize("case", [
+    dict(kind="vigor", ori_noise=None, circular=True, wseed=0, grd="vigor"),                 # C2: N_rot = 20
+    dict(kind="vigor", ori_noise=180, circular=False, wseed=0, grd="vigor_fov180"),          # C4: FoV 180
+    dict(kind="kitti", ori_noise=None, circular=False, wseed=1, grd="kitti"),
+])
+def test_forward_bf16_vs_oracle(case, synth_sd):
+    from test_forward_gpu import build
+    net = build(case, synth_sd).set_precision("bf16")
+    grd, sat = synth.synthetic_pair(2, case["grd"], 991)
+    out = net(grd.cuda(), sat.cuda())
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref = O.forward(synth_sd(case["kind"], case["wseed"]), grd, sat, case["kind"], case["circular"], case["ori_noise"])
+    assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
+    assert all(t.dtype == torch.float32 for t in out)
+    lg, rl = out[0].cpu(), ref[0]
+    rng = (rl.max() - rl.min()).item()
+    err = (lg - rl).abs().max().item()
+    assert err < 5e-2 * rng, "logits err %.3e vs range %.3e" % (err, rng)
+    idx = rl.argmax(1)
+    for b in range(2):   # the oracle's arg-max pixel is (within tolerance) the bf16 maximum
+        assert lg[b].max().item() - lg[b, idx[b]].item() < 5e-2 * rng
+    for a, bb in zip(out[3:], ref[3:]):
+        assert (a.cpu() - bb).abs().max().item() < 2e-2
+    assert abs(out[1].sum().item() - 2.0) < 1e-3
+    # fp32 precision is restored by switching back (packed weights are re-derived)
+    net.set_precision("fp32")
+    out32 = net(grd.cuda(), sat.cuda())
+    assert ((out32[0].cpu() - rl).abs().max() / rl.abs().max()).item() < 1e-3
