@@ -34,12 +34,24 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class UpconvDesc(ctypes.Structure):
+    """struct ccvpe_upconv_desc (include/ccvpe_hip.h)."""
+    _fields_ = [
+        ("src0", c_void_p), ("src1", c_void_p), ("w", c_void_p), ("shift9", c_void_p), ("dst", c_void_p),
+        ("c0", c_int), ("ld0", c_int), ("c1", c_int), ("ld1", c_int),
+        ("batch", c_int), ("h1", c_int), ("w1", c_int),
+        ("n", c_int), ("kpad", c_int), ("ldd", c_int), ("act", c_int),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/ccvpe_hip.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it).
 PROTOTYPES = {
     "ccvpe_last_error": (ctypes.c_char_p, []),
     "ccvpe_abi_version": (c_int, []),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
+    "ccvpe_upconv3x3_f32": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
+    "ccvpe_upconv3x3_bf16": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
     "ccvpe_stem_conv_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_nblk": (c_int, [c_int] * 4),
     "ccvpe_dwconv_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

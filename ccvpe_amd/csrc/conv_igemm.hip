@@ -568,6 +568,239 @@ static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
   return check_launch("conv3x3_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------
+// ConvTranspose2d(k2,s2) folded into the following 3x3 conv (models.py:207-209: deconv -> cat skip ->
+// conv.0).  For output parity (py,px) the pair is ONE implicit GEMM over LOW-RES pixels (y1,x1):
+//   out[2y1+py, 2x1+px, n] = sum_{du,dv in {0,1}} Weff[py,px,du,dv][n,:] . x[y1+du-1+py, x1+dv-1+px, :]
+//                          + sum_{ky,kx}          W3[n, Cd:, ky,kx]     . skip[2y1+py+ky-1, 2x1+px+kx-1, :]
+//                          + shift9[border class of (Y,X)][n]
+// with Weff = sum over the (ky,a)/(kx,b) pairs that land on that low-res pixel of W3[:, :Cd, ky,kx] . Wd[:,:,a,b]^T
+// (packed by the host, ccvpe_amd/models.py:_pack_upconv).  K = 4*C' + 9*C1 instead of 9*(Cd + C1) plus the
+// deconv GEMM, and the 2x-upsampled deconv tensor never exists.  The deconv bias only survives for the
+// 3x3 taps that fall inside the image, hence the 9 (row class x column class) shift vectors.
+// ---------------------------------------------------------------------------------------------
+struct UpParams {
+  const void* src0;
+  const void* src1;
+  const void* w;
+  const float* shift9;
+  void* dst;
+  int out_f32;
+  int c0, ld0, c1, ld1;
+  int H1, W1;
+  int N, Kpad, Npad;
+  int cpt0, cpt1, total_chunks, stages;
+  int ldd, act;
+  int M;                 // batch * H1 * W1 (low-res pixels)
+  int tiles_n, tiles_m, tiles_total;
+};
+
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;
+  constexpr int CPS = SK / 8;
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NT * WN;
+  constexpr int A_IT = BM / 64;
+  constexpr int B_IT = (BN + 63) / 64;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  // tile order: n fastest, then the 4 parities of one low-res tile (they share src0 / skip rows in L2)
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
+  const int tn = tile % p.tiles_n;
+  const int par = (tile / p.tiles_n) & 3;
+  const int tm = tile / (p.tiles_n * 4);
+  const int py = par >> 1, px = par & 1;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int H2 = 2 * p.H1, W2 = 2 * p.W1;
+
+  const int srow = tid >> 2;
+  const int ssub = tid & 3;
+  const int chunk_in_stage = (ssub * E) >> 3;
+  const int half = (ssub * E) & 7;
+  const T* src0 = reinterpret_cast<const T*>(p.src0);
+  const T* src1 = reinterpret_cast<const T*>(p.src1);
+  const T* wp = reinterpret_cast<const T*>(p.w) + (size_t)par * p.Npad * p.Kpad;
+
+  int a_b[A_IT], a_y[A_IT], a_x[A_IT];
+  bool a_ok[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    const int m = m0 + srow + 64 * it;
+    a_ok[it] = m < p.M;
+    const int mm = a_ok[it] ? m : 0;
+    const int hw = p.H1 * p.W1;
+    const int b = mm / hw;
+    const int rem = mm - b * hw;
+    a_b[it] = b;
+    a_y[it] = rem / p.W1;
+    a_x[it] = rem - a_y[it] * p.W1;
+  }
+  // K cursor of this thread, advanced incrementally (no per-stage divisions):
+  //   ph 0 = low-res source (4 taps x cpt0 chunks), ph 1 = skip (9 taps x cpt1 chunks)
+  int kc = chunk_in_stage, ph = 0, tap = 0, r = chunk_in_stage;
+  auto normalise = [&]() {
+    while (kc < p.total_chunks) {
+      const int cur = ph == 0 ? p.cpt0 : p.cpt1;
+      if (r < cur) break;
+      r -= cur;
+      if (++tap == 4 && ph == 0) { ph = 1; tap = 0; }
+    }
+  };
+  normalise();
+
+  f32x4 a_reg[A_IT], b_reg[B_IT];
+
+  auto load_stage = [&](int s) {
+    const bool kvalid = kc < p.total_chunks;
+    const bool from0 = ph == 0;
+    const int ch = r * 8 + half;
+    int dy, dx;
+    if (from0) {
+      dy = (tap >> 1) - 1 + py;
+      dx = (tap & 1) - 1 + px;
+    } else {
+      const int ky = tap >= 6 ? 2 : (tap >= 3 ? 1 : 0);
+      dy = py + ky - 1;
+      dx = px + (tap - 3 * ky) - 1;
+    }
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (a_ok[it] && kvalid) {
+        if (from0) {
+          const int iy = a_y[it] + dy, ix = a_x[it] + dx;
+          if ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1)
+            v = *reinterpret_cast<const f32x4*>(src0 + ((size_t)(a_b[it] * p.H1 + iy) * p.W1 + ix) * p.ld0 + ch);
+        } else {
+          const int iy = 2 * a_y[it] + dy, ix = 2 * a_x[it] + dx;
+          if ((unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2)
+            v = *reinterpret_cast<const f32x4*>(src1 + ((size_t)(a_b[it] * H2 + iy) * W2 + ix) * p.ld1 + ch);
+        }
+      }
+      a_reg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = srow + 64 * it;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nrow < BN && n0 + nrow < p.Npad)
+        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + s * SK + ssub * E);
+      b_reg[it] = v;
+    }
+    kc += CPS;
+    r += CPS;
+    normalise();
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = a_reg[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = srow + 64 * it;
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 4;
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < p.stages; ++s) {
+    const int buf = s & 1;
+    const bool more = s + 1 < p.stages;
+    if (more) load_stage(s + 1);
+    f32x4 af[MT], bf[NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+      af[i] = *reinterpret_cast<const f32x4*>(&As[buf][(wm * MT + i) * 16 + frow][fk]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[buf][(wn * NT + j) * 16 + frow][fk]);
+    if (sizeof(T) == 4) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
+    }
+    if (more) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: pixel (2y1+py, 2x1+px); shift picked by the pixel's border class --------------
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
+  IgemmParams ep;   // reuse store4 (needs N, act, residual, dst, out_f32)
+  ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int m = m0 + (wm * MT + i) * 16 + epix;
+    if (m >= p.M) continue;
+    const int hw = p.H1 * p.W1;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    const int y1 = rem / p.W1;
+    const int Y = 2 * y1 + py, X = 2 * (rem - y1 * p.W1) + px;
+    const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
+    const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
+    const float* shp = p.shift9 + (size_t)(rc * 3 + cc) * p.N;
+    const size_t pix = (size_t)(b * H2 + Y) * W2 + X;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + (wn * NT + j) * 16 + en;
+      if (n >= p.N) continue;
+      float sh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh[q] = (n + q < p.N) ? shp[n + q] : 0.f;
+      store4<T>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
+    }
+  }
+}
+
+template <typename T, int MT, int NT, int WN>
+static int launch_up(const UpParams& p0, hipStream_t stream) {
+  constexpr int WM = 4 / WN;
+  constexpr int BM = 16 * MT * WM;
+  constexpr int BN = 16 * NT * WN;
+  UpParams p = p0;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.Npad + BN - 1) / BN;
+  const long total = (long)p.tiles_m * p.tiles_n * 4;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "upconv: grid too large");
+  p.tiles_total = (int)total;
+  hipLaunchKernelGGL((upconv_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
+  return check_launch("upconv_kernel");
+}
+
 // Pick the N tile that wastes the fewest MFMA columns, then the widest.
 struct TileCfg { int mt, nt, wn; };
 static const TileCfg kCfgs[] = {
@@ -645,6 +878,46 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32) {
 #undef CCVPE_CASE
   return fail(CCVPE_EINVAL, "conv_igemm: no tile config");
 }
+
+template <typename T>
+static int upconv_any(const ccvpe_upconv_desc* d, void* stream) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;
+  constexpr int CPS = SK / 8;
+  if (!d) return fail(CCVPE_EINVAL, "upconv: null desc");
+  if (d->c0 <= 0 || d->c0 % 8 || d->c1 < 0 || d->c1 % 8) return fail(CCVPE_EINVAL, "upconv: c0/c1 must be multiples of 8");
+  if (d->c1 > 0 && !d->src1) return fail(CCVPE_EINVAL, "upconv: c1>0 but src1 null");
+  if (d->ld0 % E || (d->c1 && d->ld1 % E) || d->kpad % SK || d->ldd % 4) return fail(CCVPE_EINVAL, "upconv: bad strides");
+  if (!aligned16(d->src0) || (d->src1 && !aligned16(d->src1)) || !aligned16(d->w) || !aligned16(d->dst))
+    return fail(CCVPE_EINVAL, "upconv: pointers must be 16-byte aligned");
+  if (!d->shift9) return fail(CCVPE_EINVAL, "upconv: shift9 required");
+  UpParams p;
+  p.src0 = d->src0; p.src1 = d->src1; p.w = d->w; p.shift9 = d->shift9; p.dst = d->dst;
+  p.out_f32 = sizeof(T) == 4;
+  p.c0 = d->c0; p.ld0 = d->ld0; p.c1 = d->c1; p.ld1 = d->ld1;
+  p.H1 = d->h1; p.W1 = d->w1;
+  p.N = d->n; p.Kpad = d->kpad; p.Npad = (d->n + 15) / 16 * 16;
+  p.cpt0 = d->c0 / 8; p.cpt1 = d->c1 / 8;
+  p.total_chunks = 4 * p.cpt0 + 9 * p.cpt1;
+  if (p.total_chunks * 8 > p.Kpad) return fail(CCVPE_EINVAL, "upconv: kpad %d < K %d", p.Kpad, p.total_chunks * 8);
+  p.stages = (p.total_chunks + CPS - 1) / CPS;
+  p.ldd = d->ldd; p.act = d->act;
+  const long M = (long)d->batch * d->h1 * d->w1;
+  if (M <= 0 || 4 * M > 0x7fffffffL) return fail(CCVPE_EINVAL, "upconv: bad M");
+  p.M = (int)M;
+  p.tiles_n = p.tiles_m = p.tiles_total = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const TileCfg c = kCfgs[pick_cfg(p.Npad)];
+#define CCVPE_CASE(MT_, NT_, WN_) \
+  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) return launch_up<T, MT_, NT_, WN_>(p, st);
+  CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)
+  CCVPE_CASE(4, 5, 1) CCVPE_CASE(4, 3, 1) CCVPE_CASE(4, 1, 1) CCVPE_CASE(2, 7, 1)
+#undef CCVPE_CASE
+  return fail(CCVPE_EINVAL, "upconv: no tile config");
+}
+
+extern "C" int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* d, void* stream) { return upconv_any<float>(d, stream); }
+extern "C" int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* d, void* stream) { return upconv_any<bf16_t>(d, stream); }
 
 extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   return conv_igemm_any<float>(d, stream, 1);

@@ -123,6 +123,55 @@ def _pack_deconv(w, bias, col_map, ldo, dtype=torch.float32):
     return _pad2(out, dtype), bias.repeat(4).contiguous()
 
 
+# which (3x3 tap k, deconv tap a) pairs land on low-res offset d for output parity p:  _UP_S[p][d]
+_UP_S = {0: {0: ((0, 1),), 1: ((1, 0), (2, 1))}, 1: {0: ((0, 0), (1, 1)), 1: ((2, 0),)}}
+_UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image for border class 0/1/2
+# Decoder levels (index j = 0..5 <-> level 6..1) whose ConvTranspose2d is folded into the following 3x3
+# conv (csrc/conv_igemm.hip: upconv_kernel).  Measured at B=64 fp32: levels 6-3 gain 2.3 ms/step (fewer
+# FLOPs, no deconv launch, no upsampled intermediate); levels 2-1 (N <= 40) lose because the gather-based
+# kernel re-reads the activation per tap from L2, so they keep deconv GEMM + LDS-halo 3x3 kernel.
+FOLD_LEVELS = (0, 1, 2, 3)
+
+
+def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
+    """Effective weights of  conv3x3(cat[deconv2x2s2(x), skip])  per output parity.
+
+    wd [Cin_ref,Cd,2,2], bd [Cd]: the ConvTranspose2d; col_map re-orders its input channels into this
+    implementation's concat order (cp channels incl. padding); w3 [Co,Cd+C1,3,3], b3 [Co]: the conv.
+    Returns (w [4][Co^16][K^], shift9 [9][Co]) with K = 4*cp + 9*C1; products are accumulated in fp64."""
+    cd, co = wd.shape[1], w3.shape[0]
+    c1 = w3.shape[1] - cd
+    wd_my = wd.new_zeros((cp, cd, 2, 2), dtype=torch.float64)
+    for d0, s0, n in col_map:
+        wd_my[d0:d0 + n] = wd[s0:s0 + n].double()
+    w3d = w3[:, :cd].double()
+    k = 4 * cp + 9 * c1
+    kmult = 16 if dtype == torch.float32 else 32
+    out = wd.new_zeros((4, _round_up(co, 16), _round_up(k, kmult)), dtype=torch.float64)
+    for py in range(2):
+        for px in range(2):
+            par = py * 2 + px
+            for du in range(2):
+                for dv in range(2):
+                    weff = wd.new_zeros((co, cp), dtype=torch.float64)
+                    for ky, a in _UP_S[py][du]:
+                        for kx, b in _UP_S[px][dv]:
+                            weff += w3d[:, :, ky, kx] @ wd_my[:, :, a, b].t()
+                    tap = du * 2 + dv
+                    out[par, :co, tap * cp:(tap + 1) * cp] = weff
+            if c1:
+                out[par, :co, 4 * cp:k] = w3[:, cd:].double().permute(0, 2, 3, 1).reshape(co, 9 * c1)
+    shift9 = wd.new_zeros((9, co), dtype=torch.float64)
+    for rc in range(3):
+        for cc in range(3):
+            v = b3.double().clone()
+            for ky in _UP_R[rc]:
+                for kx in _UP_R[cc]:
+                    v += w3d[:, :, ky, kx] @ bd.double()
+            shift9[rc * 3 + cc] = v
+    return out.to(dtype).contiguous(), shift9.float().contiguous()
+
+
 def _pack_model(sd, kind, n_tail, dtype=torch.float32):
     spec = MODEL_SPECS[kind]
     pk = _Obj()
@@ -162,9 +211,13 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32):
         lv.up_w, lv.up_b = _pack_deconv(sd["deconv%d.weight" % lvl], sd["deconv%d.bias" % lvl],
                                         [(0, 1, c), (c, 0, 1)], ldo, dtype)
         lv.c0, lv.c1 = dc_out, c_in - dc_out
+        lv.n_a = c_out
+        if j in FOLD_LEVELS:
+            lv.fw, lv.fshift = _pack_upconv(sd["deconv%d.weight" % lvl], sd["deconv%d.bias" % lvl],
+                                            [(0, 1, c), (c, 0, 1)], ldo, sd["conv%d.0.weight" % lvl],
+                                            sd["conv%d.0.bias" % lvl], dtype)
         lv.w_a = _pack_conv(sd["conv%d.0.weight" % lvl], dtype)
         lv.b_a = sd["conv%d.0.bias" % lvl].contiguous()
-        lv.n_a = c_out
         if lvl != 1:
             lv.w_b = _pack_conv(sd["conv%d.2.weight" % lvl], dtype)
             lv.n_b = c_out
@@ -188,6 +241,11 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32):
                                             [(0, 0, dc_in)], dc_in, dtype)
         ov.up_n = 4 * dc_out
         ov.c0, ov.c1 = dc_out, c_in - dc_out
+        if j in FOLD_LEVELS:
+            cmap = [(0, n_rot, c6), (c6 + 1, 0, n_rot)] if j == 0 else [(0, 0, dc_in)]
+            ov.fw, ov.fshift = _pack_upconv(sd["deconv%d_ori.weight" % lvl], sd["deconv%d_ori.bias" % lvl], cmap,
+                                            ov.k, sd["conv%d_ori.0.weight" % lvl], sd["conv%d_ori.0.bias" % lvl],
+                                            dtype)
         ov.w_a = _pack_conv(sd["conv%d_ori.0.weight" % lvl], dtype)
         ov.b_a = sd["conv%d_ori.0.bias" % lvl].contiguous()
         ov.n_a = c_out
@@ -353,10 +411,14 @@ class _CVMBase(nn.Module):
                     scores_out.append(sc if self.ori_noise is None else sc[:, n_max:])
                 else:
                     scores_out.append(sc)
-                up = ops.conv_igemm(cat, lv.ldo, lv.up_w, lv.up_n, batch=batch, in_h=hw, in_w=hw,
-                                    shift=lv.up_b, out_mode=ops.OUT_DECONV2X, algo_k=lv.c + 1)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
-                y = _double_conv(lv, up, skip, batch, 2 * hw)
+                if j in FOLD_LEVELS:   # deconv folded into conv.0: one GEMM per output parity on the low-res input
+                    y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,
+                                      src1=skip, c1=lv.c1, act=ops.ACT_RELU)
+                else:
+                    up = ops.conv_igemm(cat, lv.ldo, lv.up_w, lv.up_n, batch=batch, in_h=hw, in_w=hw,
+                                        shift=lv.up_b, out_mode=ops.OUT_DECONV2X, algo_k=lv.c + 1)
+                    y = _double_conv(lv, up, skip, batch, 2 * hw)
                 if j < 5:
                     x = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
                                        kh=3, kw=3, pad=1, shift=lv.b_b)
@@ -370,10 +432,14 @@ class _CVMBase(nn.Module):
             for j in range(6):
                 ov = pk.ori[j]
                 hw = xo.shape[1]
-                up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
-                                    shift=ov.up_b, out_mode=ops.OUT_DECONV2X, algo_k=ov.k_algo)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
-                y = _double_conv(ov, up, skip, batch, 2 * hw)
+                if j in FOLD_LEVELS:
+                    y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
+                                      src1=skip, c1=ov.c1, act=ops.ACT_RELU)
+                else:
+                    up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
+                                        shift=ov.up_b, out_mode=ops.OUT_DECONV2X, algo_k=ov.k_algo)
+                    y = _double_conv(ov, up, skip, batch, 2 * hw)
                 if j < 5:
                     xo = ops.conv_igemm(y, ov.n_a, ov.w_b, ov.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
                                         kh=3, kw=3, pad=1, shift=ov.b_b)

@@ -152,6 +152,35 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     return dst
 
 
+def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, act=ACT_NONE, algo_flops=None):
+    """ConvTranspose2d(k2,s2) folded into the following 3x3 conv (ccvpe_upconv3x3_f32 / _bf16).
+    src0 [B,h1,w1,ld0] low-res, src1 [B,2h1,2w1,ld1] skip; returns [B,2h1,2w1,n]."""
+    lib = _lib.load()
+    dt = _act_dtype(src0)
+    for t, nm in ((src0, "src0"), (src1, "src1"), (w_packed, "w")):
+        _chk(t, nm, dt)
+    _chk(shift9, "shift9")
+    dst = torch.empty((batch, 2 * h1, 2 * w1, n), device=src0.device, dtype=dt)
+    d = _lib.UpconvDesc()
+    d.src0, d.src1, d.w, d.shift9, d.dst = _ptr(src0), _ptr(src1), _ptr(w_packed), _ptr(shift9), _ptr(dst)
+    d.c0, d.ld0, d.c1, d.ld1 = c0, src0.shape[-1], c1, (src1.shape[-1] if src1 is not None else 0)
+    d.batch, d.h1, d.w1 = batch, h1, w1
+    d.n, d.kpad, d.ldd, d.act = n, w_packed.shape[-1], n, act
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
+    fn = lib.ccvpe_upconv3x3_f32 if dt == torch.float32 else lib.ccvpe_upconv3x3_bf16
+    check(fn(ctypes.byref(d), _stream()), "ccvpe_upconv3x3")
+    if rec is not None:
+        m = batch * h1 * w1 * 4
+        k_eff = 4 * c0 + 9 * c1
+        flops = algo_flops if algo_flops is not None else 2.0 * m * n * k_eff
+        esz = 4.0 if dt == torch.float32 else 2.0
+        nbytes = esz * (batch * h1 * w1 * c0 + m * c1 + m * n + 4 * n * k_eff)
+        name = igemm_tile(n).replace("igemm_f32_kernel<", "upconv_kernel<%s," % ("f32" if dt == torch.float32 else "bf16"))
+        rec.end(name, "up3x3 M%d N%d Keff%d" % (m, n, k_eff), flops, nbytes, ev0)
+    return dst
+
+
 def stem_conv(x_nchw, w, scale, shift, circular, out_dtype=torch.float32):
     lib = _lib.load()
     for t, nm in ((x_nchw, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):

@@ -85,6 +85,32 @@ typedef struct ccvpe_conv_desc {
 int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* desc, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * ConvTranspose2d(k=2,s=2) folded into the 3x3 conv that follows it (models.py:207-209 and the same
+ * pair at every decoder level of both branches: x = deconvK(x); x = cat[x, skip]; x = convK.0(x)).
+ * Per output parity (py,px) the pair is one implicit GEMM over the LOW-RES pixels with 2x2 taps on
+ * src0 and the ordinary 3x3 taps (stride 2, parity offset) on the skip:
+ *   K = 4*c0 + 9*c1   instead of   9*(Cd + c1) + the deconv GEMM, and no upsampled intermediate.
+ * w: [4][npad16][kpad] effective weights, parity-major ((py*2+px)), k = (du*2+dv)*c0 + ch for the
+ * low-res source then 4*c0 + (ky*3+kx)*c1 + ch for the skip.  shift9: [9][n] = conv bias + the
+ * deconv-bias terms of the 3x3 taps that fall inside the image, indexed by
+ * (row class*3 + col class), class 0 = first row/col, 1 = interior, 2 = last.
+ * ----------------------------------------------------------------------------------------- */
+typedef struct ccvpe_upconv_desc {
+  const void* src0;   /* [B,h1,w1,ld0] low-res input of the deconv (fp32 or bf16)   */
+  const void* src1;   /* [B,2h1,2w1,ld1] skip, or NULL                              */
+  const void* w;      /* packed effective weights                                    */
+  const float* shift9;
+  void* dst;          /* [B,2h1,2w1,ldd]                                             */
+  int c0, ld0, c1, ld1;
+  int batch, h1, w1;
+  int n, kpad, ldd;
+  int act;
+} ccvpe_upconv_desc;
+
+int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* desc, void* stream);
+int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* desc, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * EfficientNet stem: 3x3 stride-2 conv on the NCHW image + folded BN + swish, NHWC out.
  * TF-"SAME" padding (0 before, 1 after) from the 224 schedule; `circular` wraps along W and
  * zero-pads along H.  efficientnet_pytorch/model.py:181-182,289; utils.py:254-282,318-358.

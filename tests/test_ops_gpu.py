@@ -120,6 +120,37 @@ def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
     close(nchw(got), want, 1e-4, "deconv")
 
 
+@pytest.mark.parametrize("cp,cref,cd,c1,co,h1,w1,bf16", [
+    (48, 41, 16, 0, 16, 9, 11, False),        # level 1 (no skip)
+    (88, 81, 40, 16, 40, 6, 7, False),        # level 2
+    (168, 161, 80, 24, 80, 5, 5, False),
+    (648, 641, 320, 112, 320, 3, 4, False),
+    (1304, 1281, 1024, 320, 640, 2, 2, False),
+    (64, 64, 32, 16, 32, 7, 6, False),        # ori branch: plain input
+    (88, 81, 40, 16, 40, 6, 7, True),
+    (648, 641, 320, 112, 320, 3, 4, True),
+])
+def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf16):
+    """relu(conv3x3(cat[deconv2x2s2(x)+b, skip])+b)  ==  the folded per-parity GEMM (incl. borders)."""
+    from ccvpe_amd.models import _pack_upconv
+    b = 2
+    dt = torch.bfloat16 if bf16 else torch.float32
+    rnd = (lambda t: t.to(dt).float())
+    x = rnd(synth.normal((b, cp, h1, w1), 600 + cp))
+    x[:, cref:] = 0                                          # padding channels of the concat buffer
+    skip = rnd(synth.normal((b, c1, 2 * h1, 2 * w1), 601)) if c1 else None
+    wd = synth.normal((cref, cd, 2, 2), 602, (1.0 / cref) ** 0.5)
+    bd = synth.normal((cd,), 603, 0.3)
+    w3 = synth.normal((co, cd + c1, 3, 3), 604, (1.0 / (9 * (cd + c1))) ** 0.5)
+    b3 = synth.normal((co,), 605, 0.1)
+    d = F.conv_transpose2d(x[:, :cref], wd, bd, stride=2)
+    want = F.relu(F.conv2d(torch.cat([d, skip], 1) if c1 else d, w3, b3, padding=1))
+    fw, fshift = _pack_upconv(wd.cuda(), bd.cuda(), [(0, 0, cref)], cp, w3.cuda(), b3.cuda(), dt)
+    got = ops.upconv3x3(nhwc(x).to(dt).cuda().contiguous(), cp, fw, fshift, co, batch=b, h1=h1, w1=w1,
+                        src1=nhwc(skip).to(dt).cuda().contiguous() if c1 else None, c1=c1, act=ops.ACT_RELU)
+    close(nchw(got).float(), want, 2e-2 if bf16 else 1e-4, "upconv cp=%d" % cp)
+
+
 # ------------------------------------------------------------------------------------------
 # EfficientNet pieces
 # ------------------------------------------------------------------------------------------
