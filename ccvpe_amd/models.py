@@ -130,7 +130,7 @@ _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image fo
 # conv (csrc/conv_igemm.hip: upconv_kernel).  Measured at B=64 fp32: levels 6-3 gain 2.3 ms/step (fewer
 # FLOPs, no deconv launch, no upsampled intermediate); levels 2-1 (N <= 40) lose because the gather-based
 # kernel re-reads the activation per tap from L2, so they keep deconv GEMM + LDS-halo 3x3 kernel.
-FOLD_LEVELS = (0, 1, 2, 3)
+FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "0123"))
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
