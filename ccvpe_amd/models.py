@@ -127,10 +127,9 @@ def _pack_deconv(w, bias, col_map, ldo, dtype=torch.float32):
 _UP_S = {0: {0: ((0, 1),), 1: ((1, 0), (2, 1))}, 1: {0: ((0, 0), (1, 1)), 1: ((2, 0),)}}
 _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image for border class 0/1/2
 # Decoder levels (index j = 0..5 <-> level 6..1) whose ConvTranspose2d is folded into the following 3x3
-# conv (csrc/conv_igemm.hip: upconv_kernel).  Measured at B=64 fp32: levels 6-3 gain 2.3 ms/step (fewer
-# FLOPs, no deconv launch, no upsampled intermediate); levels 2-1 (N <= 40) lose because the gather-based
-# kernel re-reads the activation per tap from L2, so they keep deconv GEMM + LDS-halo 3x3 kernel.
-FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "0123"))
+# conv (csrc/conv_igemm.hip: upconv kernels).  Measured at B=64 fp32 (ms/step): none 46.8, levels 6-3 42.6,
+# 6-2 41.95, all six 41.7 -> all levels by default (CCVPE_FOLD_LEVELS overrides, e.g. "" to disable).
+FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
