@@ -129,6 +129,7 @@ _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image fo
 # Decoder levels (index j = 0..5 <-> level 6..1) whose ConvTranspose2d is folded into the following 3x3
 # conv (csrc/conv_igemm.hip: upconv kernels).  Measured at B=64 fp32 (ms/step): none 46.8, levels 6-3 42.6,
 # 6-2 41.95, all six 41.7 -> all levels by default (CCVPE_FOLD_LEVELS overrides, e.g. "" to disable).
+OVERLAP_DECODERS = __import__("os").environ.get("CCVPE_OVERLAP_DECODERS", "0") == "1"
 FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
 
 
@@ -347,6 +348,35 @@ class _CVMBase(nn.Module):
             self._pack_key = key
         return self._pack_cache
 
+    def _side_stream(self):
+        dev = next(self.parameters()).device
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = torch.cuda.Stream(device=dev)
+            self._side = st
+        return st
+
+    def _ori_decoder(self, pk, cat6, sfeats, batch):
+        """Orientation decoder (models.py:323-341): six (deconv -> cat skip -> double_conv) levels and the
+        final 3x3 conv to (cos, sin) + F.normalize."""
+        xo = cat6
+        for j in range(6):
+            ov = pk.ori[j]
+            hw = xo.shape[1]
+            skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+            if j in FOLD_LEVELS:
+                y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
+                                  src1=skip, c1=ov.c1, act=ops.ACT_RELU)
+            else:
+                up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
+                                    shift=ov.up_b, out_mode=ops.OUT_DECONV2X, algo_k=ov.k_algo)
+                y = _double_conv(ov, up, skip, batch, 2 * hw)
+            if j < 5:
+                xo = ops.conv_igemm(y, ov.n_a, ov.w_b, ov.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
+                                    kh=3, kw=3, pad=1, shift=ov.b_b)
+            else:
+                return ops.head_conv3x3(y, ov.w_b, ov.b_b, 2, True)            # + F.normalize (:341)
+
     def _loc_shifts(self):
         n_rot = MODEL_SPECS[self.kind]["n_rot"]
         if self.ori_noise is None:
@@ -371,16 +401,25 @@ class _CVMBase(nn.Module):
             sat = sat.contiguous().float()
             batch = grd.shape[0]
 
-            # encoders + descriptors (models.py:151-184)
-            gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
-            _, gh, gw, _ = gfeat.shape
-            if gh != spec["grd_h"]:
-                raise ValueError("ground feature height %d != %d expected by the descriptor heads"
-                                 % (gh, spec["grd_h"]))
-            y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw,
-                                shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4), out_f32=True)
-            gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
+            # encoders + descriptors (models.py:151-184).  The two encoders are independent until the
+            # first matching block and their late MBConv blocks are small launches (<= 1 workgroup per
+            # CU), so the ground encoder + descriptor heads run on a second HIP stream and overlap with
+            # the aerial encoder (fork/join by events: also legal inside hipGraph capture).
+            main = torch.cuda.current_stream()
+            side = self._side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
+                _, gh, gw, _ = gfeat.shape
+                if gh != spec["grd_h"]:
+                    raise ValueError("ground feature height %d != %d expected by the descriptor heads"
+                                     % (gh, spec["grd_h"]))
+                y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw,
+                                    shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4), out_f32=True)
+                gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
             svol, sfeats = _run_encoder(pk.sat, sat, False, True, pk.dtype)
+            main.wait_stream(side)
+            gdesc.record_stream(main)
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
                                    in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
 
@@ -408,6 +447,14 @@ class _CVMBase(nn.Module):
                 if j == 0:
                     cat6 = cat
                     scores_out.append(sc if self.ori_noise is None else sc[:, n_max:])
+                    # the orientation decoder (models.py:323-341) needs only cat6 + the skips.  Optionally it
+                    # runs on the side stream concurrently with the localisation decoder (measured: only
+                    # 39.29 -> 39.09 ms, both are MFMA-bound; off by default so that per-kernel timings
+                    # of the dominant GEMMs are not blurred by a co-running kernel)
+                    if OVERLAP_DECODERS:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            x_ori = self._ori_decoder(pk, cat6, sfeats, batch)
                 else:
                     scores_out.append(sc)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
@@ -426,24 +473,11 @@ class _CVMBase(nn.Module):
             logits = logits_map.reshape(batch, -1)                                   # models.py:319
             heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)             # models.py:320
 
-            # orientation decoder (models.py:323-341)
-            xo = cat6
-            for j in range(6):
-                ov = pk.ori[j]
-                hw = xo.shape[1]
-                skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
-                if j in FOLD_LEVELS:
-                    y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
-                                      src1=skip, c1=ov.c1, act=ops.ACT_RELU)
-                else:
-                    up = ops.conv_igemm(xo, ov.k, ov.up_w, ov.up_n, batch=batch, in_h=hw, in_w=hw,
-                                        shift=ov.up_b, out_mode=ops.OUT_DECONV2X, algo_k=ov.k_algo)
-                    y = _double_conv(ov, up, skip, batch, 2 * hw)
-                if j < 5:
-                    xo = ops.conv_igemm(y, ov.n_a, ov.w_b, ov.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
-                                        kh=3, kw=3, pad=1, shift=ov.b_b)
-                else:
-                    x_ori = ops.head_conv3x3(y, ov.w_b, ov.b_b, 2, True)            # + F.normalize (:341)
+            if OVERLAP_DECODERS:
+                main.wait_stream(side)          # join the orientation decoder
+                x_ori.record_stream(main)
+            else:
+                x_ori = self._ori_decoder(pk, cat6, sfeats, batch)
         return (logits, heatmap, x_ori) + tuple(scores_out)
 
 
