@@ -40,15 +40,21 @@ __global__ __launch_bounds__(256) void gdesc_kernel(const float* __restrict__ y1
 // models.py:125-127 (conv1.2), :146-148 + :341 (conv1_ori.2 + F.normalize)
 // HBM-bound: 64 B read, 4-8 B written per pixel.  One thread per pixel, lanes along W.
 // ---------------------------------------------------------------------------------------------
+// Workgroup = 4 rows x 64 columns of output; the (4+2) x (64+2) x 16-channel input halo is loaded
+// coalesced into LDS ONCE (a first version issued 36 global loads per pixel and sat at 1.7 TB/s,
+// TA-bound) and the 9 taps are read from LDS.  Pixel rows are padded 16 -> 20 floats.
+constexpr int HC_TW = 64, HC_TH = 4, HC_LD = 20;
+
 template <typename TX, int COUT>
 __global__ __launch_bounds__(256) void head_conv_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ out,
                                                         int H, int W, int normalize) {
   __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 16];
+  __shared__ __attribute__((aligned(16))) float tile[(HC_TH + 2) * (HC_TW + 2) * HC_LD];
   for (int i = threadIdx.x; i < COUT * 9 * 16; i += 256) ws[i] = w[i];
-  __syncthreads();
-  // XCD-aware order (see dwconv_kernel): neighbouring rows of a sample go to the same XCD's L2.
-  const int nxb = (W + 255) / 256;
+  // XCD-aware order (see dwconv_kernel): neighbouring tiles of a sample go to the same XCD's L2.
+  const int nxb = (W + HC_TW - 1) / HC_TW;
+  const int nyb = (H + HC_TH - 1) / HC_TH;
   const int total = gridDim.x;
   int lb;
   {
@@ -56,26 +62,35 @@ __global__ __launch_bounds__(256) void head_conv_kernel(const TX* __restrict__ x
     const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
     lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  const int ox = (lb % nxb) * 256 + threadIdx.x;
-  const int oy = (lb / nxb) % H;
-  const int b = lb / (nxb * H);
-  if (ox >= W) return;
+  const int x0 = (lb % nxb) * HC_TW;
+  const int y0 = ((lb / nxb) % nyb) * HC_TH;
+  const int b = lb / (nxb * nyb);
+  const TX* xb = x + (size_t)b * H * W * 16;
+  // halo load: (HC_TH+2)*(HC_TW+2) pixels x 4 quads of 4 channels
+  constexpr int NPX = (HC_TH + 2) * (HC_TW + 2);
+  for (int idx = threadIdx.x; idx < NPX * 4; idx += 256) {
+    const int pxl = idx >> 2, q = idx & 3;
+    const int hy = pxl / (HC_TW + 2), hx = pxl - hy * (HC_TW + 2);
+    const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) v = ld4<TX>(xb + ((size_t)iy * W + ix) * 16 + q * 4);
+    *reinterpret_cast<f32x4*>(&tile[pxl * HC_LD + q * 4]) = v;
+  }
+  __syncthreads();
+  const int tx = threadIdx.x & (HC_TW - 1), ty = threadIdx.x / HC_TW;
+  const int ox = x0 + tx, oy = y0 + ty;
+  if (ox >= W || oy >= H) return;
   float acc[COUT];
 #pragma unroll
   for (int o = 0; o < COUT; ++o) acc[o] = bias[o];
-  const TX* xb = x + (size_t)b * H * W * 16;
 #pragma unroll
   for (int ky = 0; ky < 3; ++ky) {
-    const int iy = oy + ky - 1;
-    if ((unsigned)iy >= (unsigned)H) continue;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) {
-      const int ix = ox + kx - 1;
-      if ((unsigned)ix >= (unsigned)W) continue;
-      const TX* px = xb + ((size_t)iy * W + ix) * 16;
+      const float* px = &tile[((ty + ky) * (HC_TW + 2) + tx + kx) * HC_LD];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const f32x4 v = ld4<TX>(px + q * 4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(px + q * 4);
 #pragma unroll
         for (int o = 0; o < COUT; ++o) {
           const f32x4 wv = *reinterpret_cast<const f32x4*>(&ws[((o * 3 + ky) * 3 + kx) * 16 + q * 4]);
@@ -306,7 +321,7 @@ template <typename TX>
 static int head_any(const TX* x, const float* w, const float* bias, float* out, int B, int H, int W, int cout,
                     int normalize, void* stream) {
   if (!aligned16(x)) return fail(CCVPE_EINVAL, "head_conv: x must be 16-byte aligned");
-  dim3 grid(((W + 255) / 256) * H * B);
+  dim3 grid(((W + HC_TW - 1) / HC_TW) * ((H + HC_TH - 1) / HC_TH) * B);
   if (cout == 1)
     hipLaunchKernelGGL((head_conv_kernel<TX, 1>), grid, dim3(256), 0, (hipStream_t)stream, x, w, bias, out, H, W, 0);
   else if (cout == 2)

@@ -14,12 +14,16 @@ from collections import defaultdict
 
 
 def family(name):
-    m = re.search(r"(igemm_kernel|conv3x3_kernel|upconv_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)>", name)
+    """rocprof kernel name -> the name bench.py's launch recorder uses."""
+    m = re.search(r"(igemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)>", name)
     if m:
         k, t, a, b, c = m.groups()
-        if t == "float":      # names as bench.py reports them
-            return "%s<%s,%s,%s>" % ({"igemm_kernel": "igemm_f32_kernel", "conv3x3_kernel": "conv3x3_f32_kernel"}.get(k, k + "<f32")
-                                     if k != "upconv_kernel" else "upconv_kernel<f32", a, b, c) if k != "upconv_kernel" else "upconv_kernel<f32,%s,%s,%s>" % (a, b, c)
+        if t == "float":
+            if k == "igemm_kernel":
+                return "igemm_f32_kernel<%s,%s,%s>" % (a, b, c)
+            if k == "conv3x3_kernel":
+                return "conv3x3_f32_kernel<%s,%s,%s>" % (a, b, c)
+            return "%s<f32,%s,%s,%s>" % (k, a, b, c)
         return "%s<bf16,%s,%s,%s>" % (k, a, b, c)
     m = re.search(r"ccvpe::(\w+?)(<[^>]*>)?\(", name) or re.search(r"ccvpe::(\w+)", name)
     return m.group(1) if m else None
