@@ -173,6 +173,81 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Depthwise conv for SMALL planes (H*W <= 1024: MBConv blocks 6-15, 32x32 ... 10x20): one workgroup
+// per (sample, 8-channel chunk) loads the whole input plane into LDS once (fp32), computes every
+// output pixel from LDS and writes ONE squeeze-partial row.  The strip kernel above is latency-bound
+// there (~100 us per launch for a few MB: k dependent global-load rounds per thread, 2k+ tiny
+// workgroups); this one has a single coalesced load phase.
+// ---------------------------------------------------------------------------------------------
+constexpr int DWP_CH = 8;
+
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, T* __restrict__ y,
+                                                           float* __restrict__ se_partial, int H, int W, int C, int Ho,
+                                                           int Wo, int circular) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* plane = sm;                          // [H*W][8]
+  float* wl = plane + (size_t)H * W * DWP_CH; // [K*K][8]
+  float* red = wl + K * K * DWP_CH;           // [256][4]
+  const int tid = threadIdx.x;
+  const int nch = C / DWP_CH;
+  const int chunk = blockIdx.x % nch;
+  const int b = blockIdx.x / nch;
+  const int c0 = chunk * DWP_CH;
+  const T* xb = x + (size_t)b * H * W * C + c0;
+  for (int i = tid; i < H * W * 2; i += 256) {
+    const int px = i >> 1, q = i & 1;
+    *reinterpret_cast<f32x4*>(plane + px * DWP_CH + q * 4) = ld4<T>(xb + (size_t)px * C + q * 4);
+  }
+  for (int i = tid; i < K * K * DWP_CH; i += 256) wl[i] = w[(size_t)(i / DWP_CH) * C + c0 + (i % DWP_CH)];
+  __syncthreads();
+  const int cg = tid & 1;
+  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0 + cg * 4);
+  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c0 + cg * 4);
+  T* yb = y + (size_t)b * Ho * Wo * C + c0 + cg * 4;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  for (int o = tid >> 1; o < Ho * Wo; o += 128) {
+    const int oy = o / Wo, ox = o - oy * Wo;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int iy = oy * S - PB + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        int ix = ox * S - PB + kx;
+        if (circular) {
+          if (ix < 0) ix += W;
+          else if (ix >= W) ix -= W;
+        }
+        if ((unsigned)ix < (unsigned)W) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(plane + (iy * W + ix) * DWP_CH + cg * 4);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * DWP_CH + cg * 4);
+          acc += v * wv;
+        }
+      }
+    }
+    f32x4 v = acc * sc + sh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+    st4<T>(yb + (size_t)o * C, v);
+    sum += v;
+  }
+  *reinterpret_cast<f32x4*>(red + tid * 4) = sum;
+  __syncthreads();
+  if (tid < 2) {                               // fixed-order reduction over the 128 pixel lanes
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < 128; ++i) t += *reinterpret_cast<const f32x4*>(red + (i * 2 + tid) * 4);
+    *reinterpret_cast<f32x4*>(se_partial + (size_t)b * C + c0 + tid * 4) = t;
+  }
+}
+
+static bool dw_use_plane(int H, int W, int C) { return H * W <= 1024 && C % DWP_CH == 0; }
+
 static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* ychunks, int* nblk, int* Ho, int* Wo,
                         int k, int* RB) {
   const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
@@ -240,11 +315,25 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     __syncthreads();
   }
   const int lane = tid & 63, wave = tid >> 6;
-  for (int j = wave; j < Cs; j += 4) {
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)j * C + c], mean[c], s);
-    s = wave_sum(s);
-    if (lane == 0) z[j] = swishf(s + b1[j]);
+  // FC1: 4 outputs per pass and wave (independent accumulators: the loads of 4 weight rows are in
+  // flight together; one pass per output made this kernel a chain of ~12 L2 latencies)
+  for (int j0 = wave * 4; j0 < Cs; j0 += 16) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int j1 = min(j0 + 1, Cs - 1), j2 = min(j0 + 2, Cs - 1), j3 = min(j0 + 3, Cs - 1);
+    for (int c = lane; c < C; c += 64) {
+      const float m = mean[c];
+      s0 = fmaf(w1[(size_t)j0 * C + c], m, s0);
+      s1 = fmaf(w1[(size_t)j1 * C + c], m, s1);
+      s2 = fmaf(w1[(size_t)j2 * C + c], m, s2);
+      s3 = fmaf(w1[(size_t)j3 * C + c], m, s3);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == 0) {
+      z[j0] = swishf(s0 + b1[j0]);
+      if (j0 + 1 < Cs) z[j0 + 1] = swishf(s1 + b1[j0 + 1]);
+      if (j0 + 2 < Cs) z[j0 + 2] = swishf(s2 + b1[j0 + 2]);
+      if (j0 + 3 < Cs) z[j0 + 3] = swishf(s3 + b1[j0 + 3]);
+    }
   }
   __syncthreads();
   // FC2 slice: 2 threads per channel split the Cs sum (w2 is [Cs][C]: coalesced over c)
@@ -287,6 +376,7 @@ extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
   // nblk does not depend on k for the SAME schedule (Ho = ceil-like of H/stride for both k)
   int cgx, P, yc, nblk, Ho, Wo, RB;
   if (C <= 0 || C % 4) return CCVPE_EINVAL;
+  if (dw_use_plane(H, W, C)) return 1;
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, 3, &RB);
   return nblk;
 }
@@ -302,6 +392,19 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
   int cgx, P, yc, nblk, Ho, Wo, RB;
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k, &RB);
   if (circular && (k / 2 + 1 > W)) return fail(CCVPE_EINVAL, "dwconv: W too small for circular wrap");
+  if (dw_use_plane(H, W, C)) {
+    const size_t psm = ((size_t)H * W * DWP_CH + (size_t)k * k * DWP_CH + 1024) * sizeof(float);
+    dim3 pgrid((unsigned)((C / DWP_CH) * B));
+    hipStream_t pst = (hipStream_t)stream;
+#define DWP_LAUNCH(K_, S_) \
+  hipLaunchKernelGGL((dwconv_plane_kernel<T, K_, S_>), pgrid, dim3(256), psm, pst, x, w, scale, shift, y, se_partial, H, W, C, Ho, Wo, circular)
+    if (k == 3 && stride == 1) DWP_LAUNCH(3, 1);
+    else if (k == 3 && stride == 2) DWP_LAUNCH(3, 2);
+    else if (k == 5 && stride == 1) DWP_LAUNCH(5, 1);
+    else DWP_LAUNCH(5, 2);
+#undef DWP_LAUNCH
+    return check_launch("dwconv_plane_kernel");
+  }
   const long total = (long)nblk * yc * B;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "dwconv: grid too large");
   dim3 grid((unsigned)total);
