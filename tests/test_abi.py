@@ -109,3 +109,37 @@ def test_cpu_inputs_are_rejected_not_emulated():
     grd, sat = synth.synthetic_pair(1, "vigor", 1)
     with pytest.raises(RuntimeError, match="MI355X"):
         net(grd, sat)
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Every entry point validates before launching: bad shapes / alignment come back as CCVPE_EINVAL
+    with a message (no exception crosses the ABI, nothing is enqueued), so this runs on CPU."""
+    import ctypes
+    lib = _lib.load()
+    EINVAL = -1
+    assert lib.ccvpe_conv_igemm_f32(None, None) == EINVAL
+    assert b"null desc" in lib.ccvpe_last_error()
+    d = _lib.ConvDesc()
+    d.src0, d.w, d.dst = 256, 512, 1024            # fake 16-byte aligned "pointers": never dereferenced
+    d.c0, d.ld0, d.batch, d.in_h, d.in_w = 12, 12, 1, 4, 4       # c0 not a multiple of 8
+    d.kh = d.kw = d.stride = 1
+    d.n, d.kpad, d.ldd = 16, 16, 16
+    assert lib.ccvpe_conv_igemm_f32(ctypes.byref(d), None) == EINVAL
+    assert b"multiples of 8" in lib.ccvpe_last_error()
+    d.c0, d.ld0, d.src0 = 16, 16, 260                              # misaligned pointer
+    assert lib.ccvpe_conv_igemm_f32(ctypes.byref(d), None) == EINVAL
+    assert b"aligned" in lib.ccvpe_last_error()
+    d.src0, d.kpad = 256, 8                                        # kpad too small / not a stage multiple
+    assert lib.ccvpe_conv_igemm_bf16(ctypes.byref(d), 0, None) == EINVAL
+    assert lib.ccvpe_upconv3x3_f32(None, None) == EINVAL
+    assert lib.ccvpe_dwconv_f32(256, 256, 256, 256, 256, 256, 1, 8, 8, 6, 3, 1, 0, None) == EINVAL      # C % 4
+    assert lib.ccvpe_dwconv_f32(256, 256, 256, 256, 256, 256, 1, 8, 8, 8, 4, 1, 0, None) == EINVAL      # k = 4
+    sh = (ctypes.c_int * 2)(0, 1)
+    assert lib.ccvpe_match_level_f32(256, 40, 256, 40, 40, sh, 2, 2, 0, 3, 256, 256, 48, 1, 64, 40, None) == EINVAL
+    assert b"odd stride" in lib.ccvpe_last_error()
+    assert lib.ccvpe_match_level_f32(256, 40, 256, 40, 40, sh, 99, 2, 0, 2, 256, 256, 48, 1, 64, 40, None) == EINVAL
+    assert lib.ccvpe_head_conv3x3_f32(256, 256, 256, 256, 1, 8, 8, 3, 0, None) == EINVAL               # cout = 3
+    assert lib.ccvpe_softmax_rows_f32(256, 256, 0, 8, None) == EINVAL
+    assert lib.ccvpe_mbconv_front_nblk(8, 8, 16, 96, 4, 1) == EINVAL
+    assert lib.ccvpe_mbconv_front_nblk(16, 16, 192, 1152, 3, 1) == 0        # valid but unfused shape
+    assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 1) == 4          # 64 output rows / 16 per band
