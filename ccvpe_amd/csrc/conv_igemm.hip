@@ -354,19 +354,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // Pixel tile = TH rows x 16 columns (one MFMA tile = 16 consecutive x of one row), TH = BM/16.
 // Stage s = (chunk, tap): chunk = 16 consecutive concat channels, tap = ky*3+kx.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MT, int NT, int WN>
-__global__ __launch_bounds__(256) void conv3x3_kernel(const IgemmParams p) {
+// NW = waves per workgroup (4 or 8).  The 8-wave form (512 threads, 2x the pixel tile) stages the same W
+// tile per K-stage for twice the MFMAs: the ablation (tools/ablation) attributes 11 % of the 4-wave
+// kernel's time to W staging, 2 % to barriers, 5 % to LDS fragment reads (MFMA-only ceiling 140 TF).
+template <typename T, int MT, int NT, int WN, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const IgemmParams p) {
+  constexpr int NTHR = 64 * NW;
+  constexpr int RPP = NTHR / 4;                    // staged rows per pass
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;                        // channels per chunk: 16 (fp32) or 32 (bf16)
-  constexpr int WM = 4 / WN;
+  constexpr int WM = NW / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
   constexpr int TH = BM / 16;
   constexpr int HR = TH + 2;                       // halo rows
   constexpr int HC = 18;                           // halo columns
   constexpr int HPX = HR * HC;
-  constexpr int H_IT = (HPX * 4 + 255) / 256;      // float4 loads per thread per chunk (halo)
-  constexpr int B_IT = (BN + 63) / 64;
+  constexpr int H_IT = (HPX * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk (halo)
+  constexpr int B_IT = (BN + RPP - 1) / RPP;
 
   // halo is single-buffered (one extra barrier per 9 stages) to keep LDS <= ~40 KB -> 3-4 blocks/CU
   __shared__ __attribute__((aligned(16))) float Hs[HPX][LDS_LD];
@@ -399,7 +404,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const IgemmParams p) {
   int h_sub[H_IT];
 #pragma unroll
   for (int it = 0; it < H_IT; ++it) {
-    const int idx = tid + 256 * it;
+    const int idx = tid + NTHR * it;
     const int px = idx >> 2, sub = idx & 3;
     h_sub[it] = sub;
     if (px < HPX) {
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const IgemmParams p) {
     const int ch = chunk * SK + ssub * E;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + 64 * it;
+      const int nrow = srow + RPP * it;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
         v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
@@ -449,7 +454,7 @@ __global__ __launch_bounds__(256) void conv3x3_kernel(const IgemmParams p) {
   auto store_w = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + 64 * it;
+      const int nrow = srow + RPP * it;
       if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
     }
   };
@@ -551,9 +556,9 @@ static int launch(const IgemmParams& p0, hipStream_t stream) {
   return check_launch("igemm_kernel");
 }
 
-template <typename T, int MT, int NT, int WN>
-static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
-  constexpr int WM = 4 / WN;
+template <typename T, int MT, int NT, int WN, int NW>
+static int launch3x3_nw(const IgemmParams& p0, int batch, hipStream_t stream) {
+  constexpr int WM = NW / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
   constexpr int TH = BM / 16;
@@ -564,8 +569,22 @@ static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
   const long total = (long)p.tiles_x * p.tiles_y * batch * p.tiles_n;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv3x3: grid too large");
   p.tiles_total = (int)total;
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
+  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN, NW>), dim3(p.tiles_total), dim3(64 * NW), 0, stream, p);
   return check_launch("conv3x3_kernel");
+}
+
+template <typename T, int MT, int NT, int WN>
+static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
+  // 8 waves (256-pixel tile) when the image is tall enough for the 2x taller tile and the grid still has
+  // >= 2 workgroups per CU; only instantiated for the wide-N tiles that dominate the decoder
+  // (NT = 5 would need > 128 VGPRs: with the 4-waves/SIMD cap it spills and drops from 121 to 88 TF)
+  if constexpr (WN == 2 && NT == 4 && sizeof(T) == 4) {
+    constexpr int TH8 = 16 * MT * (8 / WN) / 16;
+    constexpr int BN = 16 * NT * WN;
+    const long blocks8 = (long)((p0.W + 15) / 16) * ((p0.H + TH8 - 1) / TH8) * batch * ((p0.Npad + BN - 1) / BN);
+    if (p0.H % TH8 == 0 && blocks8 >= 512) return launch3x3_nw<T, MT, NT, WN, 8>(p0, batch, stream);
+  }
+  return launch3x3_nw<T, MT, NT, WN, 4>(p0, batch, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
