@@ -357,8 +357,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 // NW = waves per workgroup (4 or 8).  The 8-wave form (512 threads, 2x the pixel tile) stages the same W
 // tile per K-stage for twice the MFMAs: the ablation (tools/ablation) attributes 11 % of the 4-wave
 // kernel's time to W staging, 2 % to barriers, 5 % to LDS fragment reads (MFMA-only ceiling 140 TF).
-template <typename T, int MT, int NT, int WN, int NW>
+// DMA = W tile staged by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no wait before
+// the LDS store).  The DMA writes lane-linear (base + lane*16 B), so the W stage is an UNPADDED [BN][64 B]
+// image and the bank-conflict fix is an XOR swizzle of the 16-byte piece index, applied to the per-lane
+// SOURCE address and to the fragment read: slot(r, c) = 4r + (c ^ perm[(r>>2)&3]), perm = (0,2,3,1)
+// (conflict-free for the four ds_read_b128 lane groups).  Needs Npad % BN == 0 (no row guard possible).
+__device__ __forceinline__ int w_swz(int r) { return (0x1320 >> (((r >> 2) & 3) * 4)) & 3; }
+
+template <typename T, int MT, int NT, int WN, int NW, bool DMA>
 __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const IgemmParams p) {
+  constexpr int BLD = DMA ? 16 : LDS_LD;           // floats per W stage row
   constexpr int NTHR = 64 * NW;
   constexpr int RPP = NTHR / 4;                    // staged rows per pass
   constexpr int E = ElemTraits<T>::E;
@@ -375,7 +383,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
 
   // halo is single-buffered (one extra barrier per 9 stages) to keep LDS <= ~40 KB -> 3-4 blocks/CU
   __shared__ __attribute__((aligned(16))) float Hs[HPX][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][BLD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -440,22 +448,35 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     for (int it = 0; it < H_IT; ++it)
       if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Hs[0][0] + h_off[it]) = h_reg[it];
   };
-  auto load_w = [&](int chunk, int tap) {
-    const int ch = chunk * SK + ssub * E;
+  auto load_w = [&](int chunk, int tap, int dbuf) {
+    if constexpr (DMA) {
+      // one wave-instruction per 16 rows: lane -> (row = lane>>2, swizzled piece)
+      const int rl = lane >> 2;
+      const int c = (lane & 3) ^ w_swz(rl);
+      for (int g = wave; g < BN / 16; g += NW) {
+        const T* gp = wp + (size_t)(n0 + g * 16 + rl) * p.Kpad + tap * ctot + chunk * SK + c * E;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gp,
+                                         (__attribute__((address_space(3))) void*)&Bs[dbuf][g * 16][0], 16, 0, 0);
+      }
+    } else {
+      const int ch = chunk * SK + ssub * E;
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + RPP * it;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
-        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
-      b_reg[it] = v;
+      for (int it = 0; it < B_IT; ++it) {
+        const int nrow = srow + RPP * it;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
+          v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
+        b_reg[it] = v;
+      }
     }
   };
   auto store_w = [&](int buf) {
+    if constexpr (!DMA) {
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + RPP * it;
-      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+      for (int it = 0; it < B_IT; ++it) {
+        const int nrow = srow + RPP * it;
+        if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+      }
     }
   };
 
@@ -469,7 +490,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   const int fk = (lane >> 4) * 4;
 
   load_halo(0);
-  load_w(0, 0);
+  load_w(0, 0, 0);
   store_halo();
   store_w(0);
   __syncthreads();
@@ -480,7 +501,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     int nchunk = chunk, ntap = tap + 1;
     if (ntap == 9) { ntap = 0; ++nchunk; }
     const bool next_halo = (tap == 0) && (chunk + 1 < nchunks);
-    if (more) load_w(nchunk, ntap);
+    if (more) load_w(nchunk, ntap, (s + 1) & 1);
     if (next_halo) load_halo(chunk + 1);
 
     const int ky = tap / 3, kx = tap - ky * 3;
@@ -491,7 +512,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
       af[i] = *reinterpret_cast<const f32x4*>(hb + (((wm * MT + i) + ky) * HC + frow + kx) * LDS_LD + fk);
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][fk]);
+      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][DMA ? (((lane >> 4) ^ w_swz(frow)) * 4) : fk]);
     if (sizeof(T) == 4) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -569,7 +590,10 @@ static int launch3x3_nw(const IgemmParams& p0, int batch, hipStream_t stream) {
   const long total = (long)p.tiles_x * p.tiles_y * batch * p.tiles_n;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv3x3: grid too large");
   p.tiles_total = (int)total;
-  hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN, NW>), dim3(p.tiles_total), dim3(64 * NW), 0, stream, p);
+  if (p.Npad % BN == 0)   // W by LDS-DMA (no row guard possible: the tile must be fully inside the packed rows)
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN, NW, true>), dim3(p.tiles_total), dim3(64 * NW), 0, stream, p);
+  else
+    hipLaunchKernelGGL((conv3x3_kernel<T, MT, NT, WN, NW, false>), dim3(p.tiles_total), dim3(64 * NW), 0, stream, p);
   return check_launch("conv3x3_kernel");
 }
 
@@ -577,7 +601,8 @@ template <typename T, int MT, int NT, int WN>
 static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
   // 8 waves (256-pixel tile) when the image is tall enough for the 2x taller tile and the grid still has
   // >= 2 workgroups per CU; only instantiated for the wide-N tiles that dominate the decoder
-  // (NT = 5 would need > 128 VGPRs: with the 4-waves/SIMD cap it spills and drops from 121 to 88 TF)
+  // (NT = 5 needs > 128 VGPRs: with the 4-waves/SIMD cap it spills (121 -> 88 TF); uncapped at one
+  // workgroup per CU it reaches 119 TF vs 122.5 for the 4-wave form, so only NT = 4 uses 8 waves)
   if constexpr (WN == 2 && NT == 4 && sizeof(T) == 4) {
     constexpr int TH8 = 16 * MT * (8 / WN) / 16;
     constexpr int BN = 16 * NT * WN;
