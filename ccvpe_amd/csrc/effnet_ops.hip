@@ -12,7 +12,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // efficientnet_pytorch/model.py:181-182,289 ; padding utils.py:265-277 (zero), :341-353 (circular W)
 // One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
 // ---------------------------------------------------------------------------------------------
-template <typename T>
+// RAW: write the convolution result only (train mode: BatchNorm needs the batch statistics first)
+template <typename T, bool RAW>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, T* __restrict__ y,
@@ -21,8 +22,8 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   __shared__ float ssc[32], ssh[32];
   for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = w[i];
   if (threadIdx.x < 32) {
-    ssc[threadIdx.x] = scale[threadIdx.x];
-    ssh[threadIdx.x] = shift[threadIdx.x];
+    ssc[threadIdx.x] = RAW ? 1.f : scale[threadIdx.x];
+    ssh[threadIdx.x] = RAW ? 0.f : shift[threadIdx.x];
   }
   __syncthreads();
   const long total = (long)B * Ho * Wo;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     for (int j = 0; j < 4; ++j) {
       const int c = c4 * 4 + j;
       const float v = acc[c] * ssc[c] + ssh[c];
-      o[j] = swishf(v);
+      o[j] = RAW ? acc[c] : swishf(v);
     }
     st4<T>(out + c4 * 4, o);
   }
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int DW_TW = 4;
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, bool RAW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, T* __restrict__ y,
@@ -146,22 +147,28 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
         for (int t = 0; t < DW_TW; ++t) acc[t] += col[t * S + kx] * wv;
       }
     }
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-    const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (!RAW) {
+      sc = *reinterpret_cast<const f32x4*>(scale + c);
+      sh = *reinterpret_cast<const f32x4*>(shift + c);
+    }
     T* yb = y + ((size_t)(b * Ho + oy) * Wo) * C + c;
 #pragma unroll
     for (int t = 0; t < DW_TW; ++t) {
       const int ox = ox0 + t;
       if (ox < Wo) {
         f32x4 v = acc[t] * sc + sh;
+        if (!RAW) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+          for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+        }
         st4<T>(yb + (size_t)ox * C, v);
         sum += v;
       }
     }
   }
   }
+  if (RAW) return;   // no squeeze partials in raw mode (uniform: whole workgroup)
   // block reduction over the P strips, fixed order
   f32x4* red4 = reinterpret_cast<f32x4*>(red);
   if (pl < P) red4[pl * cgx + cgl] = sum;
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 // ---------------------------------------------------------------------------------------------
 constexpr int DWP_CH = 8;
 
-template <typename T, int K, int S>
+template <typename T, int K, int S, bool RAW>
 __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ y,
@@ -206,8 +213,11 @@ __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__
   for (int i = tid; i < K * K * DWP_CH; i += 256) wl[i] = w[(size_t)(i / DWP_CH) * C + c0 + (i % DWP_CH)];
   __syncthreads();
   const int cg = tid & 1;
-  const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c0 + cg * 4);
-  const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c0 + cg * 4);
+  f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+  if (!RAW) {
+    sc = *reinterpret_cast<const f32x4*>(scale + c0 + cg * 4);
+    sh = *reinterpret_cast<const f32x4*>(shift + c0 + cg * 4);
+  }
   T* yb = y + (size_t)b * Ho * Wo * C + c0 + cg * 4;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (int o = tid >> 1; o < Ho * Wo; o += 128) {
@@ -232,11 +242,14 @@ __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__
       }
     }
     f32x4 v = acc * sc + sh;
+    if (!RAW) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+      for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+    }
     st4<T>(yb + (size_t)o * C, v);
     sum += v;
   }
+  if (RAW) return;
   *reinterpret_cast<f32x4*>(red + tid * 4) = sum;
   __syncthreads();
   if (tid < 2) {                               // fixed-order reduction over the 128 pixel lanes
@@ -351,14 +364,14 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
 
 using namespace ccvpe;
 
-template <typename T>
+template <typename T, bool RAW = false>
 static int stem_any(const float* x, const float* w, const float* scale, const float* shift, T* y, int B, int H, int W,
                     int circular, void* stream) {
   if (B <= 0 || H < 3 || W < 3) return fail(CCVPE_EINVAL, "stem: bad shape");
   if (!aligned16(y)) return fail(CCVPE_EINVAL, "stem: y must be 16-byte aligned");
   const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
   const long total = (long)B * Ho * Wo;
-  hipLaunchKernelGGL(stem_conv_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL((stem_conv_kernel<T, RAW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
                      w, scale, shift, y, B, H, W, Ho, Wo, circular);
   return check_launch("stem_conv_kernel");
 }
@@ -366,6 +379,10 @@ static int stem_any(const float* x, const float* w, const float* scale, const fl
 extern "C" int ccvpe_stem_conv_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
                                    int B, int H, int W, int circular, void* stream) {
   return stem_any<float>(x, w, scale, shift, y, B, H, W, circular, stream);
+}
+extern "C" int ccvpe_stem_conv_raw_f32(const float* x, const float* w, float* y, int B, int H, int W, int circular,
+                                       void* stream) {
+  return stem_any<float, true>(x, w, nullptr, nullptr, y, B, H, W, circular, stream);
 }
 extern "C" int ccvpe_stem_conv_bf16(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                     int B, int H, int W, int circular, void* stream) {
@@ -381,13 +398,13 @@ extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
   return nblk;
 }
 
-template <typename T>
+template <typename T, bool RAW = false>
 static int dwconv_any(const T* x, const float* w, const float* scale, const float* shift, T* y, float* se_partial, int B,
                       int H, int W, int C, int k, int stride, int circular, void* stream) {
   if (C <= 0 || C % 4) return fail(CCVPE_EINVAL, "dwconv: C %% 4 != 0");
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "dwconv: k/stride unsupported");
-  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || !aligned16(se_partial) || !aligned16(scale) ||
-      !aligned16(shift))
+  if (!aligned16(x) || !aligned16(w) || !aligned16(y) || (!RAW && (!aligned16(se_partial) || !aligned16(scale) ||
+      !aligned16(shift))))
     return fail(CCVPE_EINVAL, "dwconv: pointers must be 16-byte aligned");
   int cgx, P, yc, nblk, Ho, Wo, RB;
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k, &RB);
@@ -397,7 +414,7 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
     dim3 pgrid((unsigned)((C / DWP_CH) * B));
     hipStream_t pst = (hipStream_t)stream;
 #define DWP_LAUNCH(K_, S_) \
-  hipLaunchKernelGGL((dwconv_plane_kernel<T, K_, S_>), pgrid, dim3(256), psm, pst, x, w, scale, shift, y, se_partial, H, W, C, Ho, Wo, circular)
+  hipLaunchKernelGGL((dwconv_plane_kernel<T, K_, S_, RAW>), pgrid, dim3(256), psm, pst, x, w, scale, shift, y, se_partial, H, W, C, Ho, Wo, circular)
     if (k == 3 && stride == 1) DWP_LAUNCH(3, 1);
     else if (k == 3 && stride == 2) DWP_LAUNCH(3, 2);
     else if (k == 5 && stride == 1) DWP_LAUNCH(5, 1);
@@ -411,7 +428,7 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
   const size_t smem = (size_t)P * cgx * 16;
   hipStream_t st = (hipStream_t)stream;
 #define DW_LAUNCH(K_, S_)                                                                                         \
-  hipLaunchKernelGGL((dwconv_kernel<T, K_, S_>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
+  hipLaunchKernelGGL((dwconv_kernel<T, K_, S_, RAW>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
                      C, Ho, Wo, cgx, P, nblk, circular, RB, yc, (int)total)
   if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
   else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);
@@ -425,6 +442,10 @@ extern "C" int ccvpe_dwconv_f32(const float* x, const float* w, const float* sca
                                 float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,
                                 void* stream) {
   return dwconv_any<float>(x, w, scale, shift, y, se_partial, B, H, W, C, k, stride, circular, stream);
+}
+extern "C" int ccvpe_dwconv_raw_f32(const float* x, const float* w, float* y, int B, int H, int W, int C, int k,
+                                    int stride, int circular, void* stream) {
+  return dwconv_any<float, true>(x, w, nullptr, nullptr, y, nullptr, B, H, W, C, k, stride, circular, stream);
 }
 extern "C" int ccvpe_dwconv_bf16(const void* x, const float* w, const float* scale, const float* shift, void* y,
                                  float* se_partial, int B, int H, int W, int C, int k, int stride, int circular,

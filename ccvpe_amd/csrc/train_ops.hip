@@ -1,0 +1,200 @@
+// Train-mode BatchNorm for the EfficientNet encoders (efficientnet_pytorch/model.py:63,73,87,182,210 with
+// momentum 0.01, eps 1e-3 — utils.py:665-666) and drop_connect (utils.py:129-154).
+//
+// Eval mode folds BN into the conv epilogues; in train mode the statistics are those of the batch, so the
+// conv writes its raw output, `bn_stats` reduces it per channel and `bn_act` normalises.
+//
+//   bn_stats : per-channel (count, mean, M2) partials per workgroup (Welford over the workgroup's rows,
+//              fixed order), merged by ONE workgroup with Chan's formula -> mean, biased variance, and
+//              the running-statistics update (unbiased variance, momentum m):  deterministic, and free
+//              of the E[x^2]-E[x]^2 cancellation.
+//   bn_act   : y = act((x-mean)*rsqrt(var+eps)*gamma+beta) [* dc_scale[b]] [+ residual], optional
+//              per-(sample, workgroup) channel sums of y for the SE squeeze.
+// All HBM-bound elementwise/reduction work on fp32 NHWC rows.
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BNS_ROWS = 256;   // rows per workgroup in the stats kernel
+
+// one thread per channel column slice: thread t handles channel (t % cw) for rows r = t / cw, +R, ...
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long rows, int C,
+                                                               float* __restrict__ part /*[nblk][3][C]*/) {
+  extern __shared__ float sm[];   // [R][cw][3]
+  const int cw = C < 256 ? C : 256;
+  const int R = 256 / cw;
+  const int tid = threadIdx.x;
+  const int cl = tid % cw, rr = tid / cw;
+  const long r0 = (long)blockIdx.x * BNS_ROWS;
+  const long r1 = r0 + BNS_ROWS < rows ? r0 + BNS_ROWS : rows;
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + cl;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (rr < R && c < C) {
+      for (long r = r0 + rr; r < r1; r += R) {          // Welford
+        const float v = x[r * C + c];
+        n += 1.f;
+        const float d = v - mean;
+        mean += d / n;
+        m2 = fmaf(d, v - mean, m2);
+      }
+    }
+    sm[(rr * cw + cl) * 3 + 0] = n;
+    sm[(rr * cw + cl) * 3 + 1] = mean;
+    sm[(rr * cw + cl) * 3 + 2] = m2;
+    __syncthreads();
+    if (rr == 0 && c < C) {                              // Chan merge over the R row slices, fixed order
+      float na = sm[cl * 3], ma = sm[cl * 3 + 1], sa = sm[cl * 3 + 2];
+      for (int j = 1; j < R; ++j) {
+        const float nb = sm[(j * cw + cl) * 3], mb = sm[(j * cw + cl) * 3 + 1], sb = sm[(j * cw + cl) * 3 + 2];
+        if (nb > 0.f) {
+          const float nt = na + nb, d = mb - ma;
+          ma += d * (nb / nt);
+          sa += sb + d * d * (na * nb / nt);
+          na = nt;
+        }
+      }
+      float* p = part + (size_t)blockIdx.x * 3 * C;
+      p[c] = na;
+      p[C + c] = ma;
+      p[2 * C + c] = sa;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_stats_merge_kernel(const float* __restrict__ part, int nblk, int C,
+                                                             float* __restrict__ mean, float* __restrict__ var,
+                                                             float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                             float momentum) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float na = 0.f, ma = 0.f, sa = 0.f;
+  for (int j = 0; j < nblk; ++j) {
+    const float* p = part + (size_t)j * 3 * C;
+    const float nb = p[c], mb = p[C + c], sb = p[2 * C + c];
+    if (nb > 0.f) {
+      const float nt = na + nb, d = mb - ma;
+      ma += d * (nb / nt);
+      sa += sb + d * d * (na * nb / nt);
+      na = nt;
+    }
+  }
+  mean[c] = ma;
+  var[c] = sa / na;                                           // biased: what the normalisation uses
+  if (run_mean) {
+    run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * ma;
+    run_var[c] = (1.f - momentum) * run_var[c] + momentum * (na > 1.f ? sa / (na - 1.f) : sa);   // unbiased
+  }
+}
+
+// rows of one sample are contiguous: grid = (chunks per sample, B); thread = 4 channels
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                     const float* __restrict__ var, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, int act,
+                                                     const float* __restrict__ residual,
+                                                     const float* __restrict__ dc_scale, float* __restrict__ y,
+                                                     float* __restrict__ se_partial, int rows_per_sample, int C,
+                                                     int rows_per_block) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx] float4 (SE partials)
+  const int b = blockIdx.y;
+  const int cg4 = C >> 2;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(r0 + rows_per_block, rows_per_sample);
+  const float dcs = dc_scale ? dc_scale[b] : 1.0f;
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    if (pl < P && cg < cg4) {
+      const int c = cg * 4;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(var + c);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(beta + c);
+      f32x4 sc, sh;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        sc[j] = ga[j] / sqrtf(vv[j] + eps);
+        sh[j] = be[j] - mu[j] * sc[j];
+      }
+      for (int r = r0 + pl; r < r1; r += P) {
+        const size_t off = ((size_t)b * rows_per_sample + r) * C + c;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + off) * sc + sh;
+        if (act == CCVPE_ACT_SWISH) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+        } else if (act == CCVPE_ACT_RELU) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        }
+        v *= dcs;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + off);
+        *reinterpret_cast<f32x4*>(y + off) = v;
+        sum += v;
+      }
+    }
+    if (se_partial) {
+      f32x4* red4 = reinterpret_cast<f32x4*>(red);
+      if (pl < P) red4[pl * cgx + cgl] = sum;
+      __syncthreads();
+      if (pl == 0 && cg < cg4) {
+        f32x4 t = red4[cgl];
+        for (int q = 1; q < P; ++q) t += red4[q * cgx + cgl];
+        *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * gridDim.x + blockIdx.x) * C + cg * 4) = t;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+extern "C" int ccvpe_bn_stats_nblk(int rows) { return (int)((rows + BNS_ROWS - 1) / BNS_ROWS); }
+
+extern "C" int ccvpe_bn_stats_f32(const float* x, int rows, int channels, float* mean, float* var, float* run_mean,
+                                  float* run_var, float momentum, float* scratch, void* stream) {
+  if (rows <= 0 || channels <= 0) return fail(CCVPE_EINVAL, "bn_stats: bad shape");
+  if ((run_mean == nullptr) != (run_var == nullptr)) return fail(CCVPE_EINVAL, "bn_stats: run_mean/run_var both or none");
+  const int nblk = (int)((rows + BNS_ROWS - 1) / BNS_ROWS);
+  const int cw = channels < 256 ? channels : 256;
+  const int R = 256 / cw;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), (size_t)R * cw * 3 * sizeof(float), st, x, (long)rows,
+                     channels, scratch);
+  hipLaunchKernelGGL(bn_stats_merge_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, scratch, nblk, channels, mean,
+                     var, run_mean, run_var, momentum);
+  return check_launch("bn_stats");
+}
+
+extern "C" int ccvpe_bn_act_nblk(int rows_per_sample) {
+  int rpb = rows_per_sample / 32;
+  if (rpb < 8) rpb = 8;
+  return (rows_per_sample + rpb - 1) / rpb;
+}
+
+extern "C" int ccvpe_bn_act_f32(const float* x, const float* mean, const float* var, const float* gamma,
+                                const float* beta, float eps, int act, const float* residual, const float* dc_scale,
+                                float* y, float* se_partial, int batch, int rows_per_sample, int channels,
+                                void* stream) {
+  if (batch <= 0 || rows_per_sample <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "bn_act: bad shape");
+  if (!aligned16(x) || !aligned16(y) || (residual && !aligned16(residual)) || !aligned16(mean) || !aligned16(var) ||
+      !aligned16(gamma) || !aligned16(beta))
+    return fail(CCVPE_EINVAL, "bn_act: pointers must be 16-byte aligned");
+  int rpb = rows_per_sample / 32;
+  if (rpb < 8) rpb = 8;
+  const int nblk = (rows_per_sample + rpb - 1) / rpb;
+  const int cg4 = channels / 4;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  hipLaunchKernelGGL(bn_act_kernel, dim3(nblk, batch), dim3(256), (size_t)P * cgx * 16, (hipStream_t)stream, x, mean, var,
+                     gamma, beta, eps, act, residual, dc_scale, y, se_partial, rows_per_sample, channels, rpb);
+  return check_launch("bn_act_kernel");
+}

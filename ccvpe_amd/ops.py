@@ -322,6 +322,69 @@ def softmax_rows(logits):
     return out
 
 
+# ----------------------------------------------------------------------------------------------
+# train-mode pieces
+# ----------------------------------------------------------------------------------------------
+def stem_conv_raw(x_nchw, w, circular):
+    """Stem convolution only (train mode: BN needs the batch statistics first)."""
+    lib = _lib.load()
+    _chk(x_nchw, "x")
+    _chk(w, "w")
+    b, c, h, wd = x_nchw.shape
+    ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
+    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=torch.float32)
+    check(lib.ccvpe_stem_conv_raw_f32(_ptr(x_nchw), _ptr(w), _ptr(y), b, h, wd, int(bool(circular)), _stream()),
+          "ccvpe_stem_conv_raw_f32")
+    return y
+
+
+def dwconv_raw(x, w, k, stride, circular):
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(w, "w")
+    b, h, wd, c = x.shape
+    tot = (k - 1) if stride == 1 else (k - 2)
+    ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
+    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_dwconv_raw_f32(_ptr(x), _ptr(w), _ptr(y), b, h, wd, c, k, stride, int(bool(circular)), _stream()),
+          "ccvpe_dwconv_raw_f32")
+    return y
+
+
+def bn_stats(x, run_mean=None, run_var=None, momentum=0.01):
+    """Per-channel batch mean / biased variance of an NHWC tensor; updates the running statistics in place
+    (momentum as torch: new = (1-m)*old + m*batch, unbiased variance)."""
+    lib = _lib.load()
+    _chk(x, "x")
+    _chk(run_mean, "run_mean")
+    _chk(run_var, "run_var")
+    c = x.shape[-1]
+    rows = x.numel() // c
+    mean = torch.empty((c,), device=x.device, dtype=torch.float32)
+    var = torch.empty((c,), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((lib.ccvpe_bn_stats_nblk(rows) * 3 * c,), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_bn_stats_f32(_ptr(x), rows, c, _ptr(mean), _ptr(var), _ptr(run_mean), _ptr(run_var),
+                                 float(momentum), _ptr(scratch), _stream()), "ccvpe_bn_stats_f32")
+    return mean, var
+
+
+def bn_act(x, mean, var, gamma, beta, eps, act, residual=None, dc_scale=None, want_se=False):
+    """Normalise + activation (+ drop-connect scale, + residual); optionally SE squeeze partials."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (mean, "mean"), (var, "var"), (gamma, "gamma"), (beta, "beta"), (residual, "residual"),
+                  (dc_scale, "dc_scale")):
+        _chk(t, nm)
+    b, c = x.shape[0], x.shape[-1]
+    rps = x.numel() // (b * c)
+    y = torch.empty_like(x)
+    part = None
+    if want_se:
+        part = torch.empty((b, lib.ccvpe_bn_act_nblk(rps), c), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_bn_act_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps), act, _ptr(residual),
+                               _ptr(dc_scale), _ptr(y), _ptr(part), b, rps, c, _stream()), "ccvpe_bn_act_f32")
+    return (y, part) if want_se else y
+
+
 def eval_postprocess(heatmap, ori):
     """train_VIGOR.py:294-324 on the device: returns [B,6] = (y, x, cos, sin, angle_deg, prob)."""
     lib = _lib.load()

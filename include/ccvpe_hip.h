@@ -215,6 +215,31 @@ int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const floa
                                float* scratch, int batch, int hw, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Train-mode pieces (efficientnet_pytorch/model.py:63,73,87,182,210: BatchNorm2d with batch statistics,
+ * momentum 0.01, eps 1e-3; utils.py:129-154 drop_connect).  In train mode the conv kernels write their
+ * raw output (ccvpe_conv_igemm_f32 with scale = shift = NULL, ccvpe_stem_conv_raw_f32,
+ * ccvpe_dwconv_raw_f32), then:
+ *   ccvpe_bn_stats_f32 : per-channel mean and BIASED variance of x [rows, channels] (Welford partials per
+ *       256-row workgroup merged with Chan's formula: deterministic); if run_mean/run_var are given they
+ *       are updated in place: run = (1-momentum)*run + momentum*(mean | UNBIASED variance).
+ *       scratch: 3 * channels * ccvpe_bn_stats_nblk(rows) floats.
+ *   ccvpe_bn_act_f32   : y = act((x-mean)/sqrt(var+eps)*gamma+beta) [* dc_scale[b]] [+ residual]; with
+ *       se_partial != NULL also writes per-(sample, workgroup) channel sums of y
+ *       [batch][ccvpe_bn_act_nblk(rows_per_sample)][channels] for ccvpe_se_gate_f32.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_stem_conv_raw_f32(const float* x_nchw, const float* w, float* y, int batch, int in_h, int in_w,
+                            int circular, void* stream);
+int ccvpe_dwconv_raw_f32(const float* x, const float* w, float* y, int batch, int in_h, int in_w, int channels,
+                         int k, int stride, int circular, void* stream);
+int ccvpe_bn_stats_nblk(int rows);
+int ccvpe_bn_stats_f32(const float* x, int rows, int channels, float* mean, float* var, float* run_mean,
+                       float* run_var, float momentum, float* scratch, void* stream);
+int ccvpe_bn_act_nblk(int rows_per_sample);
+int ccvpe_bn_act_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
+                     float eps, int act, const float* residual, const float* dc_scale, float* y,
+                     float* se_partial, int batch, int rows_per_sample, int channels, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers

@@ -66,10 +66,20 @@ def same_conv(x, w, k, s, sched, circular, groups=1):
     return F.conv2d(x, w, None, s, 0, 1, groups)
 
 
-def bn_eval(x, sd, p):
-    """nn.BatchNorm2d in eval mode (model.py:63,73,87,182,210)."""
-    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
-                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+BN_MOMENTUM = 0.01     # model.py:52: 1 - batch_norm_momentum(0.99)
+
+
+def bn_eval(x, sd, p, train=None):
+    """nn.BatchNorm2d (model.py:63,73,87,182,210).  Eval mode: running statistics.  Train mode
+    (`train` = dict collecting the updated running statistics): batch statistics, running statistics
+    updated with momentum 0.01 and the unbiased variance, exactly as torch does."""
+    if train is None:
+        return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                            sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+    rm, rv = sd[p + ".running_mean"].clone(), sd[p + ".running_var"].clone()
+    y = F.batch_norm(x, rm, rv, sd[p + ".weight"], sd[p + ".bias"], True, BN_MOMENTUM, BN_EPS)
+    train[p + ".running_mean"], train[p + ".running_var"] = rm, rv
+    return y
 
 
 def swish(x):
@@ -77,41 +87,45 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
-def mbconv(x, sd, p, k, s, e, cin, cout, sched, circular):
-    """MBConvBlock.forward in eval mode (model.py:90-131); drop_connect is the identity
-    when not training (utils.py:141-142)."""
+def mbconv(x, sd, p, k, s, e, cin, cout, sched, circular, train=None, drop_scale=None):
+    """MBConvBlock.forward (model.py:90-131).  Eval: drop_connect is the identity (utils.py:141-142).
+    Train: `drop_scale` [B] = binary_mask / keep_prob multiplies the block output before the skip
+    (utils.py:145-153; the mask itself is random upstream, so parity tests inject it)."""
     inp = x
     if e != 1:
         x = swish(bn_eval(same_conv(x, sd[p + "._expand_conv.weight"], 1, 1, sched, circular),
-                          sd, p + "._bn0"))
+                          sd, p + "._bn0", train))
     mid = cin * e
     x = same_conv(x, sd[p + "._depthwise_conv.weight"], k, s, sched, circular, groups=mid)
-    x = swish(bn_eval(x, sd, p + "._bn1"))
+    x = swish(bn_eval(x, sd, p + "._bn1", train))
     # squeeze-excite (model.py:113-118)
     z = x.mean(dim=(2, 3), keepdim=True)
     z = swish(F.conv2d(z, sd[p + "._se_reduce.weight"], sd[p + "._se_reduce.bias"]))
     z = F.conv2d(z, sd[p + "._se_expand.weight"], sd[p + "._se_expand.bias"])
     x = torch.sigmoid(z) * x
-    x = bn_eval(F.conv2d(x, sd[p + "._project_conv.weight"]), sd, p + "._bn2")
+    x = bn_eval(F.conv2d(x, sd[p + "._project_conv.weight"]), sd, p + "._bn2", train)
     if s == 1 and cin == cout:          # model.py:126-130
+        if drop_scale is not None:
+            x = x * drop_scale.view(-1, 1, 1, 1)
         x = x + inp
     return x
 
 
-def efficientnet_features(x, sd, prefix, circular):
+def efficientnet_features(x, sd, prefix, circular, train=None, drop_scales=None):
     """EfficientNet.extract_features_multiscale (model.py:303-326); extract_features
     (model.py:278-301) is the same computation without the list.
-    Returns (head_out [B,1280,h,w], [16 block outputs])."""
+    Returns (head_out [B,1280,h,w], [16 block outputs]).  drop_scales: {block index: [B]} (train)."""
     sched = STATIC_IMAGE_SIZE
     x = swish(bn_eval(same_conv(x, sd[prefix + "._conv_stem.weight"], 3, 2, sched, circular),
-                      sd, prefix + "._bn0"))
+                      sd, prefix + "._bn0", train))
     sched = math.ceil(sched / 2)
     feats = []
     for i, (k, s, e, cin, cout) in enumerate(B0_BLOCKS):
-        x = mbconv(x, sd, "%s._blocks.%d" % (prefix, i), k, s, e, cin, cout, sched, circular)
+        ds = None if drop_scales is None else drop_scales.get(i)
+        x = mbconv(x, sd, "%s._blocks.%d" % (prefix, i), k, s, e, cin, cout, sched, circular, train, ds)
         sched = math.ceil(sched / s)
         feats.append(x)
-    x = swish(bn_eval(F.conv2d(x, sd[prefix + "._conv_head.weight"]), sd, prefix + "._bn1"))
+    x = swish(bn_eval(F.conv2d(x, sd[prefix + "._conv_head.weight"]), sd, prefix + "._bn1", train))
     return x, feats
 
 
@@ -188,7 +202,7 @@ MODEL_CFG = {
 
 
 def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
-            return_intermediates=False):
+            return_intermediates=False, train_stats=None, drop_scales=None):
     """CVM_VIGOR.forward (models.py:150-343) when kind='vigor' and ori_noise is None;
     CVM_VIGOR_ori_prior.forward (models.py:448-652) when ori_noise is a number;
     CVM_KITTI.forward (models.py:752-950) when kind='kitti'.
@@ -204,9 +218,13 @@ def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
         loc_shifts = list(range(-k, k + 1))
     inter = {}
 
-    gfeat, _ = efficientnet_features(grd, sd, "grd_efficientnet", circular_padding)
+    # train_stats: pass a dict to run the encoders in TRAIN mode (batch-stat BN); it receives the updated
+    # running statistics.  drop_scales: {"grd_efficientnet"|"sat_efficientnet": {block: [B] scale}}.
+    dsg = None if drop_scales is None else drop_scales.get("grd_efficientnet")
+    dss = None if drop_scales is None else drop_scales.get("sat_efficientnet")
+    gfeat, _ = efficientnet_features(grd, sd, "grd_efficientnet", circular_padding, train_stats, dsg)
     gdesc = [ground_descriptor(gfeat, sd, l) for l in range(1, 7)]
-    svol, sfeats = efficientnet_features(sat, sd, "sat_efficientnet", False)
+    svol, sfeats = efficientnet_features(sat, sd, "sat_efficientnet", False, train_stats, dss)
     sdesc = aerial_descriptor(svol, sd)
     inter.update(grd_feature=gfeat, grd_descriptors=gdesc, sat_feature=svol,
                  sat_descriptor=sdesc, sat_skips=[sfeats[i] for i in SKIP_BLOCKS])

@@ -25,6 +25,27 @@ BLOCK_HW = (8, 12)                       # MBConv module fixtures: input [2, cin
 ZERO_PAD_BLOCKS = (0, 1, 3, 5, 8, 11, 15)  # subset stored for the non-circular encoder
 
 
+TRAIN_CASE = dict(kind="vigor", circular=True, wseed=0, pseed=2024, batch=2, grd="vigor")
+
+
+def train_drop_masks(batch):
+    """Deterministic drop_connect draws {(encoder, block): [B] 0/1} for the train-mode parity case and
+    the matching per-sample scales mask/keep_prob (rate = 0.2*block/16, model.py:293-295)."""
+    from ccvpe_amd import synth
+    skip = [i for i, (k, s, e, cin, cout) in enumerate(synth.B0_BLOCKS) if s == 1 and cin == cout and i > 0]
+    masks, scales = {}, {"grd_efficientnet": {}, "sat_efficientnet": {}}
+    for enc, seed in (("grd_efficientnet", 1), ("sat_efficientnet", 2)):
+        for i in skip:
+            mk = (synth.uniform((batch,), 9000 + seed * 100 + i) > 0.3).float()
+            masks[(enc, i)] = mk
+            scales[enc][i] = mk / (1.0 - 0.2 * i / 16)
+    return masks, scales, skip
+
+
+RUNNING_STAT_SAMPLES = ("grd_efficientnet._bn0", "grd_efficientnet._blocks.3._bn1", "grd_efficientnet._blocks.15._bn2",
+                        "sat_efficientnet._blocks.0._bn1", "sat_efficientnet._blocks.9._bn0", "sat_efficientnet._bn1")
+
+
 def summarize_forward(out):
     """9-tuple -> dict of small numpy arrays (strided samples + arg-max facts)."""
     logits, heat, ori = out[0], out[1], out[2]

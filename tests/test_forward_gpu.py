@@ -99,11 +99,14 @@ def test_weights_repacked_after_update(synth_sd):
     assert torch.allclose(b, a + 1.0, atol=1e-5)
 
 
-def test_train_mode_raises(synth_sd):
+def test_train_mode_outputs_carry_no_autograd_graph(synth_sd):
+    """Backward is not implemented: train-mode outputs must not pretend to be differentiable."""
     net = build("vigor_prior0", synth_sd).train()
     grd, sat = synth.synthetic_pair(1, "vigor", 3)
-    with pytest.raises(NotImplementedError):
-        net(grd.cuda(), sat.cuda())
+    out = net(grd.cuda(), sat.cuda())
+    assert not out[0].requires_grad
+    with pytest.raises(RuntimeError):
+        out[0].sum().backward()
 
 
 def test_hipgraph_replay_is_bit_identical(synth_sd):

@@ -44,6 +44,26 @@ def test_forward_matches_reference_golden(name, synth_sd):
         G.assert_close(t[:, :, ::st, ::st].numpy(), want["sat_block%d_s" % blk], RTOL, ATOL, "skip")
 
 
+def test_train_mode_forward_matches_reference_golden(synth_sd):
+    """Batch-statistic BN + injected drop_connect draws + running-stat updates (reference in .train())."""
+    c = G.TRAIN_CASE
+    want = G.load("fwd_vigor_trainmode")
+    sd = synth_sd(c["kind"], c["wseed"])
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    _, scales, _ = G.train_drop_masks(c["batch"])
+    stats = {}
+    with torch.no_grad():
+        out = O.forward(sd, grd, sat, c["kind"], c["circular"], None, train_stats=stats, drop_scales=scales)
+    got = G.summarize_forward(out)
+    assert (got["top4_idx"][:, 0] == want["top4_idx"][:, 0]).all()
+    G.assert_close(got["logits_s4"], want["logits_s4"], RTOL, ATOL, "train logits")
+    for i in range(1, 7):
+        G.assert_close(got["score%d" % i], want["score%d" % i], RTOL, 2e-6, "train score%d" % i)
+    for k in G.RUNNING_STAT_SAMPLES:
+        G.assert_close(stats[k + ".running_mean"].numpy(), want["rm:" + k], 1e-5, 1e-6, "running_mean " + k)
+        G.assert_close(stats[k + ".running_var"].numpy(), want["rv:" + k], 1e-5, 1e-6, "running_var " + k)
+
+
 @pytest.mark.parametrize("circ", [True, False])
 def test_effnet_modules(circ, synth_sd):
     want = G.load("effnet_modules_" + ("circ" if circ else "zero"))

@@ -61,6 +61,34 @@ def main():
                 d["grd_desc%d" % l] = getattr(net, "grd_feature_to_descriptor%d" % l)(gf).numpy()
             save("fwd_" + name, d)
 
+        # ---- train-mode forward (batch-stat BN, injected drop_connect draws) ----------------------------
+        import efficientnet_pytorch.model as effmodel
+        c = G.TRAIN_CASE
+        sd = sds[(c["kind"], c["wseed"])]
+        masks, _, skip = G.train_drop_masks(c["batch"])
+        order = [("grd_efficientnet", i) for i in skip] + [("sat_efficientnet", i) for i in skip]
+        calls = []
+
+        def injected_drop_connect(inputs, p, training):
+            key = order[len(calls)]
+            calls.append(key)
+            return inputs / (1 - p) * masks[key].view(-1, 1, 1, 1)
+        real_dc = effmodel.drop_connect
+        effmodel.drop_connect = injected_drop_connect
+        net = ref_models.CVM_VIGOR("cpu", c["circular"])
+        net.load_state_dict(sd, strict=True)
+        net.train()
+        grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+        out = net(grd, sat)
+        effmodel.drop_connect = real_dc
+        assert len(calls) == len(order)
+        d = G.summarize_forward(out)
+        after = net.state_dict()
+        for k in G.RUNNING_STAT_SAMPLES:
+            d["rm:" + k] = after[k + ".running_mean"].numpy()
+            d["rv:" + k] = after[k + ".running_var"].numpy()
+        save("fwd_vigor_trainmode", d)
+
         # ---- single MBConv blocks / stem on small inputs -----------------------------------
         sd = sds[("vigor", 0)]
         for circ, pfx in ((True, "grd_efficientnet"), (False, "sat_efficientnet")):
