@@ -75,6 +75,10 @@ PROTOTYPES = {
     "ccvpe_bn_stats_f32": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_float, c_void_p, c_void_p]),
     "ccvpe_bn_act_nblk": (c_int, [c_int]),
     "ccvpe_bn_act_f32": (c_int, [c_void_p] * 5 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_conv_wgrad_scratch_floats": (c_int, [c_int] * 9),
+    "ccvpe_conv_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                     c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ccvpe_colsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ccvpe_conv_igemm_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "ccvpe_stem_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

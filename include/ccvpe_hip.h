@@ -240,6 +240,24 @@ int ccvpe_bn_act_f32(const float* x, const float* mean, const float* var, const 
                      float* se_partial, int batch, int rows_per_sample, int channels, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Backward building blocks (the autograd wiring is not built yet).
+ *   ccvpe_conv_wgrad_f32: weight gradient of any dense conv of the path,
+ *       dw[n][tap][c] = sum_pixels dy[pixel][n] * x[pixel*stride - pad + tap][c]     (layout O,kh,kw,I)
+ *     x given as one or two concatenated NHWC sources (like the forward), dy [batch,Ho,Wo,ldy].
+ *     scratch: ccvpe_conv_wgrad_scratch_floats(...) floats.  ConvTranspose2d(k2,s2): call it with
+ *     x := the (high-res) output gradient, dy := the (low-res) forward input, k=2, stride=2.
+ *   input gradients need no new kernel: they are ccvpe_conv_igemm_f32 calls with re-packed weights
+ *     (1x1: W^T; 3x3: taps flipped, in/out swapped; deconv <-> conv 2x2 stride 2) — ccvpe_amd/backward.py.
+ *   ccvpe_colsum_f32: per-channel column sums (bias gradients); scratch ceil(rows/256)*channels floats.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad, int ctot,
+                                    int n);
+int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1, const float* dy,
+                         int ldy, float* dw, float* scratch, int batch, int in_h, int in_w, int kh, int kw,
+                         int stride, int pad, int n, void* stream);
+int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers
