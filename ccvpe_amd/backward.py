@@ -85,3 +85,95 @@ def conv2x2s2_dgrad(dy, w):
     c = w.shape[1]
     wp, _ = _pack_deconv(w, w.new_zeros((c,)), [(0, 0, n)], n)
     return ops.conv_igemm(dy, n, wp, 4 * c, batch=b, in_h=h, in_w=wd, out_mode=ops.OUT_DECONV2X)
+
+
+# ---- EfficientNet train-mode pieces (csrc/train_bwd.hip) ----------------------------------------------
+
+def _bc(x):
+    b, c = x.shape[0], x.shape[-1]
+    return b, x.numel() // (b * c), c
+
+
+def bn_act_bwd(x, dv, mean, var, gamma, beta, eps, act, gate=None, dmean=None, dc_scale=None):
+    """Backward of ops.bn_act: returns (dx, dgamma, dbeta).  gate / dmean [B,C] fold the SE branches in."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (dv, "dv"), (mean, "mean"), (var, "var"), (gamma, "gamma"), (beta, "beta"), (gate, "gate"),
+                  (dmean, "dmean"), (dc_scale, "dc_scale")):
+        ops._chk(t, nm)
+    b, rps, c = _bc(x)
+    dx = torch.empty_like(x)
+    dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
+    dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((2 * c * b * lib.ccvpe_bn_bwd_nblk(rps),), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_bn_act_bwd_f32(ops._ptr(x), ops._ptr(dv), ops._ptr(mean), ops._ptr(var), ops._ptr(gamma), ops._ptr(beta),
+                                   ops._ptr(gate), ops._ptr(dmean), ops._ptr(dc_scale), float(eps), act, ops._ptr(dx),
+                                   ops._ptr(dgamma), ops._ptr(dbeta), ops._ptr(scratch), b, rps, c, ops._stream()),
+          "ccvpe_bn_act_bwd_f32")
+    return dx, dgamma, dbeta
+
+
+def se_dgate_partials(x, dv, mean, var, gamma, beta, eps, act):
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (dv, "dv")):
+        ops._chk(t, nm)
+    b, rps, c = _bc(x)
+    part = torch.empty((b, lib.ccvpe_bn_bwd_nblk(rps), c), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_se_dgate_f32(ops._ptr(x), ops._ptr(dv), ops._ptr(mean), ops._ptr(var), ops._ptr(gamma), ops._ptr(beta),
+                                 float(eps), act, ops._ptr(part), b, rps, c, ops._stream()), "ccvpe_se_dgate_f32")
+    return part
+
+
+def se_bwd(se_partial, hw, dgate_partial, w1, b1, w2t, b2):
+    """Returns (dmean [B,C] (already / HW), dw1 [Cs,C], db1, dw2 [C,Cs], db2)."""
+    lib = _lib.load()
+    for t, nm in ((se_partial, "se_partial"), (dgate_partial, "dgate_partial"), (w1, "w1"), (b1, "b1"), (w2t, "w2t"),
+                  (b2, "b2")):
+        ops._chk(t, nm)
+    b, nblk, c = se_partial.shape
+    cs = w1.shape[0]
+    dev = se_partial.device
+    dmean = torch.empty((b, c), device=dev, dtype=torch.float32)
+    dw1 = torch.empty((cs, c), device=dev, dtype=torch.float32)
+    db1 = torch.empty((cs,), device=dev, dtype=torch.float32)
+    dw2 = torch.empty((c, cs), device=dev, dtype=torch.float32)
+    db2 = torch.empty((c,), device=dev, dtype=torch.float32)
+    scratch = torch.empty((2 * b * (c + cs),), device=dev, dtype=torch.float32)
+    check(lib.ccvpe_se_bwd_f32(ops._ptr(se_partial), nblk, 1.0 / float(hw), ops._ptr(dgate_partial), dgate_partial.shape[1],
+                               ops._ptr(w1), ops._ptr(b1), ops._ptr(w2t), ops._ptr(b2), ops._ptr(dmean), ops._ptr(dw1),
+                               ops._ptr(db1), ops._ptr(dw2), ops._ptr(db2), ops._ptr(scratch), b, c, cs, ops._stream()),
+          "ccvpe_se_bwd_f32")
+    return dmean, dw1, db1, dw2, db2
+
+
+def dwconv_dgrad(dy, w, in_h, in_w, k, stride, circular):
+    lib = _lib.load()
+    ops._chk(dy, "dy")
+    ops._chk(w, "w")
+    b, c = dy.shape[0], dy.shape[-1]
+    dx = torch.empty((b, in_h, in_w, c), device=dy.device, dtype=torch.float32)
+    check(lib.ccvpe_dwconv_dgrad_f32(ops._ptr(dy), ops._ptr(w), ops._ptr(dx), b, in_h, in_w, c, k, stride,
+                                     int(bool(circular)), ops._stream()), "ccvpe_dwconv_dgrad_f32")
+    return dx
+
+
+def dwconv_wgrad(x, dy, k, stride, circular):
+    """Depthwise weight gradient in the packed layout [k*k][C]."""
+    lib = _lib.load()
+    ops._chk(x, "x")
+    ops._chk(dy, "dy")
+    b, h, w, c = x.shape
+    nblk = lib.ccvpe_dwconv_wgrad_nblk(h, w, k, stride)
+    scratch = torch.empty((b * nblk * k * k * c,), device=x.device, dtype=torch.float32)
+    dw = torch.empty((k * k, c), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_dwconv_wgrad_f32(ops._ptr(x), ops._ptr(dy), ops._ptr(dw), ops._ptr(scratch), b, h, w, c, k, stride,
+                                     int(bool(circular)), ops._stream()), "ccvpe_dwconv_wgrad_f32")
+    return dw
+
+
+def relu_bwd(y, dy):
+    lib = _lib.load()
+    ops._chk(y, "y")
+    ops._chk(dy, "dy")
+    dx = torch.empty_like(dy)
+    check(lib.ccvpe_relu_bwd_f32(ops._ptr(y), ops._ptr(dy), ops._ptr(dx), dy.numel(), ops._stream()), "ccvpe_relu_bwd_f32")
+    return dx

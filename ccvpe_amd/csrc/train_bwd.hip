@@ -1,0 +1,578 @@
+// Backward of the train-mode BatchNorm + activation (+ drop_connect scale, + SE gating) and small
+// elementwise backward helpers.  Forward (csrc/train_ops.hip):
+//     xhat = (x - mean) * istd ;  z = xhat*gamma + beta ;  y = act(z) * dcs[b] (+ residual)
+// and, when the BN output u = act(z) feeds squeeze-excite:  v = u * gate[b,c] (model.py:113-118).
+// Given the gradient dv w.r.t. the consumer's input (v, or y when there is no SE):
+//     du   = dv * gate[b,c] + dmean[b,c] / HW        (SE: gate product + the avg-pool branch)
+//     g    = du * dcs[b] * act'(z)
+//     dbeta = sum g ; dgamma = sum g*xhat ; dx = gamma*istd*(g - dbeta/M - xhat*dgamma/M)
+// Two kernels: a per-channel reduction (partials per workgroup, merged in fixed order: deterministic) and
+// an elementwise apply that recomputes g.  The residual branch's gradient is dv itself (no kernel).
+// swish'(z) = s*(1 + z*(1-s)), s = sigmoid(z)   (efficientnet_pytorch/utils.py:71-75).
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct BnBwdParams {
+  const float* x;       // raw conv output [B, rows_per_sample, C]
+  const float* dv;      // incoming gradient, same shape
+  const float* mean;
+  const float* var;
+  const float* gamma;
+  const float* beta;
+  const float* gate;    // [B,C] or null
+  const float* dmean;   // [B,C] or null (already divided by HW)
+  const float* dcs;     // [B] or null
+  float eps;
+  int act;
+  int rows_per_sample, C, rows_per_block, nblk;   // nblk = workgroups per sample
+};
+
+__device__ __forceinline__ float act_grad(int act, float z) {
+  if (act == CCVPE_ACT_SWISH) {
+    const float s = sigmoidf(z);
+    return s * (1.0f + z * (1.0f - s));
+  }
+  if (act == CCVPE_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+
+// g for 4 channels of one row
+__device__ __forceinline__ void bn_bwd_g(const BnBwdParams& p, int b, size_t off, int c, const f32x4& mu, const f32x4& istd,
+                                         const f32x4& ga, const f32x4& be, float dcs, f32x4& g, f32x4& xh) {
+  const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off);
+  f32x4 du = *reinterpret_cast<const f32x4*>(p.dv + off);
+  if (p.gate) du *= *reinterpret_cast<const f32x4*>(p.gate + (size_t)b * p.C + c);
+  if (p.dmean) du += *reinterpret_cast<const f32x4*>(p.dmean + (size_t)b * p.C + c);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xh[j] = (xv[j] - mu[j]) * istd[j];
+    const float z = xh[j] * ga[j] + be[j];
+    g[j] = du[j] * dcs * act_grad(p.act, z);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p, float* __restrict__ part /*[B*nblk][2][C]*/) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx][2] float4
+  const int b = blockIdx.y;
+  const int cg4 = p.C >> 2;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int r0 = blockIdx.x * p.rows_per_block;
+  const int r1 = min(r0 + p.rows_per_block, p.rows_per_sample);
+  const float dcs = p.dcs ? p.dcs[b] : 1.0f;
+  float* out = part + ((size_t)b * p.nblk + blockIdx.x) * 2 * p.C;
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (pl < P && cg < cg4) {
+      const int c = cg * 4;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.var + c);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      f32x4 istd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) istd[j] = 1.0f / sqrtf(vv[j] + p.eps);
+      for (int r = r0 + pl; r < r1; r += P) {
+        f32x4 g, xh;
+        bn_bwd_g(p, b, ((size_t)b * p.rows_per_sample + r) * p.C + c, c, mu, istd, ga, be, dcs, g, xh);
+        s0 += g;
+        s1 += g * xh;
+      }
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red);
+    if (pl < P) {
+      red4[(pl * cgx + cgl) * 2] = s0;
+      red4[(pl * cgx + cgl) * 2 + 1] = s1;
+    }
+    __syncthreads();
+    if (pl == 0 && cg < cg4) {
+      f32x4 t0 = red4[cgl * 2], t1 = red4[cgl * 2 + 1];
+      for (int q = 1; q < P; ++q) {
+        t0 += red4[(q * cgx + cgl) * 2];
+        t1 += red4[(q * cgx + cgl) * 2 + 1];
+      }
+      *reinterpret_cast<f32x4*>(out + cg * 4) = t0;
+      *reinterpret_cast<f32x4*>(out + p.C + cg * 4) = t1;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restrict__ part, int nparts, int C,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a = 0.f, b = 0.f;
+  for (int k = 0; k < nparts; ++k) {
+    a += part[(size_t)k * 2 * C + c];
+    b += part[(size_t)k * 2 * C + C + c];
+  }
+  dbeta[c] = a;
+  dgamma[c] = b;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p, const float* __restrict__ dbeta,
+                                                           const float* __restrict__ dgamma, float inv_m,
+                                                           float* __restrict__ dx) {
+  const int b = blockIdx.y;
+  const int cg4 = p.C >> 2;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int r0 = blockIdx.x * p.rows_per_block;
+  const int r1 = min(r0 + p.rows_per_block, p.rows_per_sample);
+  const float dcs = p.dcs ? p.dcs[b] : 1.0f;
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    if (pl < P && cg < cg4) {
+      const int c = cg * 4;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.var + c);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      const f32x4 db = *reinterpret_cast<const f32x4*>(dbeta + c) * inv_m;
+      const f32x4 dg = *reinterpret_cast<const f32x4*>(dgamma + c) * inv_m;
+      f32x4 istd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) istd[j] = 1.0f / sqrtf(vv[j] + p.eps);
+      for (int r = r0 + pl; r < r1; r += P) {
+        const size_t off = ((size_t)b * p.rows_per_sample + r) * p.C + c;
+        f32x4 g, xh;
+        bn_bwd_g(p, b, off, c, mu, istd, ga, be, dcs, g, xh);
+        *reinterpret_cast<f32x4*>(dx + off) = ga * istd * (g - db - xh * dg);
+      }
+    }
+  }
+}
+
+// dgate[b,c] = sum_px dv[b,px,c] * u[b,px,c],  u = act(bn(x))  (the SE product's gradient w.r.t. the gate)
+__global__ __launch_bounds__(256) void se_dgate_kernel(const BnBwdParams p, float* __restrict__ part /*[B][nblk][C]*/) {
+  extern __shared__ __attribute__((aligned(16))) float red[];
+  const int b = blockIdx.y;
+  const int cg4 = p.C >> 2;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int r0 = blockIdx.x * p.rows_per_block;
+  const int r1 = min(r0 + p.rows_per_block, p.rows_per_sample);
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f};
+    if (pl < P && cg < cg4) {
+      const int c = cg * 4;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.var + c);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      for (int r = r0 + pl; r < r1; r += P) {
+        const size_t off = ((size_t)b * p.rows_per_sample + r) * p.C + c;
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(p.x + off);
+        const f32x4 dv = *reinterpret_cast<const f32x4*>(p.dv + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float z = (xv[j] - mu[j]) / sqrtf(vv[j] + p.eps) * ga[j] + be[j];
+          const float u = p.act == CCVPE_ACT_SWISH ? swishf(z) : (p.act == CCVPE_ACT_RELU ? fmaxf(z, 0.f) : z);
+          s0[j] = fmaf(dv[j], u, s0[j]);
+        }
+      }
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red);
+    if (pl < P) red4[pl * cgx + cgl] = s0;
+    __syncthreads();
+    if (pl == 0 && cg < cg4) {
+      f32x4 t = red4[cgl];
+      for (int q = 1; q < P; ++q) t += red4[q * cgx + cgl];
+      *reinterpret_cast<f32x4*>(part + ((size_t)b * p.nblk + blockIdx.x) * p.C + cg * 4) = t;
+    }
+    __syncthreads();
+  }
+}
+
+// dx = dy where y > 0 else 0   (ReLU between the two convs of double_conv, models.py:45)
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
+                                                       float* __restrict__ dx, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+  f32x4 g = reinterpret_cast<const f32x4*>(dy)[i];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) g[j] = yv[j] > 0.f ? g[j] : 0.f;
+  reinterpret_cast<f32x4*>(dx)[i] = g;
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+static int bn_rows_per_block(int rows_per_sample) {
+  int rpb = rows_per_sample / 32;
+  return rpb < 8 ? 8 : rpb;
+}
+
+static int fill_bn_params(BnBwdParams& p, const float* x, const float* dv, const float* mean, const float* var,
+                          const float* gamma, const float* beta, const float* gate, const float* dmean,
+                          const float* dcs, float eps, int act, int batch, int rows_per_sample, int channels) {
+  if (batch <= 0 || rows_per_sample <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "bn_bwd: bad shape");
+  if (!aligned16(x) || !aligned16(dv) || !aligned16(mean) || !aligned16(var) || !aligned16(gamma) || !aligned16(beta) ||
+      (gate && !aligned16(gate)) || (dmean && !aligned16(dmean)))
+    return fail(CCVPE_EINVAL, "bn_bwd: pointers must be 16-byte aligned");
+  p.x = x; p.dv = dv; p.mean = mean; p.var = var; p.gamma = gamma; p.beta = beta;
+  p.gate = gate; p.dmean = dmean; p.dcs = dcs; p.eps = eps; p.act = act;
+  p.rows_per_sample = rows_per_sample; p.C = channels;
+  p.rows_per_block = bn_rows_per_block(rows_per_sample);
+  p.nblk = (rows_per_sample + p.rows_per_block - 1) / p.rows_per_block;
+  return CCVPE_OK;
+}
+
+extern "C" int ccvpe_bn_bwd_nblk(int rows_per_sample) {
+  const int rpb = bn_rows_per_block(rows_per_sample);
+  return (rows_per_sample + rpb - 1) / rpb;
+}
+
+extern "C" int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float* mean, const float* var,
+                                    const float* gamma, const float* beta, const float* gate, const float* dmean,
+                                    const float* dc_scale, float eps, int act, float* dx, float* dgamma, float* dbeta,
+                                    float* scratch, int batch, int rows_per_sample, int channels, void* stream) {
+  BnBwdParams p;
+  const int rc = fill_bn_params(p, x, dv, mean, var, gamma, beta, gate, dmean, dc_scale, eps, act, batch, rows_per_sample,
+                                channels);
+  if (rc) return rc;
+  const int cg4 = channels / 4, cgx = cg4 < 256 ? cg4 : 256, P = 256 / cgx;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(p.nblk, batch);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), (size_t)P * cgx * 2 * 16, st, p, scratch);
+  hipLaunchKernelGGL(bn_bwd_merge_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, scratch, p.nblk * batch, channels,
+                     dbeta, dgamma);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, p, dbeta, dgamma,
+                     1.0f / ((float)batch * (float)rows_per_sample), dx);
+  return check_launch("bn_act_bwd");
+}
+
+extern "C" int ccvpe_se_dgate_f32(const float* x, const float* dv, const float* mean, const float* var,
+                                  const float* gamma, const float* beta, float eps, int act, float* part, int batch,
+                                  int rows_per_sample, int channels, void* stream) {
+  BnBwdParams p;
+  const int rc = fill_bn_params(p, x, dv, mean, var, gamma, beta, nullptr, nullptr, nullptr, eps, act, batch,
+                                rows_per_sample, channels);
+  if (rc) return rc;
+  const int cg4 = channels / 4, cgx = cg4 < 256 ? cg4 : 256, P = 256 / cgx;
+  hipLaunchKernelGGL(se_dgate_kernel, dim3(p.nblk, batch), dim3(256), (size_t)P * cgx * 16, (hipStream_t)stream, p, part);
+  return check_launch("se_dgate_kernel");
+}
+
+extern "C" int ccvpe_relu_bwd_f32(const float* y, const float* dy, float* dx, int n_elems, void* stream) {
+  if (n_elems <= 0 || n_elems % 4) return fail(CCVPE_EINVAL, "relu_bwd: n %% 4");
+  const long n4 = n_elems / 4;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, y, dy, dx, n4);
+  return check_launch("relu_bwd_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Depthwise conv backward (efficientnet_pytorch/model.py:181-182; padding utils.py:265-277 / 341-353).
+// Forward: y[b,oy,ox,c] = sum_{ky,kx} xpad[b, oy*S+ky, ox*S+kx, c] * w[ky,kx,c], xpad = x padded by PB before
+// (zero rows; zero or circular columns).
+//   dgrad: dx[b,iy,ix,c] = sum over the (ky,kx,oy,ox) whose padded coordinate maps onto (iy,ix).
+//   wgrad: dw[ky,kx,c]   = sum_{b,oy,ox} dy[b,oy,ox,c] * xpad[b, oy*S+ky, ox*S+kx, c]   (partials + merge).
+// ---------------------------------------------------------------------------------------------
+namespace ccvpe {
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                       float* __restrict__ dx, int B, int H, int W, int C, int Ho,
+                                                       int Wo, int circular) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  const int cg4 = C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  const long total = (long)B * H * W * cg4;
+  if (idx >= total) return;
+  const int cg = (int)(idx % cg4);
+  long px = idx / cg4;
+  const int ix = (int)(px % W);
+  px /= W;
+  const int iy = (int)(px % H);
+  const int b = (int)(px / H);
+  const int c = cg * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float* dyb = dy + (size_t)b * Ho * Wo * C + c;
+  const int mlo = circular ? -1 : 0, mhi = circular ? 1 : 0;
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    const int ty = iy + PB - ky;
+    if (ty < 0 || (ty % S) != 0) continue;
+    const int oy = ty / S;
+    if (oy >= Ho) continue;
+    for (int m = mlo; m <= mhi; ++m) {
+      const int jp = ix + PB + m * W;          // padded column this input column appears at
+      if (jp < 0 || jp >= W + ((S == 1) ? (K - 1) : (K - 2))) continue;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int tx = jp - kx;
+        if (tx < 0 || (tx % S) != 0) continue;
+        const int ox = tx / S;
+        if (ox >= Wo) continue;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dyb + ((size_t)oy * Wo + ox) * C);
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(ky * K + kx) * C + c);
+        acc += g * wv;
+      }
+    }
+  }
+  *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + c) = acc;
+}
+
+constexpr int DWW_ROWS = 4;   // output rows per workgroup
+
+template <int K, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       float* __restrict__ part, int H, int W, int C, int Ho, int Wo,
+                                                       int circular, int nblk) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx] float4
+  const int b = blockIdx.y;
+  const int cg4 = C >> 2;
+  const int cgx = cg4 < 64 ? cg4 : 64;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int oy0 = blockIdx.x * DWW_ROWS;
+  const int npx = min(DWW_ROWS, Ho - oy0) * Wo;
+  float* out = part + ((size_t)b * nblk + blockIdx.x) * K * K * C;
+  const float* xb = x + (size_t)b * H * W * C;
+  const float* dyb = dy + ((size_t)b * Ho + oy0) * Wo * C;
+  f32x4* red4 = reinterpret_cast<f32x4*>(red);
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    const bool live = pl < P && cg < cg4;
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      for (int o = pl; o < npx; o += P) {
+        const int oy = oy0 + o / Wo, ox = o % Wo;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dyb + (size_t)o * C + cg * 4);
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          const int iy = oy * S - PB + ky;
+          if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            int ix = ox * S - PB + kx;
+            if (circular) {
+              if (ix < 0) ix += W;
+              else if (ix >= W) ix -= W;
+            }
+            if ((unsigned)ix < (unsigned)W)
+              acc[ky * K + kx] += g * *reinterpret_cast<const f32x4*>(xb + ((size_t)iy * W + ix) * C + cg * 4);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+      if (pl < P) red4[pl * cgx + cgl] = acc[t];
+      __syncthreads();
+      if (pl == 0 && cg < cg4) {
+        f32x4 s = red4[cgl];
+        for (int q = 1; q < P; ++q) s += red4[q * cgx + cgl];
+        *reinterpret_cast<f32x4*>(out + (size_t)t * C + cg * 4) = s;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int n,
+                                                        float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int k = 0; k < nparts; ++k) a += part[(size_t)k * n + i];
+  out[i] = a;
+}
+
+}  // namespace ccvpe
+
+static void dw_out_dims(int H, int W, int k, int stride, int* Ho, int* Wo) {
+  const int tot = stride == 1 ? k - 1 : k - 2;
+  *Ho = (H + tot - k) / stride + 1;
+  *Wo = (W + tot - k) / stride + 1;
+}
+
+extern "C" int ccvpe_dwconv_dgrad_f32(const float* dy, const float* w, float* dx, int batch, int in_h, int in_w,
+                                      int channels, int k, int stride, int circular, void* stream) {
+  if (batch <= 0 || in_h <= 0 || in_w <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "dw_dgrad: bad shape");
+  if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(CCVPE_EINVAL, "dw_dgrad: k in {3,5}, stride in {1,2}");
+  int Ho, Wo;
+  dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
+  const long total = (long)batch * in_h * in_w * (channels / 4);
+  dim3 grid((unsigned)((total + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+#define DG(K_, S_) hipLaunchKernelGGL((dw_dgrad_kernel<K_, S_>), grid, dim3(256), 0, st, dy, w, dx, batch, in_h, in_w, channels, Ho, Wo, circular)
+  if (k == 3 && stride == 1) DG(3, 1);
+  else if (k == 3) DG(3, 2);
+  else if (stride == 1) DG(5, 1);
+  else DG(5, 2);
+#undef DG
+  return check_launch("dw_dgrad_kernel");
+}
+
+extern "C" int ccvpe_dwconv_wgrad_nblk(int in_h, int in_w, int k, int stride) {
+  int Ho, Wo;
+  dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
+  return (Ho + DWW_ROWS - 1) / DWW_ROWS;
+}
+
+extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw, float* scratch, int batch, int in_h,
+                                      int in_w, int channels, int k, int stride, int circular, void* stream) {
+  if (batch <= 0 || in_h <= 0 || in_w <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "dw_wgrad: bad shape");
+  if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(CCVPE_EINVAL, "dw_wgrad: k in {3,5}, stride in {1,2}");
+  int Ho, Wo;
+  dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
+  const int nblk = (Ho + DWW_ROWS - 1) / DWW_ROWS;
+  const int cg4 = channels / 4, cgx = cg4 < 64 ? cg4 : 64, P = 256 / cgx;
+  dim3 grid(nblk, batch);
+  hipStream_t st = (hipStream_t)stream;
+  const size_t lds = (size_t)P * cgx * 16;
+#define WG(K_, S_) hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_>), grid, dim3(256), lds, st, x, dy, scratch, in_h, in_w, channels, Ho, Wo, circular, nblk)
+  if (k == 3 && stride == 1) WG(3, 1);
+  else if (k == 3) WG(3, 2);
+  else if (stride == 1) WG(5, 1);
+  else WG(5, 2);
+#undef WG
+  const int n = k * k * channels;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch, nblk * batch, n, dw);
+  return check_launch("dw_wgrad_kernel");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Squeeze-excite backward (efficientnet_pytorch/model.py:113-118).  Forward per sample:
+//   m = mean_px(u) ; z1 = W1 m + b1 ; a = swish(z1) ; z2 = W2 a + b2 ; gate = sigmoid(z2)
+// se_bwd_sample_kernel (one workgroup per sample) recomputes the forward from the squeeze partials and emits
+//   dz2 [B][C], dz1 [B][Cs], a [B][Cs], m [B][C] and dmean [B][C] = (W1^T dz1) / HW
+// se_bwd_weights_kernel then reduces over the batch: dW2[c][s] = sum_b dz2[b,c] a[b,s] (reference layout
+// [C][Cs]), dW1[s][c] = sum_b dz1[b,s] m[b,c], db2 = sum_b dz2, db1 = sum_b dz1.
+// ---------------------------------------------------------------------------------------------
+namespace ccvpe {
+
+__global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restrict__ se_partial, int nblk, float inv_hw,
+                                                            const float* __restrict__ dg_partial, int ndg,
+                                                            const float* __restrict__ w1, const float* __restrict__ b1,
+                                                            const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                            float* __restrict__ dz2_o, float* __restrict__ dz1_o,
+                                                            float* __restrict__ a_o, float* __restrict__ m_o,
+                                                            float* __restrict__ dmean_o, int C, int Cs) {
+  extern __shared__ float sm[];
+  float* m = sm;            // [C]
+  float* dz2 = m + C;       // [C]
+  float* z1 = dz2 + C;      // [Cs]
+  float* a = z1 + Cs;       // [Cs]
+  float* dz1 = a + Cs;      // [Cs]
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int c = tid; c < C; c += 256) {
+    float s = 0.f;
+    for (int k = 0; k < nblk; ++k) s += se_partial[((size_t)b * nblk + k) * C + c];
+    m[c] = s * inv_hw;
+    m_o[(size_t)b * C + c] = s * inv_hw;
+  }
+  __syncthreads();
+  for (int s = wv; s < Cs; s += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(w1[(size_t)s * C + c], m[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float z = acc + b1[s];
+      z1[s] = z;
+      a[s] = swishf(z);
+      a_o[(size_t)b * Cs + s] = a[s];
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float z = b2[c];
+    for (int s = 0; s < Cs; ++s) z = fmaf(w2t[(size_t)s * C + c], a[s], z);
+    const float g = sigmoidf(z);
+    float dg = 0.f;
+    for (int k = 0; k < ndg; ++k) dg += dg_partial[((size_t)b * ndg + k) * C + c];
+    const float d = dg * g * (1.0f - g);
+    dz2[c] = d;
+    dz2_o[(size_t)b * C + c] = d;
+  }
+  __syncthreads();
+  for (int s = wv; s < Cs; s += 4) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) acc = fmaf(w2t[(size_t)s * C + c], dz2[c], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      const float z = z1[s], sg = sigmoidf(z);
+      const float d = acc * sg * (1.0f + z * (1.0f - sg));
+      dz1[s] = d;
+      dz1_o[(size_t)b * Cs + s] = d;
+    }
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float dm = 0.f;
+    for (int s = 0; s < Cs; ++s) dm = fmaf(w1[(size_t)s * C + c], dz1[s], dm);
+    dmean_o[(size_t)b * C + c] = dm * inv_hw;
+  }
+}
+
+__global__ __launch_bounds__(256) void se_bwd_weights_kernel(const float* __restrict__ dz2, const float* __restrict__ dz1,
+                                                             const float* __restrict__ a, const float* __restrict__ m,
+                                                             float* __restrict__ dw1, float* __restrict__ db1,
+                                                             float* __restrict__ dw2, float* __restrict__ db2, int B,
+                                                             int C, int Cs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = C * Cs;
+  if (i < n) {
+    {  // dW2 [C][Cs]
+      const int c = i / Cs, s = i % Cs;
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc = fmaf(dz2[(size_t)b * C + c], a[(size_t)b * Cs + s], acc);
+      dw2[i] = acc;
+    }
+    {  // dW1 [Cs][C]
+      const int s = i / C, c = i % C;
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc = fmaf(dz1[(size_t)b * Cs + s], m[(size_t)b * C + c], acc);
+      dw1[i] = acc;
+    }
+  }
+  if (i < C) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dz2[(size_t)b * C + i];
+    db2[i] = acc;
+  }
+  if (i < Cs) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += dz1[(size_t)b * Cs + i];
+    db1[i] = acc;
+  }
+}
+
+}  // namespace ccvpe
+
+extern "C" int ccvpe_se_bwd_f32(const float* se_partial, int nblk, float inv_hw, const float* dgate_partial, int ndg,
+                                const float* w1, const float* b1, const float* w2t, const float* b2, float* dmean,
+                                float* dw1, float* db1, float* dw2, float* db2, float* scratch, int batch, int channels,
+                                int squeezed, void* stream) {
+  if (batch <= 0 || channels <= 0 || squeezed <= 0 || nblk <= 0 || ndg <= 0) return fail(CCVPE_EINVAL, "se_bwd: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  float* dz2 = scratch;                              // [B][C]
+  float* m = dz2 + (size_t)batch * channels;         // [B][C]
+  float* dz1 = m + (size_t)batch * channels;         // [B][Cs]
+  float* a = dz1 + (size_t)batch * squeezed;         // [B][Cs]
+  const size_t lds = (size_t)(2 * channels + 3 * squeezed) * sizeof(float);
+  hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(batch), dim3(256), lds, st, se_partial, nblk, inv_hw, dgate_partial, ndg, w1,
+                     b1, w2t, b2, dz2, dz1, a, m, dmean, channels, squeezed);
+  hipLaunchKernelGGL(se_bwd_weights_kernel, dim3((channels * squeezed + 255) / 256), dim3(256), 0, st, dz2, dz1, a, m, dw1,
+                     db1, dw2, db2, batch, channels, squeezed);
+  return check_launch("se_bwd");
+}

@@ -258,6 +258,40 @@ int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, 
 int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Backward of the train-mode EfficientNet pieces (csrc/train_bwd.hip).
+ *   ccvpe_bn_act_bwd_f32 : backward of ccvpe_bn_act_f32 (batch-statistics BN + activation [* dc_scale]).
+ *       dv is the gradient w.r.t. the consumer's input; with gate/dmean ([batch][channels]) the SE product
+ *       and average-pool branches are folded in: du = dv*gate + dmean.  Writes dx (w.r.t. the raw conv
+ *       output), dgamma, dbeta.  scratch: 2*channels*batch*ccvpe_bn_bwd_nblk(rows_per_sample) floats.
+ *       The residual branch's gradient is dv itself.
+ *   ccvpe_se_dgate_f32   : partial sums [batch][ccvpe_bn_bwd_nblk()][channels] of dv * u, u = act(bn(x)).
+ *   ccvpe_se_bwd_f32     : the two SE 1x1 convs; consumes the forward squeeze partials and the dgate partials,
+ *       writes dmean [batch][channels] (already / HW), dw1 [Cs][C], db1, dw2 [C][Cs], db2.
+ *       scratch: 2*batch*(channels+squeezed) floats.
+ *   ccvpe_dwconv_dgrad_f32 / ccvpe_dwconv_wgrad_f32 : depthwise conv input / weight gradients (dw [k][k][C]);
+ *       wgrad scratch: batch*ccvpe_dwconv_wgrad_nblk()*k*k*channels floats.
+ *   ccvpe_relu_bwd_f32   : dx = dy * (y > 0).
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_bn_bwd_nblk(int rows_per_sample);
+int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float* mean, const float* var, const float* gamma,
+                         const float* beta, const float* gate, const float* dmean, const float* dc_scale, float eps,
+                         int act, float* dx, float* dgamma, float* dbeta, float* scratch, int batch,
+                         int rows_per_sample, int channels, void* stream);
+int ccvpe_se_dgate_f32(const float* x, const float* dv, const float* mean, const float* var, const float* gamma,
+                       const float* beta, float eps, int act, float* part, int batch, int rows_per_sample,
+                       int channels, void* stream);
+int ccvpe_se_bwd_f32(const float* se_partial, int nblk, float inv_hw, const float* dgate_partial, int ndg,
+                     const float* w1, const float* b1, const float* w2t, const float* b2, float* dmean, float* dw1,
+                     float* db1, float* dw2, float* db2, float* scratch, int batch, int channels, int squeezed,
+                     void* stream);
+int ccvpe_dwconv_dgrad_f32(const float* dy, const float* w, float* dx, int batch, int in_h, int in_w, int channels,
+                           int k, int stride, int circular, void* stream);
+int ccvpe_dwconv_wgrad_nblk(int in_h, int in_w, int k, int stride);
+int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw, float* scratch, int batch, int in_h, int in_w,
+                           int channels, int k, int stride, int circular, void* stream);
+int ccvpe_relu_bwd_f32(const float* y, const float* dy, float* dx, int n_elems, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers

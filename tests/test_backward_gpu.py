@@ -72,3 +72,101 @@ def test_deconv_backward_vs_autograd(bw, cin, cout, h):
     dyd = nhwc(dy).cuda()
     close(bw.deconv_wgrad(nhwc(x.detach()).cuda(), dyd), wt.grad, 2e-4, "deconv wgrad")
     close(bw.deconv_dgrad(dyd, wt.detach().cuda()).permute(0, 3, 1, 2), x.grad, 2e-4, "deconv dgrad")
+
+
+# ---- EfficientNet train-mode backward pieces --------------------------------------------------------------
+
+def _act(z, act):
+    return z * torch.sigmoid(z) if act == 2 else (torch.relu(z) if act == 1 else z)
+
+
+@pytest.mark.parametrize("c,h,w,act,with_se,with_dcs", [(32, 20, 24, 2, True, False), (96, 9, 7, 2, False, True),
+                                                        (40, 5, 6, 0, False, True), (1152, 3, 4, 2, True, False),
+                                                        (16, 33, 17, 1, False, False)])
+def test_bn_act_bwd_vs_autograd(bw, c, h, w, act, with_se, with_dcs):
+    from ccvpe_amd import ops
+    b, eps = 4, 1e-3
+    x = synth.normal((b, h, w, c), 900 + c).double().requires_grad_(True)
+    gamma = (1.0 + 0.3 * synth.normal((c,), 901)).double().requires_grad_(True)
+    beta = (0.2 * synth.normal((c,), 902)).double().requires_grad_(True)
+    gate = torch.sigmoid(synth.normal((b, c), 903)).double().requires_grad_(True) if with_se else None
+    dcs = (synth.uniform((b,), 904) > 0.3).double() / 0.7 if with_dcs else None
+    mean = x.mean(dim=(0, 1, 2))
+    var = x.var(dim=(0, 1, 2), unbiased=False)
+    u = _act((x - mean) / torch.sqrt(var + eps) * gamma + beta, act)
+    if dcs is not None:
+        u = u * dcs.view(b, 1, 1, 1)
+    if with_se:
+        pooled = u.mean(dim=(1, 2))                       # the squeeze branch: loss also depends on the mean
+        wm = synth.normal((b, c), 905).double()
+        v = u * gate.view(b, 1, 1, c)
+    else:
+        v = u
+    dv = synth.normal((b, h, w, c), 906).double()
+    loss = (v * dv).sum()
+    if with_se:
+        loss = loss + (pooled * wm).sum()
+    loss.backward()
+    xd = x.detach().float().cuda()
+    md, vd = mean.detach().float().cuda(), var.detach().float().cuda()
+    gd, bd = gamma.detach().float().cuda(), beta.detach().float().cuda()
+    dvd = dv.float().cuda()
+    gated = gate.detach().float().cuda() if with_se else None
+    dmean = (wm / (h * w)).float().cuda() if with_se else None
+    dcsd = dcs.float().cuda() if with_dcs else None
+    dx, dgamma, dbeta = bw.bn_act_bwd(xd, dvd, md, vd, gd, bd, eps, act, gated, dmean, dcsd)
+    close(dx, x.grad, 2e-4, "bn dx")
+    close(dgamma, gamma.grad, 2e-4, "dgamma")
+    close(dbeta, beta.grad, 2e-4, "dbeta")
+    if with_se:
+        part = bw.se_dgate_partials(xd, dvd, md, vd, gd, bd, eps, act)
+        close(part.sum(dim=1), gate.grad, 2e-4, "dgate")
+
+
+@pytest.mark.parametrize("c,k,stride,h,w,circ", [(32, 3, 1, 12, 16, True), (96, 3, 2, 16, 20, True),
+                                                 (144, 5, 2, 10, 14, False), (240, 5, 1, 7, 9, True),
+                                                 (1152, 3, 1, 4, 4, False), (672, 5, 2, 8, 8, True)])
+def test_dwconv_backward_vs_autograd(bw, c, k, stride, h, w, circ):
+    from oracle import ccvpe_oracle as orc
+    b = 3
+    x = synth.normal((b, c, h, w), 910 + c).requires_grad_(True)
+    wt = synth.normal((c, 1, k, k), 911, 0.3).requires_grad_(True)
+    y = orc.same_conv(x, wt, k, stride, 224, circ, groups=c)
+    dy = synth.normal(tuple(y.shape), 912)
+    y.backward(dy)
+    wp = wt.detach().reshape(c, k * k).t().contiguous().cuda()         # [k*k][C]
+    dyd, xd = nhwc(dy).cuda(), nhwc(x.detach()).cuda()
+    close(bw.dwconv_dgrad(dyd, wp, h, w, k, stride, circ), nhwc(x.grad), 2e-4, "dw dgrad")
+    close(bw.dwconv_wgrad(xd, dyd, k, stride, circ), wt.grad.reshape(c, k * k).t(), 2e-4, "dw wgrad")
+
+
+@pytest.mark.parametrize("c,cs,hw", [(32, 8, 100), (1152, 48, 12), (96, 4, 35)])
+def test_se_bwd_vs_autograd(bw, c, cs, hw):
+    b = 5
+    u = synth.normal((b, hw, c), 920 + c).double()
+    w1 = synth.normal((cs, c), 921, c ** -0.5).double().requires_grad_(True)
+    b1 = synth.normal((cs,), 922, 0.1).double().requires_grad_(True)
+    w2 = synth.normal((c, cs), 923, cs ** -0.5).double().requires_grad_(True)
+    b2 = synth.normal((c,), 924, 0.1).double().requires_grad_(True)
+    m = u.mean(dim=1).requires_grad_(True)
+    z1 = m @ w1.t() + b1
+    gate = torch.sigmoid((z1 * torch.sigmoid(z1)) @ w2.t() + b2)
+    dgate = synth.normal((b, c), 925).double()
+    (gate * dgate).sum().backward()
+    # forward squeeze partials in 3 chunks, dgate partials in 2
+    chunks = [u[:, i::3].sum(dim=1) for i in range(3)]
+    sep = torch.stack(chunks, dim=1).float().cuda()
+    dgp = torch.stack([0.25 * dgate, 0.75 * dgate], dim=1).float().cuda()
+    dmean, dw1, db1, dw2, db2 = bw.se_bwd(sep, hw, dgp, w1.detach().float().cuda(), b1.detach().float().cuda(),
+                                          w2.detach().t().contiguous().float().cuda(), b2.detach().float().cuda())
+    close(dmean, m.grad / hw, 2e-4, "dmean")
+    close(dw1, w1.grad, 2e-4, "dw1")
+    close(db1, b1.grad, 2e-4, "db1")
+    close(dw2, w2.grad, 2e-4, "dw2")
+    close(db2, b2.grad, 2e-4, "db2")
+
+
+def test_relu_bwd(bw):
+    y = torch.relu(synth.normal((2, 5, 6, 16), 930))
+    dy = synth.normal((2, 5, 6, 16), 931)
+    close(bw.relu_bwd(y.cuda(), dy.cuda()), dy * (y > 0), 1e-7, "relu bwd")
