@@ -87,6 +87,18 @@ PROTOTYPES = {
     "ccvpe_dwconv_wgrad_nblk": (c_int, [c_int] * 4),
     "ccvpe_dwconv_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "ccvpe_relu_bwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),
+    "ccvpe_softmax_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
+    "ccvpe_l2norm2_bwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
+    "ccvpe_head_conv3x3_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    "ccvpe_ground_descriptor_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(c_int)] + [c_void_p] * 4 +
+                                        [c_int] * 3 + [c_void_p]),
+    "ccvpe_add_cols_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "ccvpe_stem_wgrad_nblk": (c_int, [c_int] * 3),
+    "ccvpe_stem_conv_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
+    "ccvpe_match_bwd_nblk": (c_int, [c_int]),
+    "ccvpe_match_level_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int,
+                                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                          c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ccvpe_conv_igemm_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "ccvpe_stem_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

@@ -177,3 +177,106 @@ def relu_bwd(y, dy):
     dx = torch.empty_like(dy)
     check(lib.ccvpe_relu_bwd_f32(ops._ptr(y), ops._ptr(dy), ops._ptr(dx), dy.numel(), ops._stream()), "ccvpe_relu_bwd_f32")
     return dx
+
+
+# ---- heads / glue (csrc/heads_bwd.hip, csrc/matching_bwd.hip) --------------------------------------------
+
+HEAD_BWD_SCRATCH = (1024 + 1) * 2 * 145       # CCVPE_HEAD_BWD_SCRATCH
+
+
+def softmax_bwd(heatmap, dheatmap, dlogits_direct=None):
+    lib = _lib.load()
+    for t, nm in ((heatmap, "heatmap"), (dheatmap, "dheatmap"), (dlogits_direct, "dlogits_direct")):
+        ops._chk(t, nm)
+    rows, n = heatmap.shape
+    out = torch.empty_like(heatmap)
+    check(lib.ccvpe_softmax_bwd_f32(ops._ptr(heatmap), ops._ptr(dheatmap), ops._ptr(dlogits_direct), ops._ptr(out), rows, n,
+                                    ops._stream()), "ccvpe_softmax_bwd_f32")
+    return out
+
+
+def l2norm2_bwd(raw, dout):
+    lib = _lib.load()
+    ops._chk(raw, "raw")
+    ops._chk(dout, "dout")
+    b = raw.shape[0]
+    hw = raw.numel() // (2 * b)
+    out = torch.empty_like(raw)
+    check(lib.ccvpe_l2norm2_bwd_f32(ops._ptr(raw), ops._ptr(dout), ops._ptr(out), b, hw, ops._stream()),
+          "ccvpe_l2norm2_bwd_f32")
+    return out
+
+
+def head_conv3x3_bwd(x, w, dout):
+    """x [B,H,W,16], w [cout,3,3,16] packed, dout [B,cout,H,W] -> (dx, dw [cout,3,3,16], dbias [cout])."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (w, "w"), (dout, "dout")):
+        ops._chk(t, nm)
+    b, h, wd, _ = x.shape
+    cout = dout.shape[1]
+    dx = torch.empty_like(x)
+    dw = torch.empty((cout, 3, 3, 16), device=x.device, dtype=torch.float32)
+    db = torch.empty((cout,), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((HEAD_BWD_SCRATCH,), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_head_conv3x3_bwd_f32(ops._ptr(x), ops._ptr(w), ops._ptr(dout), ops._ptr(dx), ops._ptr(dw), ops._ptr(db),
+                                         ops._ptr(scratch), b, h, wd, cout, ops._stream()), "ccvpe_head_conv3x3_bwd_f32")
+    return dx, dw, db
+
+
+def ground_descriptor_bwd(y1, wh, cd, dout):
+    """-> (dy1 [B,h,w,ld], dwh [6,h], dbh [6])."""
+    lib = _lib.load()
+    for t, nm in ((y1, "y1"), (wh, "wh"), (dout, "dout")):
+        ops._chk(t, nm)
+    b, h, w, ld = y1.shape
+    cd_arr = (ctypes.c_int * 6)(*cd)
+    dy1 = torch.empty_like(y1)
+    dwh = torch.empty((6, h), device=y1.device, dtype=torch.float32)
+    dbh = torch.empty((6,), device=y1.device, dtype=torch.float32)
+    check(lib.ccvpe_ground_descriptor_bwd_f32(ops._ptr(y1), ld, ops._ptr(wh), cd_arr, ops._ptr(dout), ops._ptr(dy1),
+                                              ops._ptr(dwh), ops._ptr(dbh), b, h, w, ops._stream()),
+          "ccvpe_ground_descriptor_bwd_f32")
+    return dy1, dwh, dbh
+
+
+def add_cols(src, col_off, channels, dst, accumulate=True):
+    """dst[..., :channels] (+)= src[..., col_off:col_off+channels] (both NHWC, any pixel strides)."""
+    lib = _lib.load()
+    ops._chk(src, "src")
+    ops._chk(dst, "dst")
+    rows = src.numel() // src.shape[-1]
+    check(lib.ccvpe_add_cols_f32(ops._ptr(src), src.shape[-1], col_off, ops._ptr(dst), dst.shape[-1], channels, rows,
+                                 int(bool(accumulate)), ops._stream()), "ccvpe_add_cols_f32")
+    return dst
+
+
+def stem_conv_wgrad(img, dy, circular):
+    """img [B,3,H,W] NCHW, dy [B,H/2,W/2,32] -> dw in the packed layout [3,3,3,32] (ky,kx,ci,co)."""
+    lib = _lib.load()
+    ops._chk(img, "img")
+    ops._chk(dy, "dy")
+    b, _, h, w = img.shape
+    scratch = torch.empty((864 * lib.ccvpe_stem_wgrad_nblk(b, h, w),), device=img.device, dtype=torch.float32)
+    dw = torch.empty((3, 3, 3, 32), device=img.device, dtype=torch.float32)
+    check(lib.ccvpe_stem_conv_wgrad_f32(ops._ptr(img), ops._ptr(dy), ops._ptr(dw), ops._ptr(scratch), b, h, w,
+                                        int(bool(circular)), ops._stream()), "ccvpe_stem_conv_wgrad_f32")
+    return dw
+
+
+def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, ddst, channels, dg_out):
+    """Backward of ops.match_level.  x [B,H,W,ldx]; g [B,ldg] view; scores/dscores [B,n,H,W]; ddst [B,H,W,ldo];
+    dg_out [B,ldg'] view that receives dg (first L entries per row).  Returns dx [B,H,W,channels]."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (scores, "scores"), (dscores, "dscores"), (ddst, "ddst")):
+        ops._chk(t, nm)
+    b, h, w, ldx = x.shape
+    hw = h * w
+    n = len(shifts)
+    sh = (ctypes.c_int * n)(*shifts)
+    dx = torch.empty((b, h, w, channels), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((b * lib.ccvpe_match_bwd_nblk(hw) * (L + 1),), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_match_level_bwd_f32(ops._ptr(x), ldx, ops._ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride,
+                                        ops._ptr(scores), ops._ptr(dscores), ops._ptr(ddst), ddst.shape[-1], ops._ptr(dx),
+                                        channels, ops._ptr(dg_out), dg_out.stride(0), ops._ptr(scratch), b, hw, channels,
+                                        ops._stream()), "ccvpe_match_level_bwd_f32")
+    return dx

@@ -1,0 +1,286 @@
+// Backward of the fused rotational matching + LMU concat (csrc/matching.hip; models.py:186-205 ...).
+// Forward per pixel p of sample b (gg / ww = doubled descriptor / window tables, off_i = (-shift_i*stride) mod C):
+//     num_i = sum_c x[c] gg[c+off_i] ;  n_i^2 = sum_c x[c]^2 ww[c+off_i] ;  s_i = num_i / (n_i G),  G = ||g||
+//     dst[0:C] = x / max(||x||, 1e-12) ; dst[C] = max_{i<n_max} s_i ; dst[C+1+j] = s_{n-n_tail+j}
+// Backward, with ds_i = dscores_i + [i == argmax] ddst[C] + [i >= n-n_tail] ddst[C+1+i-(n-n_tail)]:
+//     a_i = ds_i / (n_i G),  b_i = ds_i s_i / n_i^2
+//     dx[c]  = normalize_bwd(ddst[0:C])[c] + sum_i ( a_i gg[c+off_i] - b_i x[c] ww[c+off_i] )
+//     dg[k]  = sum_p sum_i a_i x[c : (c+off_i) mod C == k]  -  g[k]/G^2 * sum_p sum_i ds_i s_i
+// Same mapping as the forward (lane = pixel, 32-channel tiles transposed through LDS, wave-uniform LDS
+// broadcasts of the tables).  dg is a reduction over pixels: every (channel, shift) term is summed across
+// the wave with a butterfly and accumulated by lane 0 into a per-wave LDS vector; the workgroup writes
+// one partial row [L+1] and a finishing kernel reduces the rows in fixed order (deterministic).
+#include "common.h"
+
+namespace ccvpe {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MatchOffsetsB {
+  int off[CCVPE_MAX_SHIFTS];
+};
+
+constexpr int MBK = 32;
+
+template <int NPAD>
+__global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
+                                                        int ldg, int L, const MatchOffsetsB mo, int n_shifts, int n_max,
+                                                        int n_tail, const float* __restrict__ scores,
+                                                        const float* __restrict__ dscores, const float* __restrict__ ddst,
+                                                        int ldo, float* __restrict__ dx, int lddx,
+                                                        float* __restrict__ part, int nblk, int hw, int C) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int TPB = blockDim.x;
+  const int XLD = TPB + 1;
+  const int NW = TPB >> 6;
+  float* gg = sm;                       // [2C]
+  float* ww = gg + 2 * C;               // [2C]
+  float* xs = ww + 2 * C;               // [MBK][XLD]
+  float* dd = xs + MBK * XLD;           // [MBK][XLD]
+  float* dgw = dd + MBK * XLD;          // [NW][L+1]
+  float* red = dgw + NW * (L + 1);      // [4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * TPB;
+  const int p = p0 + tid;
+  const bool pvalid = p < hw;
+  const bool partial = L < C;
+  const float* xb = x + (size_t)b * hw * ldx;
+  const float* db = ddst + (size_t)b * hw * ldo;
+
+  float gsq = 0.f;
+  for (int k = tid; k < 2 * C; k += TPB) {
+    const int kk = k < C ? k : k - C;
+    const float v = kk < L ? g[(size_t)b * ldg + kk] : 0.f;
+    gg[k] = v;
+    ww[k] = kk < L ? 1.f : 0.f;
+    if (k < C) gsq = fmaf(v, v, gsq);
+  }
+  for (int k = tid; k < NW * (L + 1); k += TPB) dgw[k] = 0.f;
+  gsq = wave_sum(gsq);
+  if (lane == 0) red[wv] = gsq;
+  __syncthreads();
+  float gnorm = 0.f;
+  for (int i = 0; i < NW; ++i) gnorm += red[i];
+  gnorm = sqrtf(gnorm);
+
+  // ---- pass A: ||x||^2, <x, ddst[0:C]>, window norms ------------------------------------------------
+  float nrm[NPAD];
+#pragma unroll
+  for (int i = 0; i < NPAD; ++i) nrm[i] = 0.f;
+  float tot = 0.f, xd = 0.f;
+  constexpr int F4 = MBK / 4;
+  for (int c0 = 0; c0 < C; c0 += MBK) {
+    const int ck = min(MBK, C - c0);
+    for (int idx = tid; idx < TPB * F4; idx += TPB) {
+      const int pp = idx / F4;
+      const int cq = (idx - pp * F4) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+      if (p0 + pp < hw && cq < ck) {
+        v = *reinterpret_cast<const f32x4*>(xb + (size_t)(p0 + pp) * ldx + c0 + cq);
+        d = *reinterpret_cast<const f32x4*>(db + (size_t)(p0 + pp) * ldo + c0 + cq);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xs[(cq + j) * XLD + pp] = v[j];
+        dd[(cq + j) * XLD + pp] = d[j];
+      }
+    }
+    __syncthreads();
+    for (int cc = 0; cc < ck; ++cc) {
+      const float xv = xs[cc * XLD + tid];
+      const float x2 = xv * xv;
+      tot += x2;
+      xd = fmaf(xv, dd[cc * XLD + tid], xd);
+      if (partial) {
+#pragma unroll
+        for (int i = 0; i < NPAD; ++i)
+          if (i < n_shifts) nrm[i] = fmaf(x2, ww[c0 + cc + mo.off[i]], nrm[i]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- per-pixel coefficients ---------------------------------------------------------------------------
+  float a[NPAD], bq[NPAD];
+  float T = 0.f;
+  {
+    const int tail0 = n_shifts - n_tail;
+    int amax = 0;
+    float mx = 0.f;
+    if (pvalid) {
+#pragma unroll
+      for (int i = 0; i < NPAD; ++i) {
+        if (i < n_max) {
+          const float s = scores[((size_t)b * n_shifts + i) * hw + p];
+          if (i == 0) mx = s;
+          else if (s > mx || s != s) { mx = s; amax = i; }
+        }
+      }
+    }
+    const float* drow = db + (size_t)p * ldo;
+#pragma unroll
+    for (int i = 0; i < NPAD; ++i) {
+      a[i] = 0.f;
+      bq[i] = 0.f;
+      if (i < n_shifts && pvalid) {
+        const float s = scores[((size_t)b * n_shifts + i) * hw + p];
+        float ds = dscores ? dscores[((size_t)b * n_shifts + i) * hw + p] : 0.f;
+        if (i == amax) ds += drow[C];
+        if (i >= tail0) ds += drow[C + 1 + (i - tail0)];
+        const float n2 = partial ? nrm[i] : tot;
+        a[i] = ds / (sqrtf(n2) * gnorm);
+        bq[i] = ds * s / n2;
+        T = fmaf(ds, s, T);
+      }
+    }
+  }
+  const float xn = sqrtf(tot);
+  const float k1 = 1.0f / fmaxf(xn, 1e-12f);
+  const float k2 = xn > 1e-12f ? xd * k1 * k1 * k1 : 0.f;
+
+  // ---- pass B: dx and the dg partials -------------------------------------------------------------------
+  for (int c0 = 0; c0 < C; c0 += MBK) {
+    const int ck = min(MBK, C - c0);
+    for (int idx = tid; idx < TPB * F4; idx += TPB) {
+      const int pp = idx / F4;
+      const int cq = (idx - pp * F4) * 4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f}, d = {0.f, 0.f, 0.f, 0.f};
+      if (p0 + pp < hw && cq < ck) {
+        v = *reinterpret_cast<const f32x4*>(xb + (size_t)(p0 + pp) * ldx + c0 + cq);
+        d = *reinterpret_cast<const f32x4*>(db + (size_t)(p0 + pp) * ldo + c0 + cq);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        xs[(cq + j) * XLD + pp] = v[j];
+        dd[(cq + j) * XLD + pp] = d[j];
+      }
+    }
+    __syncthreads();
+    for (int cc = 0; cc < ck; ++cc) {
+      const float xv = xs[cc * XLD + tid];
+      float acc = pvalid ? dd[cc * XLD + tid] * k1 - xv * k2 : 0.f;
+#pragma unroll
+      for (int i = 0; i < NPAD; ++i) {
+        if (i < n_shifts) {
+          const int k = c0 + cc + mo.off[i];
+          const int kk = k >= C ? k - C : k;
+          if (kk < L) {
+            acc = fmaf(a[i], gg[k], acc);
+            acc = fmaf(-bq[i], xv, acc);
+            const float s = wave_sum(a[i] * xv);
+            if (lane == 0) dgw[wv * (L + 1) + kk] += s;
+          }
+        }
+      }
+      dd[cc * XLD + tid] = acc;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < TPB * F4; idx += TPB) {
+      const int pp = idx / F4;
+      const int cq = (idx - pp * F4) * 4;
+      if (p0 + pp < hw && cq < ck) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = dd[(cq + j) * XLD + pp];
+        *reinterpret_cast<f32x4*>(dx + ((size_t)b * hw + p0 + pp) * lddx + c0 + cq) = o;
+      }
+    }
+    __syncthreads();
+  }
+  T = wave_sum(T);
+  if (lane == 0) dgw[wv * (L + 1) + L] = T;
+  __syncthreads();
+  float* out = part + ((size_t)b * nblk + blockIdx.x) * (L + 1);
+  for (int k = tid; k <= L; k += TPB) {
+    float s = 0.f;
+    for (int w = 0; w < NW; ++w) s += dgw[w * (L + 1) + k];
+    out[k] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void match_dg_finish_kernel(const float* __restrict__ part, int nblk,
+                                                              const float* __restrict__ g, int ldg, int L,
+                                                              float* __restrict__ dg, int ldg_out) {
+  __shared__ float red[4];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  float gsq = 0.f;
+  for (int k = tid; k < L; k += 256) {
+    const float v = g[(size_t)b * ldg + k];
+    gsq = fmaf(v, v, gsq);
+  }
+  gsq = wave_sum(gsq);
+  if ((tid & 63) == 0) red[tid >> 6] = gsq;
+  __syncthreads();
+  const float g2 = red[0] + red[1] + red[2] + red[3];
+  const float* pb = part + (size_t)b * nblk * (L + 1);
+  float T = 0.f;
+  for (int q = 0; q < nblk; ++q) T += pb[(size_t)q * (L + 1) + L];
+  for (int k = tid; k < L; k += 256) {
+    float s = 0.f;
+    for (int q = 0; q < nblk; ++q) s += pb[(size_t)q * (L + 1) + k];
+    dg[(size_t)b * ldg_out + k] = s - T * g[(size_t)b * ldg + k] / g2;
+  }
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+static int match_bwd_tpb(int hw) { return hw >= 256 ? 256 : ((hw + 63) / 64) * 64; }
+
+extern "C" int ccvpe_match_bwd_nblk(int hw) {
+  const int tpb = match_bwd_tpb(hw);
+  return (hw + tpb - 1) / tpb;
+}
+
+template <int NPAD>
+static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, int L, const MatchOffsetsB& mo, int n_shifts,
+                            int n_max, int n_tail, const float* scores, const float* dscores, const float* ddst, int ldo,
+                            float* dx, int lddx, float* part, int B, int hw, int C, hipStream_t st) {
+  const int tpb = match_bwd_tpb(hw);
+  const int nblk = (hw + tpb - 1) / tpb;
+  const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 1) + (size_t)(tpb / 64) * (L + 1) + 4);
+  if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level_bwd: C=%d needs %zu B of LDS", C, smem);
+  auto kern = match_bwd_kernel<NPAD>;
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "match_level_bwd: set smem attr: %s", hipGetErrorString(e));
+  }
+  hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(tpb), smem, st, x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores,
+                     dscores, ddst, ldo, dx, lddx, part, nblk, hw, C);
+  return check_launch("match_bwd_kernel");
+}
+
+extern "C" int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
+                                         int n_shifts, int n_max, int n_tail, int stride, const float* scores,
+                                         const float* dscores, const float* ddst, int ldo, float* dx, int lddx, float* dg,
+                                         int ldg_out, float* scratch, int B, int hw, int C, void* stream) {
+  if (n_shifts < 1 || n_shifts > CCVPE_MAX_SHIFTS) return fail(CCVPE_EINVAL, "match_level_bwd: n_shifts %d out of range", n_shifts);
+  if (n_max < 1 || n_max > n_shifts || n_tail < 0 || n_tail > n_shifts) return fail(CCVPE_EINVAL, "match_level_bwd: bad n_max/n_tail");
+  if (C % 8 || ldx % 4 || ldo % 4 || lddx % 4 || ldo < C + 1 + n_tail || lddx < C)
+    return fail(CCVPE_EINVAL, "match_level_bwd: C%%8, ldx%%4, ldo%%4, lddx%%4, ldo>=C+1+n_tail required");
+  if (L < 1 || L > C || L > ldg || L > ldg_out) return fail(CCVPE_EINVAL, "match_level_bwd: bad L");
+  if (!aligned16(x) || !aligned16(ddst) || !aligned16(dx)) return fail(CCVPE_EINVAL, "match_level_bwd: 16-byte alignment");
+  MatchOffsetsB mo;
+  for (int i = 0; i < CCVPE_MAX_SHIFTS; ++i) {
+    long o = 0;
+    if (i < n_shifts) {
+      o = (-(long)shifts[i] * stride) % C;
+      if (o < 0) o += C;
+    }
+    mo.off[i] = (int)o;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int rc;
+  if (n_shifts <= 8)
+    rc = launch_match_bwd<8>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
+  else if (n_shifts <= 24)
+    rc = launch_match_bwd<24>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
+  else
+    rc = launch_match_bwd<48>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(match_dg_finish_kernel, dim3(B), dim3(256), 0, st, scratch, ccvpe_match_bwd_nblk(hw), g, ldg, L, dg, ldg_out);
+  return check_launch("match_dg_finish_kernel");
+}

@@ -292,6 +292,44 @@ int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw, float* sc
 int ccvpe_relu_bwd_f32(const float* y, const float* dy, float* dx, int n_elems, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Backward of the head / glue operators (csrc/heads_bwd.hip, csrc/matching_bwd.hip).
+ *   ccvpe_softmax_bwd_f32   : dlogits = heatmap * (dheatmap - <heatmap, dheatmap>) [+ dlogits_direct]  (models.py:320)
+ *   ccvpe_l2norm2_bwd_f32   : backward of F.normalize over the (cos, sin) pair (models.py:341); raw [B,2,HW]
+ *   ccvpe_head_conv3x3_bwd_f32 : backward of ccvpe_head_conv3x3_f32 with normalize = 0: x [B,H,W,16] NHWC,
+ *       dout [B,cout,H,W]; writes dx [B,H,W,16], dw [cout][3][3][16], dbias [cout].
+ *       scratch: CCVPE_HEAD_BWD_SCRATCH floats.
+ *   ccvpe_ground_descriptor_bwd_f32 : backward of ccvpe_ground_descriptor_f32: dout [B][w*sum(cd)] ->
+ *       dy1 [B,h,w,ld] (pad columns zeroed), dwh [6][h], dbh [6].
+ *   ccvpe_add_cols_f32      : dst[row, 0:channels] (+)= src[row, col_off : col_off+channels]  (skip-connection
+ *       gradients are column slices of the decoder convs' input gradients).
+ *   ccvpe_stem_conv_wgrad_f32 : stem weight gradient dw [3][3][3][32]; scratch: 864 * ccvpe_stem_wgrad_nblk() floats.
+ *   ccvpe_match_level_bwd_f32 : backward of ccvpe_match_level_f32.  scores = the forward's scores; dscores
+ *       [B,n_shifts,HW] (may be NULL) is the gradient arriving at the returned score volume, ddst [B,HW,ldo]
+ *       the gradient arriving at dstx (normalised features, max column, tail columns).  Writes dx [B,HW,lddx]
+ *       (first `channels` columns) and dg [B,ldg_out] (first L entries).  The max routes its gradient to the
+ *       first maximal shift, as torch.max does.  scratch: batch * ccvpe_match_bwd_nblk(hw) * (L+1) floats.
+ * ----------------------------------------------------------------------------------------- */
+#define CCVPE_HEAD_WGRAD_BLOCKS 1024
+#define CCVPE_HEAD_BWD_SCRATCH ((CCVPE_HEAD_WGRAD_BLOCKS + 1) * 2 * 145)
+int ccvpe_softmax_bwd_f32(const float* heatmap, const float* dheatmap, const float* dlogits_direct, float* dlogits,
+                          int rows, int n, void* stream);
+int ccvpe_l2norm2_bwd_f32(const float* raw, const float* dout, float* draw, int batch, int hw, void* stream);
+int ccvpe_head_conv3x3_bwd_f32(const float* x, const float* w, const float* dout, float* dx, float* dw, float* dbias,
+                               float* scratch, int batch, int h, int wd, int cout, void* stream);
+int ccvpe_ground_descriptor_bwd_f32(const float* y1, int ld, const float* wh, const int* cd, const float* dout,
+                                    float* dy1, float* dwh, float* dbh, int batch, int h, int w, void* stream);
+int ccvpe_add_cols_f32(const float* src, int ld_src, int col_off, float* dst, int ld_dst, int channels, int rows,
+                       int accumulate, void* stream);
+int ccvpe_stem_wgrad_nblk(int batch, int in_h, int in_w);
+int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, float* dw, float* scratch, int batch, int in_h,
+                              int in_w, int circular, void* stream);
+int ccvpe_match_bwd_nblk(int hw);
+int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts,
+                              int n_max, int n_tail, int stride, const float* scores, const float* dscores,
+                              const float* ddst, int ldo, float* dx, int lddx, float* dg, int ldg_out, float* scratch,
+                              int batch, int hw, int channels, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers

@@ -170,3 +170,111 @@ def test_relu_bwd(bw):
     y = torch.relu(synth.normal((2, 5, 6, 16), 930))
     dy = synth.normal((2, 5, 6, 16), 931)
     close(bw.relu_bwd(y.cuda(), dy.cuda()), dy * (y > 0), 1e-7, "relu bwd")
+
+
+# ---- heads / glue backward ----------------------------------------------------------------------------------
+
+def test_softmax_bwd(bw):
+    logits = (3.0 * synth.normal((3, 4096), 940)).double().requires_grad_(True)
+    h = torch.softmax(logits, dim=1)
+    dh = synth.normal((3, 4096), 941).double()
+    dl = synth.normal((3, 4096), 942).double() * 1e-3
+    ((h * dh).sum() + (logits * dl).sum()).backward()
+    got = bw.softmax_bwd(h.detach().float().cuda(), dh.float().cuda(), dl.float().cuda())
+    close(got, logits.grad, 2e-5, "softmax bwd")
+
+
+@pytest.mark.parametrize("cout", [1, 2])
+def test_head_conv_bwd_vs_autograd(bw, cout):
+    b, h, w = 2, 37, 70
+    x = synth.normal((b, 16, h, w), 950).requires_grad_(True)
+    wt = synth.normal((cout, 16, 3, 3), 951, 0.1).requires_grad_(True)
+    bias = synth.normal((cout,), 952, 0.1).requires_grad_(True)
+    r = F.conv2d(x, wt, bias, padding=1)
+    out = F.normalize(r, p=2, dim=1) if cout == 2 else r
+    dout = synth.normal(tuple(out.shape), 953)
+    out.backward(dout)
+    xd = nhwc(x.detach()).cuda()
+    wp = wt.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    dr = dout.cuda()
+    if cout == 2:
+        dr = bw.l2norm2_bwd(r.detach().cuda(), dr)
+    dx, dw, db = bw.head_conv3x3_bwd(xd, wp, dr)
+    close(dx, nhwc(x.grad), 2e-4, "head dx")
+    close(dw, wt.grad.permute(0, 2, 3, 1), 2e-4, "head dw")
+    close(db, bias.grad, 2e-4, "head dbias")
+
+
+def test_ground_descriptor_bwd(bw):
+    from ccvpe_amd import ops
+    cd = (8, 4, 4, 4, 2, 2)
+    b, h, w, ld = 2, 5, 10, 24
+    y1 = synth.normal((b, h, w, ld), 960).double().requires_grad_(True)
+    wh = synth.normal((6, h), 961).double().requires_grad_(True)
+    bh = synth.normal((6,), 962).double().requires_grad_(True)
+    outs, off = [], 0
+    for l in range(6):
+        d = torch.einsum("y,byxc->bxc", wh[l], y1[..., off:off + cd[l]]) + bh[l]
+        outs.append(d.reshape(b, -1))
+        off += cd[l]
+    out = torch.cat(outs, 1)
+    dout = synth.normal(tuple(out.shape), 963).double()
+    (out * dout).sum().backward()
+    got = ops.ground_descriptor(y1.detach().float().cuda(), wh.detach().float().cuda(), bh.detach().float().cuda(), cd)
+    close(got, out, 1e-5, "gdesc fwd")
+    dy1, dwh, dbh = bw.ground_descriptor_bwd(y1.detach().float().cuda(), wh.detach().float().cuda(), cd, dout.float().cuda())
+    close(dy1, y1.grad, 1e-5, "gdesc dy1")
+    close(dwh, wh.grad, 1e-5, "gdesc dwh")
+    close(dbh, bh.grad, 1e-5, "gdesc dbh")
+
+
+def test_add_cols(bw):
+    src = synth.normal((2, 3, 5, 24), 970)
+    dst = synth.normal((2, 3, 5, 8), 971)
+    want = dst + src[..., 12:20]
+    close(bw.add_cols(src.cuda(), 12, 8, dst.clone().cuda()), want, 1e-7, "add_cols")
+    close(bw.add_cols(src.cuda(), 4, 8, dst.clone().cuda(), accumulate=False), src[..., 4:12], 1e-7, "copy_cols")
+
+
+@pytest.mark.parametrize("circ", [True, False])
+def test_stem_wgrad(bw, circ):
+    from oracle import ccvpe_oracle as orc
+    x = synth.normal((2, 3, 32, 48), 980)
+    wt = synth.normal((32, 3, 3, 3), 981, 0.2).requires_grad_(True)
+    y = orc.same_conv(x, wt, 3, 2, 224, circ)
+    dy = synth.normal(tuple(y.shape), 982)
+    y.backward(dy)
+    got = bw.stem_conv_wgrad(x.cuda(), nhwc(dy).cuda(), circ)
+    close(got, wt.grad.permute(2, 3, 1, 0), 2e-4, "stem wgrad")
+
+
+@pytest.mark.parametrize("c,L,hw,shifts,n_max,n_tail,stride", [
+    (64, 64, 8, list(range(20)), 20, 20, 2),                 # level-6 style: full window, ori tail
+    (64, 64, 12, list(range(20)), 20, 0, 2),
+    (32, 20, 16, [-1, 0, 1], 3, 0, 4),                       # partial window (FoV < 360), ori_prior shifts
+    (128, 128, 5, [0] + list(range(20)), 1, 20, 4),          # ori_prior level 6: 1 loc shift + 20 recomputed
+    (16, 10, 40, list(range(16)), 16, 0, 8)])                # kitti-like, hw > 256 pixels per sample
+def test_match_level_bwd_vs_autograd(bw, c, L, hw, shifts, n_max, n_tail, stride):
+    from ccvpe_amd import ops
+    from oracle import ccvpe_oracle as orc
+    b = 2
+    n = len(shifts)
+    x = synth.normal((b, c, hw, hw), 990 + c).double().requires_grad_(True)
+    g = synth.normal((b, L), 991).double().requires_grad_(True)
+    sc = orc.rotational_matching(x, g, shifts, stride)                       # [B,n,H,W]
+    mx = sc[:, :n_max].max(dim=1, keepdim=True)[0]
+    xn = F.normalize(x, p=2, dim=1)
+    parts = [xn, mx] + ([sc[:, n - n_tail:]] if n_tail else [])
+    dst = torch.cat(parts, dim=1)                                            # our column order [X, max, tail]
+    ldo = ((c + 1 + n_tail + 7) // 8) * 8
+    dsc = synth.normal(tuple(sc.shape), 992).double()
+    ddst = synth.normal((b, hw, hw, ldo), 993).double()
+    ((sc * dsc).sum() + (nhwc(dst) * ddst[..., :dst.shape[1]]).sum()).backward()
+    xd = nhwc(x.detach().float()).cuda()
+    gd = g.detach().float().cuda()
+    scores, dstx = ops.match_level(xd, gd, L, shifts, n_max, n_tail, stride, ldo, channels=c)
+    close(scores, sc, 1e-5, "match fwd scores")
+    dg = torch.zeros((b, L + 3), device="cuda")
+    dx = bw.match_level_bwd(xd, gd, L, shifts, n_max, n_tail, stride, scores, dsc.float().cuda(), ddst.float().cuda(), c, dg)
+    close(dx, nhwc(x.grad), 2e-4, "match dx")
+    close(dg[:, :L], g.grad, 2e-4, "match dg")
