@@ -87,6 +87,7 @@ PROTOTYPES = {
     "ccvpe_dwconv_wgrad_nblk": (c_int, [c_int] * 4),
     "ccvpe_dwconv_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p]),
     "ccvpe_relu_bwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_void_p]),
+    "ccvpe_gate_mul_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "ccvpe_softmax_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_l2norm2_bwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
     "ccvpe_head_conv3x3_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),

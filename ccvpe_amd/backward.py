@@ -19,21 +19,23 @@ from ._lib import check
 from .models import _pack_conv, _pack_deconv
 
 
-def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None):
-    """d(conv2d)/d(weight) in the reference OIHW layout.  x0 [B,H,W,c0] (+ x1 [B,H,W,c1] concatenated),
-    dy [B,Ho,Wo,n]."""
+def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None):
+    """d(conv2d)/d(weight) in the reference OIHW layout.  x0 [B,H,W,ld0] (+ x1 [B,H,W,ld1] concatenated),
+    dy [B,Ho,Wo,ldy]; c0 / c1 select the first channels of wider pixel rows (default: all)."""
     lib = _lib.load()
     for t, nm in ((x0, "x0"), (x1, "x1"), (dy, "dy")):
         ops._chk(t, nm)
-    b, h, w, c0 = x0.shape
-    c1 = x1.shape[-1] if x1 is not None else 0
+    b, h, w, ld0 = x0.shape
+    ld1 = x1.shape[-1] if x1 is not None else 0
+    c0 = ld0 if c0 is None else c0
+    c1 = ld1 if c1 is None else c1
     ctot = c0 + c1
     nfl = lib.ccvpe_conv_wgrad_scratch_floats(b, h, w, kh, kw, stride, pad, ctot, n)
     if nfl <= 0:
         raise _lib.CcvpeError("ccvpe_conv_wgrad_scratch_floats rejected the shape")
     scratch = torch.empty((nfl,), device=x0.device, dtype=torch.float32)
     dw = torch.empty((n, kh * kw, ctot), device=x0.device, dtype=torch.float32)
-    check(lib.ccvpe_conv_wgrad_f32(ops._ptr(x0), c0, c0, ops._ptr(x1), c1, c1, ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
+    check(lib.ccvpe_conv_wgrad_f32(ops._ptr(x0), c0, ld0, ops._ptr(x1), c1, ld1, ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
                                    ops._ptr(scratch), b, h, w, kh, kw, stride, pad, n, ops._stream()),
           "ccvpe_conv_wgrad_f32")
     return dw.reshape(n, kh, kw, ctot).permute(0, 3, 1, 2)                 # OIHW view
@@ -280,3 +282,13 @@ def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, dds
                                         channels, ops._ptr(dg_out), dg_out.stride(0), ops._ptr(scratch), b, hw, channels,
                                         ops._stream()), "ccvpe_match_level_bwd_f32")
     return dx
+
+
+def gate_mul(u, gate):
+    lib = _lib.load()
+    ops._chk(u, "u")
+    ops._chk(gate, "gate")
+    b, rps, c = _bc(u)
+    v = torch.empty_like(u)
+    check(lib.ccvpe_gate_mul_f32(ops._ptr(u), ops._ptr(gate), ops._ptr(v), b, rps, c, ops._stream()), "ccvpe_gate_mul_f32")
+    return v

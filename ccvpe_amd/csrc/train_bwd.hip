@@ -576,3 +576,26 @@ extern "C" int ccvpe_se_bwd_f32(const float* se_partial, int nblk, float inv_hw,
                      db1, dw2, db2, batch, channels, squeezed);
   return check_launch("se_bwd");
 }
+
+// v[b,px,c] = u[b,px,c] * gate[b,c]: the SE product materialised (train mode only: the projection conv's
+// weight gradient needs the gated tensor; in eval the gate is applied inside the GEMM's operand load).
+namespace ccvpe {
+__global__ __launch_bounds__(256) void gate_mul_kernel(const float* __restrict__ u, const float* __restrict__ gate,
+                                                       float* __restrict__ v, long rows_per_sample, int C, long total4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int cg4 = C >> 2;
+  const int c = (int)(i % cg4) * 4;
+  const long b = (i / cg4) / rows_per_sample;
+  reinterpret_cast<f32x4*>(v)[i] = reinterpret_cast<const f32x4*>(u)[i] * *reinterpret_cast<const f32x4*>(gate + b * C + c);
+}
+}  // namespace ccvpe
+
+extern "C" int ccvpe_gate_mul_f32(const float* u, const float* gate, float* v, int batch, int rows_per_sample, int channels,
+                                  void* stream) {
+  if (batch <= 0 || rows_per_sample <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "gate_mul: bad shape");
+  const long total4 = (long)batch * rows_per_sample * (channels / 4);
+  hipLaunchKernelGGL(gate_mul_kernel, dim3((unsigned)((total4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, u, gate, v,
+                     (long)rows_per_sample, channels, total4);
+  return check_launch("gate_mul_kernel");
+}

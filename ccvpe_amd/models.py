@@ -14,8 +14,8 @@ BN folded to scale/shift, conv weights to [N][tap][C] K-major rows, deconv weigh
 [4*Cout][K] GEMM with the concat order this implementation uses — and every arithmetic step of
 forward() is a libccvpe_hip.so call (ccvpe_amd/ops.py).  There is no eager/CPU fallback.
 
-Scope this round: inference (eval-mode) forward.  Train-mode forward/backward (BN batch
-statistics, drop_connect, gradients) is not implemented yet and raises.
+Eval mode is the inference path (fp32 or bf16).  Train mode (fp32) lives in ccvpe_amd/train.py: batch-statistic
+BatchNorm, drop_connect and a full backward through the HIP backward kernels behind one autograd.Function.
 """
 import torch
 import torch.nn as nn
@@ -172,7 +172,7 @@ def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
     return out.to(dtype).contiguous(), shift9.float().contiguous()
 
 
-def _pack_model(sd, kind, n_tail, dtype=torch.float32):
+def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True):
     spec = MODEL_SPECS[kind]
     pk = _Obj()
     pk.dtype = dtype
@@ -212,7 +212,7 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32):
                                         [(0, 1, c), (c, 0, 1)], ldo, dtype)
         lv.c0, lv.c1 = dc_out, c_in - dc_out
         lv.n_a = c_out
-        if j in FOLD_LEVELS:
+        if fold and j in FOLD_LEVELS:
             lv.fw, lv.fshift = _pack_upconv(sd["deconv%d.weight" % lvl], sd["deconv%d.bias" % lvl],
                                             [(0, 1, c), (c, 0, 1)], ldo, sd["conv%d.0.weight" % lvl],
                                             sd["conv%d.0.bias" % lvl], dtype)
@@ -241,7 +241,7 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32):
                                             [(0, 0, dc_in)], dc_in, dtype)
         ov.up_n = 4 * dc_out
         ov.c0, ov.c1 = dc_out, c_in - dc_out
-        if j in FOLD_LEVELS:
+        if fold and j in FOLD_LEVELS:
             cmap = [(0, n_rot, c6), (c6 + 1, 0, n_rot)] if j == 0 else [(0, 0, dc_in)]
             ov.fw, ov.fshift = _pack_upconv(sd["deconv%d_ori.weight" % lvl], sd["deconv%d_ori.bias" % lvl], cmap,
                                             ov.k, sd["conv%d_ori.0.weight" % lvl], sd["conv%d_ori.0.bias" % lvl],
@@ -335,7 +335,7 @@ class _CVMBase(nn.Module):
         return tuple(key)
 
     def _packed(self):
-        key = (self.precision,) + self._weights_key()
+        key = (self.precision, self.training) + self._weights_key()
         if self._pack_cache is None or key != self._pack_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device
@@ -344,7 +344,8 @@ class _CVMBase(nn.Module):
             n_tail = MODEL_SPECS[self.kind]["n_rot"]
             dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
             with torch.no_grad():
-                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype)
+                # train mode runs the decoders unfused (ccvpe_amd/train.py): skip the fp64 fold of deconv into conv
+                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training)
             self._pack_key = key
         return self._pack_cache
 
@@ -388,58 +389,27 @@ class _CVMBase(nn.Module):
     drop_connect_rate = 0.2          # efficientnet_pytorch/utils.py:639 (GlobalParams default)
     BN_MOMENTUM = 0.01               # model.py:52
 
-    def _bn_train(self, live, name, x_raw, act, residual=None, dc_scale=None, want_se=False):
-        """BatchNorm2d in train mode through libccvpe_hip: batch statistics (+ in-place running-stat
-        update of the module's own buffers), then normalise/activate."""
-        mean, var = ops.bn_stats(x_raw, live[name + ".running_mean"], live[name + ".running_var"], self.BN_MOMENTUM)
-        live[name + ".num_batches_tracked"].add_(1)
-        return ops.bn_act(x_raw, mean, var, live[name + ".weight"].detach(), live[name + ".bias"].detach(), BN_EPS,
-                          act, residual=residual, dc_scale=dc_scale, want_se=want_se)
-
-    def _run_encoder_train(self, e, live, prefix, img, circular, multiscale, drop_masks):
-        """EfficientNet.extract_features[_multiscale] with self.training == True (model.py:278-326):
-        BN uses batch statistics, skip blocks apply drop_connect with rate 0.2*idx/16 (model.py:293-296)."""
-        x = self._bn_train(live, prefix + "._bn0", ops.stem_conv_raw(img, e.stem_w, circular), ops.ACT_SWISH)
-        feats = []
-        for i, blk in enumerate(e.blocks):
-            bp = "%s._blocks.%d" % (prefix, i)
-            b, h, w, _ = x.shape
-            t = x
-            if blk.expand:
-                t = self._bn_train(live, bp + "._bn0",
-                                   ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w), ops.ACT_SWISH)
-            u_raw = ops.dwconv_raw(t, blk.w_dw, blk.k, blk.s, circular)
-            u, part = self._bn_train(live, bp + "._bn1", u_raw, ops.ACT_SWISH, want_se=True)
-            ho, wo = u.shape[1], u.shape[2]
-            gate = ops.se_gate(part, ho * wo, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
-            p_raw = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate)
-            dc = None
-            rate = self.drop_connect_rate * float(i) / len(e.blocks)            # model.py:293-295
-            if blk.skip and rate:
-                keep = 1.0 - rate
-                if drop_masks is not None:
-                    mask = drop_masks[(prefix, i)].to(x.device, torch.float32)
-                else:                                                            # utils.py:145-150
-                    mask = torch.floor(keep + torch.rand((b,), device=x.device, dtype=torch.float32))
-                dc = (mask / keep).contiguous()
-            x = self._bn_train(live, bp + "._bn2", p_raw, ops.ACT_NONE, residual=x if blk.skip else None, dc_scale=dc)
-            if multiscale:
-                feats.append(x)
-        b, h, w, _ = x.shape
-        f = self._bn_train(live, prefix + "._bn1",
-                           ops.conv_igemm(x, 320, e.w_head, 1280, batch=b, in_h=h, in_w=w), ops.ACT_SWISH)
-        return f, feats
-
     def forward(self, grd, sat, drop_masks=None):
-        """Eval mode: the full inference path.  Train mode (self.training): the FORWARD semantics of the
-        reference in training (batch-statistic BatchNorm with running-stat updates, drop_connect); the
-        returned tensors do not carry an autograd graph yet — backward is not implemented, and there is
-        deliberately no eager fallback.  drop_masks: optional {(encoder prefix, block): [B] 0/1 tensor}
-        to inject the drop_connect draws (parity tests); None draws them like utils.py:145-150."""
+        """Eval mode: the full inference path.  Train mode (self.training): the reference's training semantics
+        (batch-statistic BatchNorm with running-stat updates, drop_connect); when autograd is enabled the returned
+        tensors carry a graph whose backward runs the HIP backward kernels (ccvpe_amd/train.py) and fills the
+        parameters' .grad — there is deliberately no eager fallback.  drop_masks: optional {(encoder prefix, block):
+        [B] 0/1 tensor} to inject the drop_connect draws (parity tests); None draws them like utils.py:145-150."""
         if self.training and self.precision != "fp32":
-            raise NotImplementedError("ccvpe_amd: train-mode forward is fp32 only")
+            raise NotImplementedError("ccvpe_amd: train mode is fp32 only")
         if not (grd.is_cuda and sat.is_cuda):
             raise RuntimeError("ccvpe_amd runs on the MI355X only: inputs must be device tensors")
+        if self.training:
+            from . import train
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                outs = train.apply(self, grd, sat, drop_masks)
+            else:
+                with torch.no_grad():
+                    outs, _ = train.forward_train(self, grd, sat, drop_masks, rec=False)
+            outs = list(outs)
+            if self.ori_noise is not None:          # ori_prior returns the recomputed 20-shift volume (models.py:501-511)
+                outs[3] = outs[3][:, len(self._loc_shifts()):]
+            return tuple(outs)
         spec = MODEL_SPECS[self.kind]
         n_rot = spec["n_rot"]
         strides = MATCH_STRIDES[self.kind]
@@ -457,12 +427,8 @@ class _CVMBase(nn.Module):
             main = torch.cuda.current_stream()
             side = self._side_stream()
             side.wait_stream(main)
-            live = self.state_dict(keep_vars=True) if self.training else None
             with torch.cuda.stream(side):
-                if self.training:
-                    gfeat, _ = self._run_encoder_train(pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks)
-                else:
-                    gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
+                gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
                 _, gh, gw, _ = gfeat.shape
                 if gh != spec["grd_h"]:
                     raise ValueError("ground feature height %d != %d expected by the descriptor heads"
@@ -470,11 +436,7 @@ class _CVMBase(nn.Module):
                 y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw,
                                     shift=pk.gd_bias, ldd=_round_up(pk.gd_n, 4), out_f32=True)
                 gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
-            if self.training:
-                svol, sfeats = self._run_encoder_train(pk.sat, live, "sat_efficientnet", sat, False, True, drop_masks)
-                self._pack_key = None      # running statistics changed in place: the folded (eval) pack is stale
-            else:
-                svol, sfeats = _run_encoder(pk.sat, sat, False, True, pk.dtype)
+            svol, sfeats = _run_encoder(pk.sat, sat, False, True, pk.dtype)
             main.wait_stream(side)
             gdesc.record_stream(main)
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],

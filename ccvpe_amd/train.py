@@ -1,0 +1,421 @@
+"""Train-mode forward + backward of the path, every arithmetic step a libccvpe_hip.so call.
+
+Reference behaviour being reproduced: `model.train()` + `loss.backward()` on CVM_VIGOR / CVM_VIGOR_ori_prior /
+CVM_KITTI (train_VIGOR.py:193-229, train_KITTI.py): BatchNorm with batch statistics and running-stat
+updates (efficientnet_pytorch/model.py:63,73,87,182,210), drop_connect (utils.py:129-154), gradients for
+every parameter the forward touches.
+
+Design: ONE torch.autograd.Function for the whole model.  forward() runs the HIP kernels and keeps a tape of
+the tensors the backward needs (raw conv outputs + batch statistics, not the normalised tensors: BN +
+activation are recomputed inside the backward kernels); backward() walks the tape in reverse with the
+backward kernels (ccvpe_amd/backward.py) and returns the parameter gradients in the reference's layouts.
+The caller's loss stays ordinary torch code on the returned tensors (losses.py), exactly as in the
+reference's training scripts.  The decoders run unfused in train mode (ConvTranspose2d as its own GEMM),
+so that the upsampled tensor exists for the backward.
+
+Determinism: no atomics anywhere; every reduction is partials + fixed-order merge.
+"""
+import torch
+
+from . import backward as bw
+from . import ops
+from .synth import MODEL_SPECS
+
+BN_EPS = 1e-3
+SKIP_BLOCKS = (15, 10, 4, 2, 0)
+
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------------
+# forward
+# ------------------------------------------------------------------------------------------------------
+def _bn(model, live, name, x_raw, act, residual=None, dc=None, want_se=False):
+    mean, var = ops.bn_stats(x_raw, live[name + ".running_mean"], live[name + ".running_var"], model.BN_MOMENTUM)
+    live[name + ".num_batches_tracked"].add_(1)
+    out = ops.bn_act(x_raw, mean, var, live[name + ".weight"].detach(), live[name + ".bias"].detach(), BN_EPS, act,
+                     residual=residual, dc_scale=dc, want_se=want_se)
+    return out, mean, var
+
+
+def encoder_forward(model, e, live, prefix, img, circular, multiscale, drop_masks, rec):
+    """EfficientNet.extract_features[_multiscale] with self.training == True (model.py:278-326).
+    Returns (features [B,h,w,1280], per-block outputs, tape or None)."""
+    tape = {"blocks": []} if rec else None
+    stem_raw = ops.stem_conv_raw(img, e.stem_w, circular)
+    x, m, v = _bn(model, live, prefix + "._bn0", stem_raw, ops.ACT_SWISH)
+    if rec:
+        tape["stem"] = (img, stem_raw, m, v)
+    feats = []
+    for i, blk in enumerate(e.blocks):
+        bp = "%s._blocks.%d" % (prefix, i)
+        b, h, w, _ = x.shape
+        s = {"x_in": x, "hw": (h, w)}
+        t = x
+        if blk.expand:
+            e_raw = ops.conv_igemm(x, blk.cin, blk.w_exp, blk.mid, batch=b, in_h=h, in_w=w)
+            t, m0, v0 = _bn(model, live, bp + "._bn0", e_raw, ops.ACT_SWISH)
+            s.update(e_raw=e_raw, m0=m0, v0=v0)
+        u_raw = ops.dwconv_raw(t, blk.w_dw, blk.k, blk.s, circular)
+        (u, part), m1, v1 = _bn(model, live, bp + "._bn1", u_raw, ops.ACT_SWISH, want_se=True)
+        ho, wo = u.shape[1], u.shape[2]
+        gate = ops.se_gate(part, ho * wo, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        if rec:      # the projection's weight gradient needs the gated tensor itself
+            vg = bw.gate_mul(u, gate)
+            p_raw = ops.conv_igemm(vg, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo)
+            s.update(t=t, u_raw=u_raw, m1=m1, v1=v1, part=part, gate=gate, vg=vg)
+        else:
+            p_raw = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate)
+        dc = None
+        rate = model.drop_connect_rate * float(i) / len(e.blocks)               # model.py:293-295
+        if blk.skip and rate:
+            keep = 1.0 - rate
+            if drop_masks is not None:
+                mask = drop_masks[(prefix, i)].to(x.device, torch.float32)
+            else:                                                                # utils.py:145-150
+                mask = torch.floor(keep + torch.rand((b,), device=x.device, dtype=torch.float32))
+            dc = (mask / keep).contiguous()
+        x, m2, v2 = _bn(model, live, bp + "._bn2", p_raw, ops.ACT_NONE, residual=x if blk.skip else None, dc=dc)
+        if rec:
+            s.update(p_raw=p_raw, m2=m2, v2=v2, dc=dc)
+            tape["blocks"].append(s)
+        if multiscale:
+            feats.append(x)
+    b, h, w, _ = x.shape
+    h_raw = ops.conv_igemm(x, 320, e.w_head, 1280, batch=b, in_h=h, in_w=w)
+    f, m, v = _bn(model, live, prefix + "._bn1", h_raw, ops.ACT_SWISH)
+    if rec:
+        tape["head"] = (x, h_raw, m, v)
+    return f, feats, tape
+
+
+def _decoder_level(lv, cat, k, k_algo, skip, batch, hw, last, cout_last, rec):
+    """deconv -> [cat skip] -> 3x3 + ReLU -> 3x3 (models.py:42-47,208-209); the last level ends in the 16 -> cout head."""
+    up = ops.conv_igemm(cat, k, lv.up_w, lv.up_n, batch=batch, in_h=hw, in_w=hw, shift=lv.up_b,
+                        out_mode=ops.OUT_DECONV2X, algo_k=k_algo)
+    y = ops.conv_igemm(up, lv.c0, lv.w_a, lv.n_a, batch=batch, in_h=2 * hw, in_w=2 * hw, kh=3, kw=3, pad=1,
+                       src1=skip, c1=lv.c1, shift=lv.b_a, act=ops.ACT_RELU)
+    if last:
+        out = ops.head_conv3x3(y, lv.w_b, lv.b_b, cout_last, cout_last == 2)
+    else:
+        out = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw, kh=3, kw=3, pad=1,
+                             shift=lv.b_b)
+    t = {"cat": cat, "k": k, "up": up, "skip": skip, "y": y, "hw": hw} if rec else None
+    return out, t
+
+
+def forward_train(model, grd, sat, drop_masks=None, rec=False):
+    """Train-mode forward.  Returns (outputs, tape): outputs = (logits, heatmap, x_ori, sc_1..sc_6) with the FULL
+    score volume of every level (the model slices level 6 for ori_prior afterwards)."""
+    spec = MODEL_SPECS[model.kind]
+    n_rot = spec["n_rot"]
+    from .models import MATCH_STRIDES
+    strides = MATCH_STRIDES[model.kind]
+    circular = bool(model.circular_padding) and model.kind != "kitti"
+    pk = model._packed()
+    live = model.state_dict(keep_vars=True)
+    grd = grd.contiguous().float()
+    sat = sat.contiguous().float()
+    batch = grd.shape[0]
+    tape = {} if rec else None
+
+    gfeat, _, gt = encoder_forward(model, pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks, rec)
+    _, gh, gw, _ = gfeat.shape
+    if gh != spec["grd_h"]:
+        raise ValueError("ground feature height %d != %d expected by the descriptor heads" % (gh, spec["grd_h"]))
+    y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw, shift=pk.gd_bias,
+                        ldd=_round_up(pk.gd_n, 4))
+    gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
+    svol, sfeats, st = encoder_forward(model, pk.sat, live, "sat_efficientnet", sat, False, True, drop_masks, rec)
+    model._pack_key = None          # running statistics changed in place: the folded (eval) pack is stale
+    sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1], in_w=svol.shape[2],
+                           kh=2, kw=2, stride=2, shift=pk.sd_bias)
+    if rec:
+        tape.update(grd=gt, sat=st, gfeat=gfeat, y1=y1, gdesc=gdesc, svol=svol, gw=gw, circular=circular,
+                    match=[], loc=[], ori=[])
+
+    loc_shifts = model._loc_shifts()
+    scores_out = []
+    x = sdesc
+    cat6 = None
+    goff = 0
+    for j in range(6):
+        lv = pk.loc[j]
+        hw = x.shape[1]
+        cd = spec["cd"][j]
+        L = gw * cd
+        g = gdesc[:, goff:goff + L]
+        if j == 0:
+            if model.ori_noise is None:
+                shifts, n_max = list(range(n_rot)), n_rot
+            else:                                               # models.py:501-511
+                shifts, n_max = loc_shifts + list(range(n_rot)), len(loc_shifts)
+            n_tail = n_rot
+        else:
+            shifts, n_max, n_tail = loc_shifts, len(loc_shifts), 0
+        sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c)
+        if rec:
+            tape["match"].append(dict(x=x, goff=goff, L=L, shifts=shifts, n_max=n_max, n_tail=n_tail, stride=strides[j],
+                                      sc=sc, c=lv.c))
+        goff += L
+        if j == 0:
+            cat6 = cat
+        scores_out.append(sc)
+        skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+        x, t = _decoder_level(lv, cat, lv.ldo, lv.c + 1, skip, batch, hw, j == 5, 1, rec)
+        if rec:
+            tape["loc"].append(t)
+    logits_map = x                                                                # [B,1,512,512]
+    logits = logits_map.reshape(batch, -1)                                        # models.py:319
+    heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)                  # models.py:320
+
+    xo = cat6
+    for j in range(6):
+        ov = pk.ori[j]
+        hw = xo.shape[1]
+        skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+        xo, t = _decoder_level(ov, xo, ov.k, ov.k_algo, skip, batch, hw, j == 5, 2, rec)
+        if rec:
+            tape["ori"].append(t)
+    if rec:
+        tape["heatmap"] = heatmap
+    return (logits, heatmap, xo) + tuple(scores_out), tape
+
+
+# ------------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------------
+def _p(live, name):
+    return live[name].detach()
+
+
+def _bn_bwd(live, name, grads, x_raw, dv, mean, var, act, **kw):
+    dx, dgamma, dbeta = bw.bn_act_bwd(x_raw, dv, mean, var, _p(live, name + ".weight"), _p(live, name + ".bias"), BN_EPS,
+                                      act, **kw)
+    grads[name + ".weight"] = dgamma
+    grads[name + ".bias"] = dbeta
+    return dx
+
+
+def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
+    """dfeat: gradient w.r.t. the 1280-channel output; dfeats {block index: gradient w.r.t. that block's output}."""
+    x_last, h_raw, m, v = tape["head"]
+    dh = _bn_bwd(live, prefix + "._bn1", grads, h_raw, dfeat, m, v, ops.ACT_SWISH)
+    grads[prefix + "._conv_head.weight"] = bw.conv_wgrad(x_last, dh, 1280, 1, 1, 1, 0)
+    dx = bw.conv1x1_dgrad(dh, _p(live, prefix + "._conv_head.weight"))
+    for i in reversed(range(len(e.blocks))):
+        blk, s = e.blocks[i], tape["blocks"][i]
+        bp = "%s._blocks.%d" % (prefix, i)
+        if i in dfeats:
+            bw.add_cols(dfeats[i], 0, blk.cout, dx)
+        h, w = s["hw"]
+        # project conv + bn2 (+ residual, drop_connect)
+        dp = _bn_bwd(live, bp + "._bn2", grads, s["p_raw"], dx, s["m2"], s["v2"], ops.ACT_NONE, dc_scale=s["dc"])
+        grads[bp + "._project_conv.weight"] = bw.conv_wgrad(s["vg"], dp, blk.cout, 1, 1, 1, 0)
+        dv = bw.conv1x1_dgrad(dp, _p(live, bp + "._project_conv.weight"))
+        # squeeze-excite
+        g1, b1 = _p(live, bp + "._bn1.weight"), _p(live, bp + "._bn1.bias")
+        dgp = bw.se_dgate_partials(s["u_raw"], dv, s["m1"], s["v1"], g1, b1, BN_EPS, ops.ACT_SWISH)
+        ho, wo = s["u_raw"].shape[1], s["u_raw"].shape[2]
+        dmean, dw1, db1, dw2, db2 = bw.se_bwd(s["part"], ho * wo, dgp, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        grads[bp + "._se_reduce.weight"], grads[bp + "._se_reduce.bias"] = dw1, db1
+        grads[bp + "._se_expand.weight"], grads[bp + "._se_expand.bias"] = dw2, db2
+        # depthwise conv + bn1
+        du = _bn_bwd(live, bp + "._bn1", grads, s["u_raw"], dv, s["m1"], s["v1"], ops.ACT_SWISH, gate=s["gate"], dmean=dmean)
+        grads[bp + "._depthwise_conv.weight"] = bw.dwconv_wgrad(s["t"], du, blk.k, blk.s, circular).t()
+        dt = bw.dwconv_dgrad(du, blk.w_dw, h, w, blk.k, blk.s, circular)
+        # expand conv + bn0
+        if blk.expand:
+            de = _bn_bwd(live, bp + "._bn0", grads, s["e_raw"], dt, s["m0"], s["v0"], ops.ACT_SWISH)
+            grads[bp + "._expand_conv.weight"] = bw.conv_wgrad(s["x_in"], de, blk.mid, 1, 1, 1, 0)
+            dxin = bw.conv1x1_dgrad(de, _p(live, bp + "._expand_conv.weight"))
+        else:
+            dxin = dt
+        if blk.skip:
+            bw.add_cols(dx, 0, blk.cin, dxin)
+        dx = dxin
+    img, stem_raw, m, v = tape["stem"]
+    ds = _bn_bwd(live, prefix + "._bn0", grads, stem_raw, dx, m, v, ops.ACT_SWISH)
+    grads[prefix + "._conv_stem.weight"] = bw.stem_conv_wgrad(img, ds, circular).permute(3, 2, 0, 1)
+
+
+def _scatter_rows(dst, src, col_map):
+    """dst (reference input-channel order) <- src (this implementation's order) along dim 0."""
+    for d0, s0, n in col_map:
+        dst[s0:s0 + n] = src[d0:d0 + n]
+    return dst
+
+
+def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, skip_block, grads):
+    """names = (deconv, conv); dout: gradient w.r.t. the level's output (NHWC, or NCHW head output when last).
+    Returns the gradient w.r.t. the level's input `cat` [B,hw,hw,k] in this implementation's column order."""
+    deconv, conv = names
+    y, up, skip, cat, k = t["y"], t["up"], t["skip"], t["cat"], t["k"]
+    w_b = _p(live, conv + ".2.weight")
+    if last:
+        dy, dwb, dbb = bw.head_conv3x3_bwd(y, lv.w_b, dout)
+        grads[conv + ".2.weight"] = dwb.permute(0, 3, 1, 2)
+        grads[conv + ".2.bias"] = dbb
+    else:
+        grads[conv + ".2.weight"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1)
+        grads[conv + ".2.bias"] = bw.bias_grad(dout)
+        dy = bw.conv3x3_dgrad(dout, w_b)
+    dy = bw.relu_bwd(y, dy)
+    grads[conv + ".0.weight"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip)
+    grads[conv + ".0.bias"] = bw.bias_grad(dy)
+    dcat2 = bw.conv3x3_dgrad(dy, _p(live, conv + ".0.weight"))                 # [B,2hw,2hw,c0+c1]
+    if skip is not None:
+        if skip_block in dfeats:
+            bw.add_cols(dcat2, lv.c0, lv.c1, dfeats[skip_block])
+        else:
+            d = torch.empty(skip.shape, device=skip.device, dtype=torch.float32)
+            dfeats[skip_block] = bw.add_cols(dcat2, lv.c0, lv.c1, d, accumulate=False)
+    # ConvTranspose2d(k2,s2): weight [Cin,Cout,2,2] (Cin in reference order), bias [Cout]
+    w_ref = _p(live, deconv + ".weight")
+    cout = w_ref.shape[1]
+    grads[deconv + ".bias"] = bw.bias_grad(dcat2)[:cout]
+    dw_ours = bw.conv_wgrad(dcat2, cat, k, 2, 2, 2, 0, c0=cout)                 # [k, Cout, 2, 2], our row order
+    grads[deconv + ".weight"] = _scatter_rows(torch.empty_like(w_ref), dw_ours, col_map)
+    w_ours = w_ref.new_zeros((k,) + tuple(w_ref.shape[1:]))
+    for d0, s0, n in col_map:
+        w_ours[d0:d0 + n] = w_ref[s0:s0 + n]
+    b, h2 = dcat2.shape[0], dcat2.shape[1]
+    return ops.conv_igemm(dcat2, cout, bw._pack_conv(w_ours), k, batch=b, in_h=h2, in_w=h2, kh=2, kw=2, stride=2,
+                          ld0=dcat2.shape[-1])
+
+
+def backward_train(model, tape, gout):
+    """gout = gradients w.r.t. (logits, heatmap, x_ori, sc_1..sc_6) (None where unused).
+    Returns {parameter name: gradient in the parameter's own layout}."""
+    spec = MODEL_SPECS[model.kind]
+    n_rot = spec["n_rot"]
+    pk = model._packed()
+    live = model.state_dict(keep_vars=True)
+    grads = {}
+    dfeats = {}
+    g_logits, g_heat, g_ori = gout[0], gout[1], gout[2]
+    g_scores = gout[3:]
+    heatmap = tape["heatmap"]
+    batch = heatmap.shape[0]
+    dev = heatmap.device
+
+    def _c(t):
+        return None if t is None else t.contiguous().float()
+
+    # ---- localisation head: softmax over the flattened map (models.py:319-320) -----------------------
+    hm = heatmap.reshape(batch, -1)
+    if g_heat is not None:
+        dlog = bw.softmax_bwd(hm, _c(g_heat).reshape(batch, -1), _c(g_logits))
+    elif g_logits is not None:
+        dlog = _c(g_logits)
+    else:
+        dlog = torch.zeros_like(hm)
+    dloc = dlog.reshape(heatmap.shape)
+    # ---- orientation head: F.normalize (models.py:341) ---------------------------------------------------
+    t5 = tape["ori"][5]
+    if g_ori is not None:
+        raw = ops.head_conv3x3(t5["y"], pk.ori[5].w_b, pk.ori[5].b_b, 2, False)
+        dori = bw.l2norm2_bwd(raw, _c(g_ori))
+    else:
+        dori = torch.zeros((batch, 2) + tuple(heatmap.shape[2:]), device=dev, dtype=torch.float32)
+
+    # ---- orientation decoder, level 1 -> 6 ----------------------------------------------------------------
+    d = dori
+    for j in reversed(range(6)):
+        lvl = 6 - j
+        ov = pk.ori[j]
+        if j == 0:
+            c6 = spec["ori"][0][0] - n_rot
+            cmap = [(0, n_rot, c6), (c6 + 1, 0, n_rot)]
+        else:
+            cmap = [(0, 0, spec["ori"][j][0])]
+        d = _decoder_level_backward(live, ov, tape["ori"][j], d, j == 5, ("deconv%d_ori" % lvl, "conv%d_ori" % lvl), cmap,
+                                    dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads)
+    dcat6_ori = d
+
+    # ---- localisation decoder + matching, level 1 -> 6 -------------------------------------------------
+    dgdesc = torch.zeros_like(tape["gdesc"])
+    d = dloc
+    for j in reversed(range(6)):
+        lvl = 6 - j
+        lv = pk.loc[j]
+        c = lv.c
+        dcat = _decoder_level_backward(live, lv, tape["loc"][j], d, j == 5, ("deconv%d" % lvl, "conv%d" % lvl),
+                                       [(0, 1, c), (c, 0, 1)], dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads)
+        if j == 0:
+            bw.add_cols(dcat6_ori, 0, lv.ldo, dcat)
+        mt = tape["match"][j]
+        g = tape["gdesc"][:, mt["goff"]:mt["goff"] + mt["L"]]
+        dg = dgdesc[:, mt["goff"]:mt["goff"] + mt["L"]]
+        d = bw.match_level_bwd(mt["x"], g, mt["L"], mt["shifts"], mt["n_max"], mt["n_tail"], mt["stride"], mt["sc"],
+                               _c(g_scores[j]), dcat, c, dg)
+    dsdesc = d
+
+    # ---- aerial descriptor: Linear(5120 -> N) == conv 2x2 stride 2 (models.py:102-104,173-184) ------------
+    w_lin = _p(live, "sat_feature_to_descriptors.1.weight")
+    w4 = w_lin.view(w_lin.shape[0], 1280, 2, 2)
+    svol = tape["svol"]
+    grads["sat_feature_to_descriptors.1.weight"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0).reshape(w_lin.shape)
+    grads["sat_feature_to_descriptors.1.bias"] = bw.bias_grad(dsdesc)
+    dsvol = bw.conv2x2s2_dgrad(dsdesc, w4)
+    encoder_backward(pk.sat, live, "sat_efficientnet", tape["sat"], dsvol, dfeats, False, grads)
+
+    # ---- ground descriptors (models.py:57-97,153-165) ---------------------------------------------------------
+    y1, gfeat = tape["y1"], tape["gfeat"]
+    dy1, dwh, dbh = bw.ground_descriptor_bwd(y1, pk.gd_wh, spec["cd"], dgdesc)
+    n = pk.gd_n
+    dwg = bw.conv_wgrad(gfeat, dy1, n, 1, 1, 1, 0).reshape(n, 1280)
+    dbg = bw.bias_grad(dy1)
+    off = 0
+    for l in range(1, 7):
+        p = "grd_feature_to_descriptor%d" % l
+        cd = spec["cd"][l - 1]
+        grads[p + ".0.weight"] = dwg[off:off + cd].reshape(live[p + ".0.weight"].shape)
+        grads[p + ".0.bias"] = dbg[off:off + cd]
+        grads[p + ".2.weight"] = dwh[l - 1].reshape(live[p + ".2.weight"].shape)
+        grads[p + ".2.bias"] = dbh[l - 1:l].reshape(live[p + ".2.bias"].shape)
+        off += cd
+    b, gh, gw, ld = dy1.shape
+    # dy1's pad columns (n..ld) are zero; the K dimension of the dgrad GEMM is padded to ld with zero weights
+    wcat = torch.cat([_p(live, "grd_feature_to_descriptor%d.0.weight" % l) for l in range(1, 7)], 0)
+    wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
+    wpad[:n] = wcat
+    dgfeat = ops.conv_igemm(dy1, ld, bw._pack_conv(wpad.permute(1, 0, 2, 3)), 1280, batch=b, in_h=gh, in_w=gw)
+    encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], grads)
+    return grads
+
+
+class CVMFunction(torch.autograd.Function):
+    """(grd, sat, *parameters) -> (logits, heatmap, x_ori, sc_1..sc_6); gradients for the parameters only."""
+
+    @staticmethod
+    def forward(ctx, model, drop_masks, names, grd, sat, *params):
+        outs, tape = forward_train(model, grd, sat, drop_masks, rec=True)
+        ctx.model, ctx.tape, ctx.names = model, tape, names
+        ctx.set_materialize_grads(False)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gout):
+        model, tape, names = ctx.model, ctx.tape, ctx.names
+        if tape is None:
+            raise RuntimeError("ccvpe_amd: backward through the same forward twice is not supported")
+        with torch.no_grad():
+            grads = backward_train(model, tape, gout)
+        ctx.tape = None
+        live = model.state_dict(keep_vars=True)
+        out = []
+        for nm in names:
+            g = grads.get(nm)
+            if g is not None:
+                g = g.reshape(live[nm].shape).contiguous()
+            out.append(g)
+        return (None, None, None, None, None) + tuple(out)
+
+
+def apply(model, grd, sat, drop_masks=None):
+    named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    names = [n for n, _ in named]
+    return CVMFunction.apply(model, drop_masks, names, grd, sat, *[p for _, p in named])

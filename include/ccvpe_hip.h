@@ -290,6 +290,9 @@ int ccvpe_dwconv_wgrad_nblk(int in_h, int in_w, int k, int stride);
 int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw, float* scratch, int batch, int in_h, int in_w,
                            int channels, int k, int stride, int circular, void* stream);
 int ccvpe_relu_bwd_f32(const float* y, const float* dy, float* dx, int n_elems, void* stream);
+/* v = u * gate[b,c] materialised (the projection conv's weight gradient reads the gated tensor). */
+int ccvpe_gate_mul_f32(const float* u, const float* gate, float* v, int batch, int rows_per_sample, int channels,
+                       void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Backward of the head / glue operators (csrc/heads_bwd.hip, csrc/matching_bwd.hip).

@@ -42,6 +42,70 @@ def train_drop_masks(batch):
     return masks, scales, skip
 
 
+def train_loss(out):
+    """Deterministic scalar touching all nine outputs (golden gradients): soft-label cross entropy on the logits
+    (losses.py:26-28 form) plus fixed pseudo-random linear functionals of the heat-map, the orientation map and the six
+    matching-score volumes.  Plain torch, so it runs on the reference's outputs (CPU) and on ours (device) alike."""
+    from ccvpe_amd import synth
+    logits, heat, ori = out[0], out[1], out[2]
+    dev = logits.device
+    b = logits.shape[0]
+    lab = synth.uniform(tuple(logits.shape), 7001) ** 30
+    lab = (lab / lab.sum(1, keepdim=True)).to(dev)
+    loss = -(lab * torch.log_softmax(logits, dim=1)).sum() / b
+    loss = loss + 50.0 * (heat.reshape(b, -1) * synth.normal(tuple(logits.shape), 7002).to(dev)).sum()
+    loss = loss + (ori * synth.normal(tuple(ori.shape), 7003).to(dev)).mean() * 10.0
+    for i, s in enumerate(out[3:]):
+        loss = loss + (s * synth.normal(tuple(s.shape), 7010 + i).to(dev)).mean() * 3.0
+    return loss
+
+
+GRAD_SAMPLE_MAX = 2048
+
+
+def summarize_grads(named_grads):
+    """{name: grad tensor or None} -> per-parameter L2 norms (all parameters) + strided samples of every tensor."""
+    d = {}
+    names, norms = [], []
+    for n, g in named_grads:
+        if g is None:
+            continue
+        g = g.detach().cpu().double().reshape(-1)
+        names.append(n)
+        norms.append(float(g.norm()))
+        step = max(1, g.numel() // GRAD_SAMPLE_MAX)
+        d["g:" + n] = g[::step][:GRAD_SAMPLE_MAX].float().numpy()
+    d["names"] = np.array(names)
+    d["norms"] = np.array(norms, dtype=np.float64)
+    return d
+
+
+# Parameters whose TRUE gradient is exactly zero, so that fp32 autograd returns round-off noise there:
+#   conv1.2.bias       softmax / cross-entropy are invariant to a constant added to every logit;
+#   most _bn2.bias     a per-channel constant is removed again by the batch-statistic BatchNorm that follows
+# (checked with the oracle in float64: norms ~1e-17).  They are only required to stay at noise level.
+def compare_grads(got, want, rel_l2=3e-2):
+    """Relative-L2 comparison of two summarize_grads() dicts.  The reference's own fp32 gradients sit 0.25 % (median)
+    to 2.5 % (worst tensor: early squeeze-excite layers) away from the float64 gradient of the same graph (B=2
+    batch-statistic BatchNorm amplifies round-off), so 3 % per tensor is the resolution of this fixture.
+    Returns (list of offending tensors, median relative error)."""
+    assert [str(n) for n in got["names"]] == [str(n) for n in want["names"]], "set of parameters with a gradient differs"
+    top = float(want["norms"].max())
+    bad, rels = [], []
+    for n, wn, gn in zip(want["names"], want["norms"], got["norms"]):
+        n = str(n)
+        w, g = want["g:" + n].astype(np.float64), got["g:" + n].astype(np.float64)
+        if wn < 1e-6 * top or n == "conv1.2.bias":
+            if gn > 1e-4 * top:
+                bad.append((n, "noise-level gradient expected", float(wn), float(gn)))
+            continue
+        r = float(np.linalg.norm(w - g) / np.linalg.norm(w))
+        rels.append(r)
+        if not (r <= rel_l2 and abs(gn - wn) <= rel_l2 * wn):
+            bad.append((n, r, float(wn), float(gn)))
+    return bad, float(np.median(rels))
+
+
 RUNNING_STAT_SAMPLES = ("grd_efficientnet._bn0", "grd_efficientnet._blocks.3._bn1", "grd_efficientnet._blocks.15._bn2",
                         "sat_efficientnet._blocks.0._bn1", "sat_efficientnet._blocks.9._bn0", "sat_efficientnet._bn1")
 

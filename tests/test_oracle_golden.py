@@ -115,3 +115,23 @@ def test_synth_is_stable():
 
 PINNED_HASH = [4181168224, 2125990995, 531683462]
 PINNED_UNIFORM = [0.5901376008987427, 0.5631661415100098, 0.5688017010688782, 0.8550075888633728]
+
+
+def test_oracle_train_mode_gradients_vs_reference_autograd():
+    """The oracle is differentiable torch code: its train-mode gradients for the shared deterministic loss must
+    match the gradients autograd produced through the REFERENCE (grad_vigor_trainmode.npz)."""
+    import torch
+    from ccvpe_amd import synth
+    c = G.TRAIN_CASE
+    want = G.load("grad_vigor_trainmode")
+    sd = synth.synthetic_state_dict(c["kind"], c["wseed"])
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+              for k, v in sd.items()}
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    _, scales, _ = G.train_drop_masks(c["batch"])
+    out = O.forward(params, grd, sat, c["kind"], c["circular"], None, train_stats={}, drop_scales=scales)
+    G.train_loss(out).backward()
+    got = G.summarize_grads([(k, v.grad) for k, v in params.items() if k in set(str(n) for n in want["names"])])
+    bad, med = G.compare_grads(got, want)
+    assert not bad, bad[:10]
+    assert med < 6e-3, med

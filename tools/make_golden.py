@@ -33,7 +33,8 @@ def main():
     sds = {}
     with torch.no_grad():
         # ---- full forwards --------------------------------------------------------------
-        for name, c in G.FORWARD_CASES.items():
+        only_train = "--only-train" in sys.argv
+        for name, c in ({} if only_train else G.FORWARD_CASES).items():
             key = (c["kind"], c["wseed"])
             if key not in sds:
                 sds[key] = synth.synthetic_state_dict(*key)
@@ -64,6 +65,8 @@ def main():
         # ---- train-mode forward (batch-stat BN, injected drop_connect draws) ----------------------------
         import efficientnet_pytorch.model as effmodel
         c = G.TRAIN_CASE
+        if (c["kind"], c["wseed"]) not in sds:
+            sds[(c["kind"], c["wseed"])] = synth.synthetic_state_dict(c["kind"], c["wseed"])
         sd = sds[(c["kind"], c["wseed"])]
         masks, _, skip = G.train_drop_masks(c["batch"])
         order = [("grd_efficientnet", i) for i in skip] + [("sat_efficientnet", i) for i in skip]
@@ -79,15 +82,22 @@ def main():
         net.load_state_dict(sd, strict=True)
         net.train()
         grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
-        out = net(grd, sat)
-        effmodel.drop_connect = real_dc
-        assert len(calls) == len(order)
+        with torch.enable_grad():
+            out = net(grd, sat)
+            effmodel.drop_connect = real_dc
+            assert len(calls) == len(order)
+            # ---- gradients of the shared deterministic loss through the REFERENCE (autograd on the CPU) --------
+            G.train_loss(out).backward()
+        save("grad_vigor_trainmode", G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()]))
+        out = [t.detach() for t in out]
         d = G.summarize_forward(out)
         after = net.state_dict()
         for k in G.RUNNING_STAT_SAMPLES:
             d["rm:" + k] = after[k + ".running_mean"].numpy()
             d["rv:" + k] = after[k + ".running_var"].numpy()
         save("fwd_vigor_trainmode", d)
+        if only_train:
+            return
 
         # ---- single MBConv blocks / stem on small inputs -----------------------------------
         sd = sds[("vigor", 0)]
