@@ -52,3 +52,36 @@ def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
     opt.step()
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in net1.named_parameters())
     assert changed >= 480          # 520 tensors receive a gradient, 26 of them exactly zero
+
+
+@pytest.mark.parametrize("kind,ori_noise,circular", [("kitti", None, False), ("vigor", 36, True)])
+def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise, circular):
+    """CVM_KITTI and CVM_VIGOR_ori_prior (5 localisation shifts + the recomputed 20-shift level-6 volume): no reference
+    golden is stored for these, so the gradients are compared with autograd through the oracle on the CPU."""
+    from ccvpe_amd import models
+    from oracle import ccvpe_oracle as O
+    sd = synth_sd(kind, 3)
+    if kind == "kitti":
+        net = models.CVM_KITTI("cuda")
+    else:
+        net = models.CVM_VIGOR_ori_prior("cuda", ori_noise, circular)
+    net.load_state_dict(sd, strict=True)
+    net = net.to("cuda:0").train()
+    grd, sat = synth.synthetic_pair(2, kind, 31)
+    masks, scales, _ = G.train_drop_masks(2)
+    out = net(grd.cuda(), sat.cuda(), drop_masks=masks)
+    G.train_loss(out).backward()
+    torch.cuda.synchronize()
+    got = G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()])
+
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+              for k, v in sd.items()}
+    ref = O.forward(params, grd, sat, kind, circular, ori_noise, train_stats={}, drop_scales=scales)
+    for a, b in zip(out, ref):
+        assert tuple(a.shape) == tuple(b.shape)
+    G.train_loss(ref).backward()
+    names = set(str(n) for n in got["names"])
+    want = G.summarize_grads([(k, v.grad) for k, v in params.items() if k in names])
+    bad, med = G.compare_grads(got, want)
+    assert not bad, "%d parameter gradients off: %s" % (len(bad), bad[:12])
+    assert med < 6e-3, med
