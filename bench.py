@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
     ap.add_argument("--no-extra", action="store_true",
                     help="skip the short bf16 C2 side measurement attached as `extra` to the default N=1 line")
+    ap.add_argument("--train", action="store_true",
+                    help="time full training steps (forward + losses + backward + gradient all-reduce + Adam) instead "
+                         "of the eval forward: BASELINE config C3 with --model kitti")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket igemm launches with HIP events in the timed region")
     return ap.parse_args()
@@ -76,6 +79,78 @@ def cpu_baseline(sd, batch=8, reps=3):
     med = statistics.median(times)
     return dict(value=batch / med, unit="img-pairs/s", cores=cores, kind="port",
                 sample="oracle forward, CVM_VIGOR_ori_prior(0), B=%d fp32, 1 warm-up + median of %d" % (batch, reps))
+
+
+def synthetic_targets(batch, n_rot, seed, dev):
+    """Ground truth of the shapes the training scripts build (datasets.py:145-166,489-501): a Gaussian (sigma 4 px) at a
+    seeded offset on the 512x512 grid, the (cos, sin) map of a seeded heading and its orientation bin."""
+    import math
+    import torch
+    from ccvpe_amd import synth
+    u = synth.uniform((batch, 3), seed)
+    ys = torch.arange(512, dtype=torch.float32).view(1, 512, 1)
+    xs = torch.arange(512, dtype=torch.float32).view(1, 1, 512)
+    cy = (64 + 384 * u[:, 0]).view(-1, 1, 1)
+    cx = (64 + 384 * u[:, 1]).view(-1, 1, 1)
+    gt = torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * 4.0 ** 2))
+    gt = (gt / gt.sum(dim=(1, 2), keepdim=True)).unsqueeze(1)                      # [B,1,512,512]
+    ang = 2 * math.pi * u[:, 2]
+    gt_ori = torch.stack([torch.cos(ang), torch.sin(ang)], 1).view(batch, 2, 1, 1).expand(batch, 2, 512, 512).contiguous()
+    bins = torch.clamp((u[:, 2] * n_rot).long(), max=n_rot - 1)
+    return gt.to(dev), gt_ori.to(dev), bins.to(dev)
+
+
+def train_main(args, net, grd, sat, dev, world, rank, n_rot):
+    """One training step as train_VIGOR.py:193-229 / train_KITTI.py run it: forward (train mode), the three losses on
+    all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam."""
+    import torch
+    import torch.nn.functional as F
+    from ccvpe_amd import harness, losses
+    net.train()
+    gt, gt_ori, bins = synthetic_targets(args.batch, n_rot, 99 + rank, dev)
+    gt_flat = gt.reshape(args.batch, -1)
+    # per-level matching labels: the heat-map pooled to the level's grid, placed in the true orientation bin
+    labels = []
+    for lvl in range(6):
+        hw = 8 << lvl
+        pooled = F.adaptive_avg_pool2d(gt, hw) * (512 // hw) ** 2                   # [B,1,hw,hw], sums to 1
+        lab = torch.zeros((args.batch, n_rot, hw, hw), device=dev)
+        lab[torch.arange(args.batch, device=dev), bins] = pooled[:, 0]
+        labels.append(lab.reshape(args.batch, -1))
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    reducer = harness.GradientAllReducer(net.parameters())
+    last = {}
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = net(grd, sat)
+        loss = losses.cross_entropy_loss(out[0], gt_flat) + losses.orientation_loss(out[2], gt_ori, gt)
+        for lvl in range(6):
+            sc = out[3 + lvl]
+            loss = loss + losses.infoNCELoss(sc.reshape(args.batch, -1), labels[lvl]) / 6.0
+        loss.backward()
+        reducer()
+        opt.step()
+        last["loss"] = loss.detach()
+
+    torch.cuda.reset_peak_memory_stats(dev)
+    elapsed = harness.timed_steps(step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=dev)
+    if rank == 0:
+        line = {
+            "metric": "train image-pairs/sec", "value": round(args.batch * world * args.steps / elapsed, 2),
+            "unit": "img-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C3: %s training step (train-mode forward, CE + orientation + 6x infoNCE losses, "
+                                   "backward, gradient all-reduce, Adam lr 1e-4)" % type(net).__name__,
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": "dp%d (RCCL all-reduce of gradients, 64 MiB buckets)" % world,
+                       "loss_after_last_step": round(float(last["loss"]), 5),
+                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+            "roofline": None, "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+        sys.stdout.flush()
 
 
 def main():
@@ -112,6 +187,14 @@ def main():
     net = net.to(dev).eval().set_precision(args.precision)
     grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank)
     grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
+    if args.train:
+        if args.precision != "fp32" or args.graph:
+            raise SystemExit("--train is fp32, eager only")
+        train_main(args, net, grd, sat, dev, world, rank, synth.MODEL_SPECS[kind]["n_rot"])
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     from ccvpe_amd import harness
     if args.graph:

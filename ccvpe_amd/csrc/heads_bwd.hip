@@ -368,3 +368,109 @@ extern "C" int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, f
   hipLaunchKernelGGL(sum_parts2_kernel, dim3((27 * 32 + 255) / 256), dim3(256), 0, st, scratch, nblk, 27 * 32, dw);
   return check_launch("stem_wgrad_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Loss backward (losses.py:4-29), gradient w.r.t. the prediction only (labels are data).  `dloss` is the
+// upstream scalar gradient on the device.  One workgroup per sample, row statistics recomputed.
+//   infoNCE : dL/ds_j   = (den_b * p_j - lab_j [lab_j > 1e-2]) / (D * T),  p = softmax(s / T) of the row,
+//                         den_b = masked label sum of the row, D = sum_b den_b
+//   CE      : dL/dz_j   = (softmax_j * sum_i lab_i - lab_j) / B
+//   ori     : dL/do_c,i = -2 (gt_o - o) * gt_i / B
+// ---------------------------------------------------------------------------------------------
+namespace ccvpe {
+
+__global__ __launch_bounds__(1024) void infonce_bwd_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
+                                                           float inv_t, const float* __restrict__ dloss,
+                                                           float* __restrict__ dsc, int n, int B) {
+  __shared__ float sh[16];
+  const float* s = sc + (size_t)blockIdx.x * n;
+  const float* l = lab + (size_t)blockIdx.x * n;
+  float z = 0.f, den = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    z += expf(s[i] * inv_t);
+    const float lv = l[i];
+    if (lv > 1e-2f) den += lv;
+  }
+  z = block_sum_b(z, sh);
+  den = block_sum_b(den, sh);
+  // D: every workgroup recomputes the (tiny) batch total in the same order
+  float D = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* lb = lab + (size_t)b * n;
+    float d = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float lv = lb[i];
+      if (lv > 1e-2f) d += lv;
+    }
+    D += block_sum_b(d, sh);
+  }
+  const float k = dloss[0] * inv_t / D;
+  float* o = dsc + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float lv = l[i];
+    o[i] = k * (den * expf(s[i] * inv_t) / z - (lv > 1e-2f ? lv : 0.f));
+  }
+}
+
+__global__ __launch_bounds__(1024) void ce_bwd_kernel(const float* __restrict__ lg, const float* __restrict__ lab,
+                                                      const float* __restrict__ dloss, float* __restrict__ dlg, int n,
+                                                      int B) {
+  __shared__ float sh[16];
+  const float* r = lg + (size_t)blockIdx.x * n;
+  const float* l = lab + (size_t)blockIdx.x * n;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) m = fmaxf(m, r[i]);
+  m = wave_max(m);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+  __syncthreads();
+  for (int i = 0; i < (int)(blockDim.x >> 6); ++i) m = fmaxf(m, sh[i]);
+  float z = 0.f, ls = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    z += expf(r[i] - m);
+    ls += l[i];
+  }
+  z = block_sum_b(z, sh);
+  ls = block_sum_b(ls, sh);
+  const float k = dloss[0] / (float)B;
+  float* o = dlg + (size_t)blockIdx.x * n;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) o[i] = k * (ls * expf(r[i] - m) / z - l[i]);
+}
+
+__global__ __launch_bounds__(256) void ori_bwd_kernel(const float* __restrict__ ori, const float* __restrict__ gto,
+                                                      const float* __restrict__ gt, const float* __restrict__ dloss,
+                                                      float* __restrict__ dori, int hw, int B) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * hw) return;
+  const int b = (int)(idx / hw), i = (int)(idx % hw);
+  const float k = -2.0f * dloss[0] / (float)B * gt[(size_t)b * hw + i];
+  const size_t i0 = (size_t)b * 2 * hw + i, i1 = i0 + hw;
+  dori[i0] = k * (gto[i0] - ori[i0]);
+  dori[i1] = k * (gto[i1] - ori[i1]);
+}
+
+}  // namespace ccvpe
+
+extern "C" int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
+                                          float* dscores, int batch, int n, void* stream) {
+  if (batch <= 0 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce_bwd: bad args");
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, scores, labels, 1.0f / temperature,
+                     dloss, dscores, n, batch);
+  return check_launch("infonce_bwd_kernel");
+}
+
+extern "C" int ccvpe_cross_entropy_loss_bwd_f32(const float* logits, const float* labels, const float* dloss, float* dlogits,
+                                                int batch, int n, void* stream) {
+  if (batch <= 0 || n <= 0) return fail(CCVPE_EINVAL, "cross_entropy_bwd: bad args");
+  hipLaunchKernelGGL(ce_bwd_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, logits, labels, dloss, dlogits, n, batch);
+  return check_launch("ce_bwd_kernel");
+}
+
+extern "C" int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const float* gt, const float* dloss,
+                                              float* dori, int batch, int hw, void* stream) {
+  if (batch <= 0 || hw <= 0) return fail(CCVPE_EINVAL, "orientation_loss_bwd: bad args");
+  const long n = (long)batch * hw;
+  hipLaunchKernelGGL(ori_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ori, gt_ori, gt, dloss,
+                     dori, hw, batch);
+  return check_launch("ori_bwd_kernel");
+}

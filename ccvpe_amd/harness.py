@@ -50,3 +50,55 @@ def aggregate_throughput(units_per_rank_per_step, steps, elapsed_max):
     """Whole-job units/s: all ranks' units divided by the slowest rank's time."""
     world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
     return units_per_rank_per_step * world * steps / elapsed_max
+
+
+class GradientAllReducer:
+    """Data-parallel training (BASELINE C3): average the parameter gradients over the ranks.
+
+    One process per GPU; `torch.distributed` backend "nccl" is RCCL over xGMI.  Gradients are packed into a few
+    LARGE flat buckets (default 64 MiB: the ~58 M-parameter model is 4 buckets) because xGMI is point-to-point and
+    a ring all-reduce is bound per link — few, large messages amortise the per-collective latency; the buckets are
+    issued asynchronously back to back and unpacked after the last one completes.  The bucket layout is fixed at
+    construction (parameter order), so every rank reduces the same bytes in the same order."""
+
+    def __init__(self, params, bucket_bytes=64 << 20):
+        self.params = [p for p in params if p.requires_grad]
+        self.buckets, cur, size = [], [], 0
+        for p in self.params:
+            nbytes = p.numel() * 4
+            if cur and size + nbytes > bucket_bytes:
+                self.buckets.append(cur)
+                cur, size = [], 0
+            cur.append(p)
+            size += nbytes
+        if cur:
+            self.buckets.append(cur)
+        self._flat = None
+
+    def __call__(self):
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        world = dist.get_world_size()
+        if self._flat is None:
+            self._flat = [torch.empty((sum(p.numel() for p in b),), device=b[0].device, dtype=torch.float32)
+                          for b in self.buckets]
+        works = []
+        for flat, bucket in zip(self._flat, self.buckets):
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is None:
+                    flat[off:off + n].zero_()
+                else:
+                    flat[off:off + n].copy_(p.grad.reshape(-1))
+                off += n
+            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
+        for w, flat, bucket in zip(works, self._flat, self.buckets):
+            w.wait()
+            flat.mul_(1.0 / world)
+            off = 0
+            for p in bucket:
+                n = p.numel()
+                if p.grad is not None:
+                    p.grad.copy_(flat[off:off + n].view_as(p.grad))
+                off += n

@@ -332,6 +332,14 @@ int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, 
                               const float* ddst, int ldo, float* dx, int lddx, float* dg, int ldg_out, float* scratch,
                               int batch, int hw, int channels, void* stream);
 
+/* Loss gradients w.r.t. the prediction (losses.py:4-29); dloss = upstream scalar gradient (device pointer). */
+int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
+                               float* dscores, int batch, int n, void* stream);
+int ccvpe_cross_entropy_loss_bwd_f32(const float* logits, const float* labels, const float* dloss, float* dlogits,
+                                     int batch, int n, void* stream);
+int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const float* gt, const float* dloss,
+                                   float* dori, int batch, int hw, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on

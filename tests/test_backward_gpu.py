@@ -278,3 +278,33 @@ def test_match_level_bwd_vs_autograd(bw, c, L, hw, shifts, n_max, n_tail, stride
     dx = bw.match_level_bwd(xd, gd, L, shifts, n_max, n_tail, stride, scores, dsc.float().cuda(), ddst.float().cuda(), c, dg)
     close(dx, nhwc(x.grad), 2e-4, "match dx")
     close(dg[:, :L], g.grad, 2e-4, "match dg")
+
+
+def test_loss_gradients_vs_oracle_autograd():
+    """ccvpe_amd.losses (the reference's losses.py API, HIP forward + backward) against autograd through the oracle."""
+    from ccvpe_amd import losses
+    from oracle import ccvpe_oracle as orc
+    sc = synth.uniform((3, 5120), 1001, -1.0, 1.0).requires_grad_(True)
+    lab = synth.uniform((3, 5120), 1002) ** 6
+    (2.5 * orc.infonce_loss(sc, lab)).backward()
+    scd = sc.detach().cuda().requires_grad_(True)
+    lo = losses.infoNCELoss(scd, lab.cuda())
+    (2.5 * lo).backward()
+    close(lo, orc.infonce_loss(sc.detach(), lab), 1e-5, "infonce value")
+    close(scd.grad, sc.grad, 1e-4, "infonce grad")
+
+    lg = synth.normal((2, 65536), 1003, 2.0).requires_grad_(True)
+    lb = synth.uniform((2, 65536), 1004) ** 20
+    lb = lb / lb.sum(1, keepdim=True)
+    orc.cross_entropy_loss(lg, lb).backward()
+    lgd = lg.detach().cuda().requires_grad_(True)
+    losses.cross_entropy_loss(lgd, lb.cuda()).backward()
+    close(lgd.grad, lg.grad, 1e-4, "ce grad")
+
+    ori = F.normalize(synth.normal((2, 2, 64, 64), 1005), dim=1).requires_grad_(True)
+    gto = F.normalize(synth.normal((2, 2, 64, 64), 1006), dim=1)
+    gt = synth.uniform((2, 1, 64, 64), 1007) ** 8
+    orc.orientation_loss(ori, gto, gt).backward()
+    od = ori.detach().cuda().requires_grad_(True)
+    losses.orientation_loss(od, gto.cuda(), gt.cuda()).backward()
+    close(od.grad, ori.grad, 1e-5, "ori grad")

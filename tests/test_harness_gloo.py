@@ -55,3 +55,34 @@ def test_two_rank_replica_harness(tmp_path):
     assert abs(t0 - 4 * 2 * 5 / e0) < 1e-9                # whole-job units / slowest time
     assert sorted(s0 + s1) == list(range(11)) and not set(s0) & set(s1)
     assert len(s0) == 6 and len(s1) == 5
+
+
+def _grad_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccvpe_amd import harness
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in ((300, 7), (5,), (64, 3, 3, 3), (1000,), (2, 2))]
+    params[1].requires_grad_(False)
+    for i, p in enumerate(params):
+        if p.requires_grad and i != 4:                   # params[4] has no gradient on any rank
+            p.grad = torch.full_like(p, float(rank + 1)) * (i + 1)
+    red = harness.GradientAllReducer(params, bucket_bytes=9000)      # forces several buckets
+    red()
+    res = [None if p.grad is None else p.grad.clone() for p in params]
+    if rank == 0:
+        torch.save((res, len(red.buckets)), out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_allreduce(tmp_path):
+    out = str(tmp_path / "grads.pt")
+    mp.spawn(_grad_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res, nb = torch.load(out, weights_only=False)
+    assert nb >= 3
+    for i in (0, 2, 3):
+        assert torch.allclose(res[i], torch.full_like(res[i], 1.5 * (i + 1)))     # mean of (1, 2) * (i + 1)
+    assert res[1] is None and res[4] is None
