@@ -100,7 +100,7 @@ PROTOTYPES = {
     "ccvpe_match_level_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int,
                                           c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                           c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ccvpe_infonce_loss_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ccvpe_infonce_loss_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_cross_entropy_loss_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_orientation_loss_bwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "ccvpe_conv_igemm_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),

@@ -67,4 +67,51 @@ template <> __device__ __forceinline__ void st4<cc_bf16>(cc_bf16* p, cc_f32x4 v)
   *reinterpret_cast<cc_bf16x4*>(p) = o;
 }
 
+// out[e] = sum_k part[k*stride + e]  (k < nparts, e < n): LN lanes per element walk the partial rows interleaved and
+// are combined through LDS in lane order -> fixed summation order (deterministic), and short serial chains even
+// when there are thousands of partial rows for a handful of elements (BatchNorm / bias / weight-gradient merges).
+template <int LN>
+__global__ __launch_bounds__(256) void sum_parts_lanes_kernel(const float* __restrict__ part, int nparts, long stride,
+                                                              int n, float* __restrict__ out) {
+  constexpr int EL = 256 / LN;
+  __shared__ float red[256];
+  const int el = threadIdx.x % EL, ln = threadIdx.x / EL;
+  const int e = blockIdx.x * EL + el;
+  float a0 = 0.f, a1 = 0.f;
+  if (e < n) {
+    int k = ln;
+    for (; k + LN < nparts; k += 2 * LN) {
+      a0 += part[(size_t)k * stride + e];
+      a1 += part[(size_t)(k + LN) * stride + e];
+    }
+    if (k < nparts) a0 += part[(size_t)k * stride + e];
+  }
+  if (LN == 1) {
+    if (e < n) out[e] = a0 + a1;
+    return;
+  }
+  red[ln * EL + el] = a0 + a1;
+  __syncthreads();
+  if (ln == 0 && e < n) {
+    float s = red[el];
+#pragma unroll 4
+    for (int q = 1; q < LN; ++q) s += red[q * EL + el];
+    out[e] = s;
+  }
+}
+
+inline void launch_sum_parts(const float* part, int nparts, long stride, int n, float* out, hipStream_t st) {
+  // enough workgroups to fill the chip when n is large, enough lanes per element when nparts is large
+  int ln = 1;
+  while (ln < 64 && nparts > 8 * ln && (long)n * ln < 256L * 1024) ln *= 4;
+  if (ln == 1)
+    hipLaunchKernelGGL((sum_parts_lanes_kernel<1>), dim3((n + 255) / 256), dim3(256), 0, st, part, nparts, stride, n, out);
+  else if (ln == 4)
+    hipLaunchKernelGGL((sum_parts_lanes_kernel<4>), dim3((n + 63) / 64), dim3(256), 0, st, part, nparts, stride, n, out);
+  else if (ln == 16)
+    hipLaunchKernelGGL((sum_parts_lanes_kernel<16>), dim3((n + 15) / 16), dim3(256), 0, st, part, nparts, stride, n, out);
+  else
+    hipLaunchKernelGGL((sum_parts_lanes_kernel<64>), dim3((n + 3) / 4), dim3(256), 0, st, part, nparts, stride, n, out);
+}
+
 }  // namespace ccvpe

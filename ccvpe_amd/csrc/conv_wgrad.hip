@@ -33,26 +33,43 @@ constexpr int WG_T = 64;    // tile: 64 output channels x 64 input channels
 constexpr int WG_BP = 32;   // pixels per stage
 constexpr int WG_LD = 68;   // LDS row stride (floats): 64 + 4
 
+// TN = output channels per tile (64, 32 or 16: the decoder's last levels have N = 16..32 and millions of pixels, a
+// 64-row tile would spend 4-16x the MFMA work on padding).  The 64 tile columns index (tap, input channel) jointly:
+// col = tap*Ctot + c, so narrow layers (Ctot = 16..48) fill the tile with several taps instead of zero columns.
+template <int TN>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  __shared__ __attribute__((aligned(16))) float Ys[2][WG_BP][WG_LD];   // dY  [pixel][n]
-  __shared__ __attribute__((aligned(16))) float Xs[2][WG_BP][WG_LD];   // X   [pixel][c]
+  constexpr int NI = TN >= 32 ? 2 : 1;              // 16-row MFMA tiles per wave along n
+  constexpr int NJ = TN == 64 ? 2 : 1;              // 16-col MFMA tiles per wave along columns
+  __shared__ __attribute__((aligned(16))) float Ys[2][WG_BP][TN + 4];   // dY  [pixel][n]
+  __shared__ __attribute__((aligned(16))) float Xs[2][WG_BP][WG_LD];    // X   [pixel][col]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wc = wave & 1;          // wave tile: 32 n x 32 c
+  const int wn = TN == 64 ? wave >> 1 : 0;          // TN == 64: 2 x 2 waves of 32 x 32;  else 4 waves of TN x 16
+  const int wc = TN == 64 ? wave & 1 : wave;
   int bid = blockIdx.x;
   const int tc = bid % p.tiles_c; bid /= p.tiles_c;
-  const int tn = bid % p.tiles_n; bid /= p.tiles_n;
-  const int tap = bid % p.taps;
-  const int split = bid / p.taps;
-  const int ky = tap / p.kw, kx = tap - ky * p.kw;
-  const int n0 = tn * WG_T, cc0 = tc * WG_T;
+  const int tn = bid % p.tiles_n;
+  const int split = bid / p.tiles_n;
+  const int n0 = tn * TN, cc0 = tc * WG_T;
   const int ctot = p.c0 + p.c1;
+  const int ncols = p.taps * ctot;
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(m_begin + p.pix_per_split, p.M);
 
-  // staging: thread -> (pixel row = tid >> 3 (0..31), 16-byte piece pair = tid & 7 -> pieces 2*(tid&7), +1)
+  // staging: thread -> (pixel row = tid >> 3 (0..31), two float4 pieces at tile column (tid & 7) * 8 + {0, 4})
   const int prow = tid >> 3;
-  const int pc = (tid & 7) * 8;                    // first channel of this thread's two float4 pieces
+  const int pc = (tid & 7) * 8;
+  int pky[2], pkx[2], pch[2];                        // per piece: tap offsets and input channel (stage-invariant)
+  bool pok[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int col = cc0 + pc + q * 4;
+    pok[q] = col < ncols;
+    const int tap = pok[q] ? col / ctot : 0;
+    pch[q] = col - tap * ctot;
+    pky[q] = tap / p.kw;
+    pkx[q] = tap - pky[q] * p.kw;
+  }
   f32x4 yr[2], xr[2];
 
   auto load_stage = [&](int m0) {
@@ -66,22 +83,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       oy = rem / p.Wo;
       ox = rem - oy * p.Wo;
     }
-    const int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
-    const bool inb = ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      const int n = n0 + pc + q * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok && n < p.N) {
-        if (n + 3 < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + n);
-        else
-          for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
+      if (pc + q * 4 < TN) {
+        const int n = n0 + pc + q * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok && n < p.N) {
+          if (n + 3 < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + n);
+          else
+            for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
+        }
+        yr[q] = v;
       }
-      yr[q] = v;
-      const int c = cc0 + pc + q * 4;
+      const int iy = oy * p.stride - p.pad + pky[q], ix = ox * p.stride - p.pad + pkx[q];
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (inb && c < ctot) {
+      if (ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
         const size_t pix = (size_t)(b * p.H + iy) * p.W + ix;
+        const int c = pch[q];
         u = (c < p.c0) ? *reinterpret_cast<const f32x4*>(p.src0 + pix * p.ld0 + c)
                        : *reinterpret_cast<const f32x4*>(p.src1 + pix * p.ld1 + (c - p.c0));
       }
@@ -91,16 +109,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      *reinterpret_cast<f32x4*>(&Ys[buf][prow][pc + q * 4]) = yr[q];
+      if (pc + q * 4 < TN) *reinterpret_cast<f32x4*>(&Ys[buf][prow][pc + q * 4]) = yr[q];
       *reinterpret_cast<f32x4*>(&Xs[buf][prow][pc + q * 4]) = xr[q];
     }
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[NI][NJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int fi = lane & 15, fq = lane >> 4;       // fragment: channel-in-tile, pixel-in-group
   const int nstage = (m_end - m_begin + WG_BP - 1) / WG_BP;
@@ -115,31 +133,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     if (more) load_stage(m_begin + (s + 1) * WG_BP);
 #pragma unroll
     for (int g = 0; g < WG_BP / 4; ++g) {
-      float a[2], bb[2];
+      float a[NI], bb[NJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) a[i] = Ys[buf][g * 4 + fq][(wn * 2 + i) * 16 + fi];
+      for (int i = 0; i < NI; ++i) a[i] = Ys[buf][g * 4 + fq][(wn * NI + i) * 16 + fi];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) bb[j] = Xs[buf][g * 4 + fq][(wc * 2 + j) * 16 + fi];
+      for (int j = 0; j < NJ; ++j) bb[j] = Xs[buf][g * 4 + fq][(wc * NJ + j) * 16 + fi];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
     }
     if (more) store_stage(buf ^ 1);
     __syncthreads();
   }
-  // D: row (n) = (lane>>4)*4 + reg, col (c) = lane&15
-  float* out = p.part + (size_t)split * p.N * p.taps * ctot;
+  // D: row (n) = (lane>>4)*4 + reg, col = lane&15.  dw layout [n][tap][c] == [n][col]
+  float* out = p.part + (size_t)split * p.N * ncols;
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < NI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = cc0 + (wc * 2 + j) * 16 + (lane & 15);
-      if (c >= ctot) continue;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = cc0 + (wc * NJ + j) * 16 + (lane & 15);
+      if (col >= ncols) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int n = n0 + (wn * 2 + i) * 16 + (lane >> 4) * 4 + r;
-        if (n < p.N) out[((size_t)n * p.taps + tap) * ctot + c] = acc[i][j][r];
+        const int n = n0 + (wn * NI + i) * 16 + (lane >> 4) * 4 + r;
+        if (n < p.N) out[(size_t)n * ncols + col] = acc[i][j][r];
       }
     }
 }
@@ -153,14 +171,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   dw[i] = s;
 }
 
-// per-channel column sums (bias gradients): partial per 256-row block then fixed-order reduce
+// per-channel column sums (bias gradients): partial per CS_ROWS-row block (all 256 threads busy: channel lanes x
+// row lanes, combined through LDS in lane order), then the fixed-order parallel reduce
+constexpr int CS_ROWS = 1024;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int C, int ld,
                                                             float* __restrict__ part) {
-  const int r0 = blockIdx.x * 256, r1 = min(r0 + 256, rows);
-  for (int c = threadIdx.x; c < C; c += 256) {
+  __shared__ float red[256];
+  const int cw = C < 256 ? C : 256;
+  const int R = 256 / cw;
+  const int cl = threadIdx.x % cw, rr = threadIdx.x / cw;
+  const int r0 = blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
+  for (int c0 = 0; c0 < C; c0 += cw) {
+    const int c = c0 + cl;
     float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += x[(size_t)r * ld + c];
-    part[(size_t)blockIdx.x * C + c] = s;
+    if (rr < R && c < C)
+      for (int r = r0 + rr; r < r1; r += R) s += x[(size_t)r * ld + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (rr == 0 && c < C) {
+      float t = red[cl];
+      for (int q = 1; q < R; ++q) t += red[q * cw + cl];
+      part[(size_t)blockIdx.x * C + c] = t;
+    }
+    __syncthreads();
   }
 }
 
@@ -169,7 +202,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 using namespace ccvpe;
 
 static int wgrad_splits(int M, int tiles, int taps) {
-  int S = 2048 / (tiles * taps > 0 ? tiles * taps : 1);
+  (void)taps;
+  int S = 2048 / (tiles > 0 ? tiles : 1);
   if (S < 1) S = 1;
   const int maxS = (M + WG_BP * 8 - 1) / (WG_BP * 8);
   if (S > maxS) S = maxS;
@@ -177,12 +211,15 @@ static int wgrad_splits(int M, int tiles, int taps) {
   return S < 1 ? 1 : S;
 }
 
+static int wgrad_tn(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+
 extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad,
                                                int ctot, int n) {
   const int Ho = (in_h + 2 * pad - kh) / stride + 1, Wo = (in_w + 2 * pad - kw) / stride + 1;
   const long M = (long)batch * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL || ctot <= 0 || n <= 0) return CCVPE_EINVAL;
-  const int tiles = ((n + WG_T - 1) / WG_T) * ((ctot + WG_T - 1) / WG_T);
+  const int tn = wgrad_tn(n);
+  const int tiles = ((n + tn - 1) / tn) * ((kh * kw * ctot + WG_T - 1) / WG_T);
   const int S = wgrad_splits((int)M, tiles, kh * kw);
   const long fl = (long)S * n * kh * kw * ctot;
   return fl > 0x7fffffffL ? CCVPE_EINVAL : (int)fl;
@@ -206,24 +243,27 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   if (M <= 0 || M > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv_wgrad: bad M");
   p.M = (int)M;
   const int ctot = c0 + c1;
-  p.tiles_n = (n + WG_T - 1) / WG_T;
-  p.tiles_c = (ctot + WG_T - 1) / WG_T;
+  const int tn = wgrad_tn(n);
+  p.tiles_n = (n + tn - 1) / tn;
+  p.tiles_c = (p.taps * ctot + WG_T - 1) / WG_T;
   p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps);
   p.pix_per_split = ((p.M + p.S - 1) / p.S + WG_BP - 1) / WG_BP * WG_BP;
   hipStream_t st = (hipStream_t)stream;
-  const long blocks = (long)p.tiles_n * p.tiles_c * p.taps * p.S;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  const long blocks = (long)p.tiles_n * p.tiles_c * p.S;
+  if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, p);
   const long n_elem = (long)n * p.taps * ctot;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((n_elem + 255) / 256)), dim3(256), 0, st, scratch, dw, n_elem, p.S);
+  launch_sum_parts(scratch, p.S, n_elem, (int)n_elem, dw, st);
   return check_launch("conv_wgrad");
 }
 
 extern "C" int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch,
                                 void* stream) {
   if (rows <= 0 || channels <= 0 || ld < channels) return fail(CCVPE_EINVAL, "colsum: bad shape");
-  const int nblk = (rows + 255) / 256;
+  const int nblk = (rows + CS_ROWS - 1) / CS_ROWS;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, scratch, out, (long)channels, nblk);
+  launch_sum_parts(scratch, nblk, channels, channels, out, st);
   return check_launch("colsum");
 }

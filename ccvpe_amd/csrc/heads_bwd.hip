@@ -312,7 +312,7 @@ extern "C" int ccvpe_head_conv3x3_bwd_f32(const float* x, const float* w, const 
   }
   // partials [nblk][cout][145] -> tmp [cout][145] (second half of scratch), then split into dw / dbias
   float* tmp = scratch + (size_t)CCVPE_HEAD_WGRAD_BLOCKS * 2 * 145;
-  hipLaunchKernelGGL(sum_parts2_kernel, dim3((cout * 145 + 255) / 256), dim3(256), 0, st, scratch, nblk, cout * 145, tmp);
+  launch_sum_parts(scratch, nblk, cout * 145, cout * 145, tmp, st);
   for (int o = 0; o < cout; ++o) {
     if (hipMemcpyAsync(dw + o * 144, tmp + o * 145, 144 * sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess ||
         hipMemcpyAsync(dbias + o, tmp + o * 145 + 144, sizeof(float), hipMemcpyDeviceToDevice, st) != hipSuccess)
@@ -365,7 +365,7 @@ extern "C" int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, f
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x_nchw, dy, scratch, batch, in_h, in_w, in_h / 2, in_w / 2,
                      circular);
-  hipLaunchKernelGGL(sum_parts2_kernel, dim3((27 * 32 + 255) / 256), dim3(256), 0, st, scratch, nblk, 27 * 32, dw);
+  launch_sum_parts(scratch, nblk, 27 * 32, 27 * 32, dw, st);
   return check_launch("stem_wgrad_kernel");
 }
 
@@ -379,8 +379,21 @@ extern "C" int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, f
 // ---------------------------------------------------------------------------------------------
 namespace ccvpe {
 
+__global__ __launch_bounds__(1024) void infonce_den_kernel(const float* __restrict__ lab, float* __restrict__ den_rows, int n) {
+  __shared__ float sh[16];
+  const float* l = lab + (size_t)blockIdx.x * n;
+  float d = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const float lv = l[i];
+    if (lv > 1e-2f) d += lv;
+  }
+  d = block_sum_b(d, sh);
+  if (threadIdx.x == 0) den_rows[blockIdx.x] = d;
+}
+
 __global__ __launch_bounds__(1024) void infonce_bwd_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
                                                            float inv_t, const float* __restrict__ dloss,
+                                                           const float* __restrict__ den_rows,
                                                            float* __restrict__ dsc, int n, int B) {
   __shared__ float sh[16];
   const float* s = sc + (size_t)blockIdx.x * n;
@@ -393,17 +406,8 @@ __global__ __launch_bounds__(1024) void infonce_bwd_kernel(const float* __restri
   }
   z = block_sum_b(z, sh);
   den = block_sum_b(den, sh);
-  // D: every workgroup recomputes the (tiny) batch total in the same order
-  float D = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float* lb = lab + (size_t)b * n;
-    float d = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-      const float lv = lb[i];
-      if (lv > 1e-2f) d += lv;
-    }
-    D += block_sum_b(d, sh);
-  }
+  float D = 0.f;                                   // batch total of the masked labels (same order in every workgroup)
+  for (int b = 0; b < B; ++b) D += den_rows[b];
   const float k = dloss[0] * inv_t / D;
   float* o = dsc + (size_t)blockIdx.x * n;
   for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -452,10 +456,11 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(const float* __restrict__ 
 }  // namespace ccvpe
 
 extern "C" int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
-                                          float* dscores, int batch, int n, void* stream) {
+                                          float* dscores, float* scratch, int batch, int n, void* stream) {
   if (batch <= 0 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce_bwd: bad args");
+  hipLaunchKernelGGL(infonce_den_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, labels, scratch, n);
   hipLaunchKernelGGL(infonce_bwd_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, scores, labels, 1.0f / temperature,
-                     dloss, dscores, n, batch);
+                     dloss, scratch, dscores, n, batch);
   return check_launch("infonce_bwd_kernel");
 }
 

@@ -249,8 +249,8 @@ extern "C" int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(p.nblk, batch);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), (size_t)P * cgx * 2 * 16, st, p, scratch);
-  hipLaunchKernelGGL(bn_bwd_merge_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, scratch, p.nblk * batch, channels,
-                     dbeta, dgamma);
+  launch_sum_parts(scratch, p.nblk * batch, 2L * channels, channels, dbeta, st);
+  launch_sum_parts(scratch + channels, p.nblk * batch, 2L * channels, channels, dgamma, st);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, p, dbeta, dgamma,
                      1.0f / ((float)batch * (float)rows_per_sample), dx);
   return check_launch("bn_act_bwd");
@@ -447,7 +447,7 @@ extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw
   else WG(5, 2);
 #undef WG
   const int n = k * k * channels;
-  hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 255) / 256), dim3(256), 0, st, scratch, nblk * batch, n, dw);
+  launch_sum_parts(scratch, nblk * batch, n, n, dw, st);
   return check_launch("dw_wgrad_kernel");
 }
 

@@ -29,8 +29,10 @@ class _InfoNCE(torch.autograd.Function):
         lib = _lib.load()
         out = torch.empty_like(s)
         g = dloss.reshape(1).contiguous().float()
+        scratch = torch.empty((s.shape[0],), device=s.device, dtype=torch.float32)
         check(lib.ccvpe_infonce_loss_bwd_f32(ops._ptr(s), ops._ptr(l), ctx.temperature, ops._ptr(g), ops._ptr(out),
-                                             s.shape[0], s.shape[1], ops._stream()), "ccvpe_infonce_loss_bwd_f32")
+                                             ops._ptr(scratch), s.shape[0], s.shape[1], ops._stream()),
+              "ccvpe_infonce_loss_bwd_f32")
         return out.reshape(ctx.shape), None, None
 
 

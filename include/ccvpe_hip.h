@@ -332,9 +332,10 @@ int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, 
                               const float* ddst, int ldo, float* dx, int lddx, float* dg, int ldg_out, float* scratch,
                               int batch, int hw, int channels, void* stream);
 
-/* Loss gradients w.r.t. the prediction (losses.py:4-29); dloss = upstream scalar gradient (device pointer). */
+/* Loss gradients w.r.t. the prediction (losses.py:4-29); dloss = upstream scalar gradient (device pointer).
+ * infoNCE scratch: batch floats. */
 int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
-                               float* dscores, int batch, int n, void* stream);
+                               float* dscores, float* scratch, int batch, int n, void* stream);
 int ccvpe_cross_entropy_loss_bwd_f32(const float* logits, const float* labels, const float* dloss, float* dlogits,
                                      int batch, int n, void* stream);
 int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const float* gt, const float* dloss,
