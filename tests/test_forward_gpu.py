@@ -99,14 +99,19 @@ def test_weights_repacked_after_update(synth_sd):
     assert torch.allclose(b, a + 1.0, atol=1e-5)
 
 
-def test_train_mode_outputs_carry_no_autograd_graph(synth_sd):
-    """Backward is not implemented: train-mode outputs must not pretend to be differentiable."""
+def test_train_mode_autograd_graph_only_when_grad_enabled(synth_sd):
+    """Train mode: outputs carry the model's single autograd node when grad is enabled (full check in
+    tests/test_train_backward_gpu.py); under torch.no_grad() they are plain tensors; eval outputs never do."""
     net = build("vigor_prior0", synth_sd).train()
     grd, sat = synth.synthetic_pair(1, "vigor", 3)
     out = net(grd.cuda(), sat.cuda())
+    assert out[0].requires_grad and out[3].requires_grad
+    assert tuple(out[3].shape)[1] == 20                      # ori_prior returns the recomputed 20-shift volume
+    with torch.no_grad():
+        out = net(grd.cuda(), sat.cuda())
     assert not out[0].requires_grad
-    with pytest.raises(RuntimeError):
-        out[0].sum().backward()
+    out = net.eval()(grd.cuda(), sat.cuda())
+    assert not out[0].requires_grad
 
 
 def test_hipgraph_replay_is_bit_identical(synth_sd):

@@ -15,7 +15,7 @@ from collections import defaultdict
 
 def family(name):
     """rocprof kernel name -> the name bench.py's launch recorder uses."""
-    m = re.search(r"(igemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)>", name)
+    m = re.search(r"(igemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)[,>]", name)
     if m:
         k, t, a, b, c = m.groups()
         if t == "float":
