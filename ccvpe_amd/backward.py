@@ -48,14 +48,16 @@ def deconv_wgrad(x, dy_hi):
     return g
 
 
-def bias_grad(dy):
+def bias_grad(dy, channels=None):
+    """Column sums of dy [.., ld]; `channels` restricts them to the first columns of wider pixel rows."""
     lib = _lib.load()
     ops._chk(dy, "dy")
-    c = dy.shape[-1]
-    rows = dy.numel() // c
+    ld = dy.shape[-1]
+    c = ld if channels is None else channels
+    rows = dy.numel() // ld
     out = torch.empty((c,), device=dy.device, dtype=torch.float32)
     scratch = torch.empty((((rows + 255) // 256) * c,), device=dy.device, dtype=torch.float32)
-    check(lib.ccvpe_colsum_f32(ops._ptr(dy), rows, c, c, ops._ptr(out), ops._ptr(scratch), ops._stream()), "ccvpe_colsum_f32")
+    check(lib.ccvpe_colsum_f32(ops._ptr(dy), rows, c, ld, ops._ptr(out), ops._ptr(scratch), ops._stream()), "ccvpe_colsum_f32")
     return out
 
 

@@ -174,24 +174,41 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // per-channel column sums (bias gradients): partial per CS_ROWS-row block (all 256 threads busy: channel lanes x
 // row lanes, combined through LDS in lane order), then the fixed-order parallel reduce
 constexpr int CS_ROWS = 1024;
+template <int V>   // V = 4: one 16-byte load per (row, 4 channels); V = 1: scalar (unaligned / odd channel counts)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int C, int ld,
                                                             float* __restrict__ part) {
-  __shared__ float red[256];
-  const int cw = C < 256 ? C : 256;
+  __shared__ __attribute__((aligned(16))) float red[256 * V];
+  const int cgn = C / V;
+  const int cw = cgn < 256 ? cgn : 256;
   const int R = 256 / cw;
   const int cl = threadIdx.x % cw, rr = threadIdx.x / cw;
   const int r0 = blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
-  for (int c0 = 0; c0 < C; c0 += cw) {
-    const int c = c0 + cl;
-    float s = 0.f;
-    if (rr < R && c < C)
-      for (int r = r0 + rr; r < r1; r += R) s += x[(size_t)r * ld + c];
-    red[threadIdx.x] = s;
+  for (int c0 = 0; c0 < cgn; c0 += cw) {
+    const int cg = c0 + cl;
+    float s[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) s[j] = 0.f;
+    if (rr < R && cg < cgn) {
+      for (int r = r0 + rr; r < r1; r += R) {
+        if (V == 4) {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(x + (size_t)r * ld + cg * 4);
+#pragma unroll
+          for (int j = 0; j < V; ++j) s[j] += v[j];
+        } else {
+          s[0] += x[(size_t)r * ld + cg];
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < V; ++j) red[threadIdx.x * V + j] = s[j];
     __syncthreads();
-    if (rr == 0 && c < C) {
-      float t = red[cl];
-      for (int q = 1; q < R; ++q) t += red[q * cw + cl];
-      part[(size_t)blockIdx.x * C + c] = t;
+    if (rr == 0 && cg < cgn) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float t = red[cl * V + j];
+        for (int q = 1; q < R; ++q) t += red[(q * cw + cl) * V + j];
+        part[(size_t)blockIdx.x * C + cg * V + j] = t;
+      }
     }
     __syncthreads();
   }
@@ -263,7 +280,10 @@ extern "C" int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, 
   if (rows <= 0 || channels <= 0 || ld < channels) return fail(CCVPE_EINVAL, "colsum: bad shape");
   const int nblk = (rows + CS_ROWS - 1) / CS_ROWS;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
+  if (channels % 4 == 0 && ld % 4 == 0 && aligned16(x))
+    hipLaunchKernelGGL((colsum_partial_kernel<4>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
+  else
+    hipLaunchKernelGGL((colsum_partial_kernel<1>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
   launch_sum_parts(scratch, nblk, channels, channels, out, st);
   return check_launch("colsum");
 }

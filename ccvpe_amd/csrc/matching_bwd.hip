@@ -8,7 +8,7 @@
 //     dg[k]  = sum_p sum_i a_i x[c : (c+off_i) mod C == k]  -  g[k]/G^2 * sum_p sum_i ds_i s_i
 // Same mapping as the forward (lane = pixel, 32-channel tiles transposed through LDS, wave-uniform LDS
 // broadcasts of the tables).  dg is a reduction over pixels: every (channel, shift) term is summed across
-// the wave with a butterfly and accumulated by lane 0 into a per-wave LDS vector; the workgroup writes
+// the workgroup's pixels through a small LDS GEMM (G[i][c] = sum_px a_i x_c) and folded into one LDS vector; the workgroup writes
 // one partial row [L+1] and a finishing kernel reduces the rows in fixed order (deterministic).
 #include "common.h"
 
@@ -37,8 +37,10 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
   float* ww = gg + 2 * C;               // [2C]
   float* xs = ww + 2 * C;               // [MBK][XLD]
   float* dd = xs + MBK * XLD;           // [MBK][XLD]
-  float* dgw = dd + MBK * XLD;          // [NW][L+1]
-  float* red = dgw + NW * (L + 1);      // [4]
+  float* as = dd + MBK * XLD;           // [n_shifts][TPB]  a_i of every pixel of the workgroup
+  float* Gs = as + n_shifts * TPB;      // [n_shifts][MBK]  G[i][c] = sum_px a_i(px) x(px, c) of the current tile
+  float* dgw = Gs + n_shifts * MBK;     // [L+1]
+  float* red = dgw + (L + 1);           // [4]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int b = blockIdx.y;
@@ -57,7 +59,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
     ww[k] = kk < L ? 1.f : 0.f;
     if (k < C) gsq = fmaf(v, v, gsq);
   }
-  for (int k = tid; k < NW * (L + 1); k += TPB) dgw[k] = 0.f;
+  for (int k = tid; k < L + 1; k += TPB) dgw[k] = 0.f;
   gsq = wave_sum(gsq);
   if (lane == 0) red[wv] = gsq;
   __syncthreads();
@@ -136,6 +138,9 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
       }
     }
   }
+#pragma unroll
+  for (int i = 0; i < NPAD; ++i)
+    if (i < n_shifts) as[i * TPB + tid] = a[i];
   const float xn = sqrtf(tot);
   const float k1 = 1.0f / fmaxf(xn, 1e-12f);
   const float k2 = xn > 1e-12f ? xd * k1 * k1 * k1 : 0.f;
@@ -169,14 +174,35 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
           if (kk < L) {
             acc = fmaf(a[i], gg[k], acc);
             acc = fmaf(-bq[i], xv, acc);
-            const float s = wave_sum(a[i] * xv);
-            if (lane == 0) dgw[wv * (L + 1) + kk] += s;
           }
         }
       }
       dd[cc * XLD + tid] = acc;
     }
+    // dg: G[i][c] = sum over the workgroup's pixels of a_i(px) * x(px, c) — every thread owns a few (i, c) entries and
+    // walks the pixels in LDS (independent FMAs; a first version summed every (c, i) term across the wave with a
+    // butterfly and spent 5 ms per launch on dependent ds_bpermute chains)
+    for (int e = tid; e < n_shifts * ck; e += TPB) {
+      const int i = e / ck, cc = e - i * ck;
+      const float* ap = as + i * TPB;
+      const float* xp = xs + cc * XLD;
+      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
+      for (int px = 0; px < TPB; px += 4) {
+        g0 = fmaf(ap[px], xp[px], g0);
+        g1 = fmaf(ap[px + 1], xp[px + 1], g1);
+        g2 = fmaf(ap[px + 2], xp[px + 2], g2);
+        g3 = fmaf(ap[px + 3], xp[px + 3], g3);
+      }
+      Gs[i * MBK + cc] = (g0 + g1) + (g2 + g3);
+    }
     __syncthreads();
+    if (tid < ck) {                    // one wave, lock-step: for a fixed shift the ck channels hit distinct dg entries
+      for (int i = 0; i < n_shifts; ++i) {
+        const int k = c0 + tid + mo.off[i];
+        const int kk = k >= C ? k - C : k;
+        if (kk < L) dgw[kk] += Gs[i * MBK + tid];
+      }
+    }
     for (int idx = tid; idx < TPB * F4; idx += TPB) {
       const int pp = idx / F4;
       const int cq = (idx - pp * F4) * 4;
@@ -190,13 +216,14 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
     __syncthreads();
   }
   T = wave_sum(T);
-  if (lane == 0) dgw[wv * (L + 1) + L] = T;
+  if (lane == 0) red[wv] = T;
   __syncthreads();
   float* out = part + ((size_t)b * nblk + blockIdx.x) * (L + 1);
-  for (int k = tid; k <= L; k += TPB) {
-    float s = 0.f;
-    for (int w = 0; w < NW; ++w) s += dgw[w * (L + 1) + k];
-    out[k] = s;
+  for (int k = tid; k < L; k += TPB) out[k] = dgw[k];
+  if (tid == 0) {
+    float t = 0.f;
+    for (int w = 0; w < NW; ++w) t += red[w];
+    out[L] = t;
   }
 }
 
@@ -241,7 +268,7 @@ static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, in
                             float* dx, int lddx, float* part, int B, int hw, int C, hipStream_t st) {
   const int tpb = match_bwd_tpb(hw);
   const int nblk = (hw + tpb - 1) / tpb;
-  const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 1) + (size_t)(tpb / 64) * (L + 1) + 4);
+  const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 1) + (size_t)n_shifts * (tpb + MBK) + (L + 1) + 4);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level_bwd: C=%d needs %zu B of LDS", C, smem);
   auto kern = match_bwd_kernel<NPAD>;
   if (smem > 64 * 1024) {

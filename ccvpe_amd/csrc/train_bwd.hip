@@ -327,22 +327,24 @@ __global__ __launch_bounds__(256) void dw_dgrad_kernel(const float* __restrict__
   *reinterpret_cast<f32x4*>(dx + (((size_t)b * H + iy) * W + ix) * C + c) = acc;
 }
 
-constexpr int DWW_ROWS = 4;   // output rows per workgroup
+// output rows per workgroup: small, so that even the 16x64 late blocks launch >= 1-2 K workgroups (the per-thread
+// loop is a chain of dependent gathers: it needs occupancy, not long rows)
+static inline int dww_rows(int Ho) { return Ho <= 64 ? 1 : (Ho <= 128 ? 2 : 4); }
 
 template <int K, int S>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                        float* __restrict__ part, int H, int W, int C, int Ho, int Wo,
-                                                       int circular, int nblk) {
+                                                       int circular, int nblk, int rows) {
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
-  extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx] float4
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [K][P][cgx] float4: one kernel row of taps per round
   const int b = blockIdx.y;
   const int cg4 = C >> 2;
   const int cgx = cg4 < 64 ? cg4 : 64;
   const int P = 256 / cgx;
   const int tid = threadIdx.x;
   const int cgl = tid % cgx, pl = tid / cgx;
-  const int oy0 = blockIdx.x * DWW_ROWS;
-  const int npx = min(DWW_ROWS, Ho - oy0) * Wo;
+  const int oy0 = blockIdx.x * rows;
+  const int npx = min(rows, Ho - oy0) * Wo;
   float* out = part + ((size_t)b * nblk + blockIdx.x) * K * K * C;
   const float* xb = x + (size_t)b * H * W * C;
   const float* dyb = dy + ((size_t)b * Ho + oy0) * Wo * C;
@@ -375,13 +377,20 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       }
     }
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
-      if (pl < P) red4[pl * cgx + cgl] = acc[t];
+    for (int ky = 0; ky < K; ++ky) {
+      if (pl < P) {
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) red4[(kx * P + pl) * cgx + cgl] = acc[ky * K + kx];
+      }
       __syncthreads();
-      if (pl == 0 && cg < cg4) {
-        f32x4 s = red4[cgl];
-        for (int q = 1; q < P; ++q) s += red4[q * cgx + cgl];
-        *reinterpret_cast<f32x4*>(out + (size_t)t * C + cg * 4) = s;
+      // K * cgx outputs, P partials each: spread over the workgroup
+      for (int i = tid; i < K * cgx; i += 256) {
+        const int kx = i / cgx, cl = i - kx * cgx;
+        if (cc + cl < cg4) {
+          f32x4 s = red4[(kx * P) * cgx + cl];
+          for (int q = 1; q < P; ++q) s += red4[(kx * P + q) * cgx + cl];
+          *reinterpret_cast<f32x4*>(out + (size_t)(ky * K + kx) * C + (cc + cl) * 4) = s;
+        }
       }
       __syncthreads();
     }
@@ -426,7 +435,8 @@ extern "C" int ccvpe_dwconv_dgrad_f32(const float* dy, const float* w, float* dx
 extern "C" int ccvpe_dwconv_wgrad_nblk(int in_h, int in_w, int k, int stride) {
   int Ho, Wo;
   dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
-  return (Ho + DWW_ROWS - 1) / DWW_ROWS;
+  const int rows = dww_rows(Ho);
+  return (Ho + rows - 1) / rows;
 }
 
 extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw, float* scratch, int batch, int in_h,
@@ -435,12 +445,13 @@ extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw
   if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(CCVPE_EINVAL, "dw_wgrad: k in {3,5}, stride in {1,2}");
   int Ho, Wo;
   dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
-  const int nblk = (Ho + DWW_ROWS - 1) / DWW_ROWS;
+  const int rows = dww_rows(Ho);
+  const int nblk = (Ho + rows - 1) / rows;
   const int cg4 = channels / 4, cgx = cg4 < 64 ? cg4 : 64, P = 256 / cgx;
   dim3 grid(nblk, batch);
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)P * cgx * 16;
-#define WG(K_, S_) hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_>), grid, dim3(256), lds, st, x, dy, scratch, in_h, in_w, channels, Ho, Wo, circular, nblk)
+  const size_t lds = (size_t)k * P * cgx * 16;
+#define WG(K_, S_) hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_>), grid, dim3(256), lds, st, x, dy, scratch, in_h, in_w, channels, Ho, Wo, circular, nblk, rows)
   if (k == 3 && stride == 1) WG(3, 1);
   else if (k == 3) WG(3, 2);
   else if (stride == 1) WG(5, 1);

@@ -19,52 +19,65 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BNS_ROWS = 256;   // rows per workgroup in the stats kernel
 
-// one thread per channel column slice: thread t handles channel (t % cw) for rows r = t / cw, +R, ...
+// thread = 4 consecutive channels (one 16-byte load per row) x row lane: thread t handles channel group
+// (t % cw) for rows r = t / cw, +R, ...
 __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ x, long rows, int C,
                                                                float* __restrict__ part /*[nblk][3][C]*/, int rows_per_block) {
-  extern __shared__ float sm[];   // [R][cw][3]
-  const int cw = C < 256 ? C : 256;
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [R][cw][3] float4
+  const int cg4 = C >> 2;
+  const int cw = cg4 < 256 ? cg4 : 256;
   const int R = 256 / cw;
   const int tid = threadIdx.x;
   const int cl = tid % cw, rr = tid / cw;
   const long r0 = (long)blockIdx.x * rows_per_block;
   const long r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
-  for (int c0 = 0; c0 < C; c0 += cw) {
-    const int c = c0 + cl;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (rr < R && c < C && r0 + rr < r1) {
+  f32x4* sm4 = reinterpret_cast<f32x4*>(sm);
+  for (int c0 = 0; c0 < cg4; c0 += cw) {
+    const int cg = c0 + cl;
+    f32x4 n = {0.f, 0.f, 0.f, 0.f}, mean = n, m2 = n;
+    if (rr < R && cg < cg4 && r0 + rr < r1) {
       // shifted sums around the slice's first value (a sample of the data, so |x - pivot| ~ sigma: no E[x^2]-E[x]^2
       // cancellation) — 2 FMAs per element instead of Welford's divide
-      const float pivot = x[(r0 + rr) * C + c];
-      float s = 0.f, q = 0.f;
+      const float* xc = x + cg * 4;
+      const f32x4 pivot = *reinterpret_cast<const f32x4*>(xc + (r0 + rr) * C);
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
+      float cnt = 0.f;
       for (long r = r0 + rr; r < r1; r += R) {
-        const float d = x[r * C + c] - pivot;
+        const f32x4 d = *reinterpret_cast<const f32x4*>(xc + r * C) - pivot;
         s += d;
-        q = fmaf(d, d, q);
-        n += 1.f;
+        q += d * d;
+        cnt += 1.f;
       }
-      mean = pivot + s / n;
-      m2 = fmaxf(q - s * s / n, 0.f);
+      const float inv = 1.0f / cnt;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        n[j] = cnt;
+        mean[j] = pivot[j] + s[j] * inv;
+        m2[j] = fmaxf(q[j] - s[j] * s[j] * inv, 0.f);
+      }
     }
-    sm[(rr * cw + cl) * 3 + 0] = n;
-    sm[(rr * cw + cl) * 3 + 1] = mean;
-    sm[(rr * cw + cl) * 3 + 2] = m2;
+    if (rr < R) {
+      sm4[(rr * cw + cl) * 3 + 0] = n;
+      sm4[(rr * cw + cl) * 3 + 1] = mean;
+      sm4[(rr * cw + cl) * 3 + 2] = m2;
+    }
     __syncthreads();
-    if (rr == 0 && c < C) {                              // Chan merge over the R row slices, fixed order
-      float na = sm[cl * 3], ma = sm[cl * 3 + 1], sa = sm[cl * 3 + 2];
+    if (rr == 0 && cg < cg4) {                           // Chan merge over the R row slices, fixed order
+      f32x4 na = sm4[cl * 3], ma = sm4[cl * 3 + 1], sa = sm4[cl * 3 + 2];
       for (int j = 1; j < R; ++j) {
-        const float nb = sm[(j * cw + cl) * 3], mb = sm[(j * cw + cl) * 3 + 1], sb = sm[(j * cw + cl) * 3 + 2];
-        if (nb > 0.f) {
-          const float nt = na + nb, d = mb - ma;
-          ma += d * (nb / nt);
-          sa += sb + d * d * (na * nb / nt);
-          na = nt;
+        const f32x4 nb = sm4[(j * cw + cl) * 3], mb = sm4[(j * cw + cl) * 3 + 1], sb = sm4[(j * cw + cl) * 3 + 2];
+        if (nb[0] > 0.f) {                               // the count is the same for the 4 channels of a thread
+          const float nt = na[0] + nb[0], f = nb[0] / nt, g = na[0] * nb[0] / nt;
+          const f32x4 d = mb - ma;
+          ma += d * f;
+          sa += sb + d * d * g;
+          na = (f32x4){nt, nt, nt, nt};
         }
       }
-      float* p = part + (size_t)blockIdx.x * 3 * C;
-      p[c] = na;
-      p[C + c] = ma;
-      p[2 * C + c] = sa;
+      float* p = part + (size_t)blockIdx.x * 3 * C + cg * 4;
+      *reinterpret_cast<f32x4*>(p) = na;
+      *reinterpret_cast<f32x4*>(p + C) = ma;
+      *reinterpret_cast<f32x4*>(p + 2 * C) = sa;
     }
     __syncthreads();
   }
@@ -203,14 +216,16 @@ extern "C" int ccvpe_bn_stats_nblk(int rows) {
 
 extern "C" int ccvpe_bn_stats_f32(const float* x, int rows, int channels, float* mean, float* var, float* run_mean,
                                   float* run_var, float momentum, float* scratch, void* stream) {
-  if (rows <= 0 || channels <= 0) return fail(CCVPE_EINVAL, "bn_stats: bad shape");
+  if (rows <= 0 || channels <= 0 || channels % 4) return fail(CCVPE_EINVAL, "bn_stats: bad shape (channels %% 4)");
+  if (!aligned16(x) || !aligned16(scratch)) return fail(CCVPE_EINVAL, "bn_stats: 16-byte alignment");
   if ((run_mean == nullptr) != (run_var == nullptr)) return fail(CCVPE_EINVAL, "bn_stats: run_mean/run_var both or none");
   int rpb, nblk, ng;
   bn_stats_geometry(rows, &rpb, &nblk, &ng);
-  const int cw = channels < 256 ? channels : 256;
+  const int cg4 = channels / 4;
+  const int cw = cg4 < 256 ? cg4 : 256;
   const int R = 256 / cw;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), (size_t)R * cw * 3 * sizeof(float), st, x, (long)rows,
+  hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk), dim3(256), (size_t)R * cw * 3 * 16, st, x, (long)rows,
                      channels, scratch, rpb);
   const float* fin = scratch;
   int nfin = nblk;

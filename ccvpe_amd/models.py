@@ -335,7 +335,10 @@ class _CVMBase(nn.Module):
         return tuple(key)
 
     def _packed(self):
-        key = (self.precision, self.training) + self._weights_key()
+        # running statistics are updated in place by the HIP kernels (no torch version bump): the eval pack (BN folded
+        # from them) additionally depends on how many train-mode forwards have run; the train pack does not use them
+        epoch = 0 if self.training else getattr(self, "_stats_epoch", 0)
+        key = (self.precision, self.training, epoch) + self._weights_key()
         if self._pack_cache is None or key != self._pack_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device

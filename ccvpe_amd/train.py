@@ -129,7 +129,7 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
                         ldd=_round_up(pk.gd_n, 4))
     gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
     svol, sfeats, st = encoder_forward(model, pk.sat, live, "sat_efficientnet", sat, False, True, drop_masks, rec)
-    model._pack_key = None          # running statistics changed in place: the folded (eval) pack is stale
+    model._stats_epoch = getattr(model, "_stats_epoch", 0) + 1      # the folded (eval) pack is stale now
     sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1], in_w=svol.shape[2],
                            kh=2, kw=2, stride=2, shift=pk.sd_bias)
     if rec:
@@ -275,7 +275,7 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
     # ConvTranspose2d(k2,s2): weight [Cin,Cout,2,2] (Cin in reference order), bias [Cout]
     w_ref = _p(live, deconv + ".weight")
     cout = w_ref.shape[1]
-    grads[deconv + ".bias"] = bw.bias_grad(dcat2)[:cout]
+    grads[deconv + ".bias"] = bw.bias_grad(dcat2, cout)
     dw_ours = bw.conv_wgrad(dcat2, cat, k, 2, 2, 2, 0, c0=cout)                 # [k, Cout, 2, 2], our row order
     grads[deconv + ".weight"] = _scatter_rows(torch.empty_like(w_ref), dw_ours, col_map)
     w_ours = w_ref.new_zeros((k,) + tuple(w_ref.shape[1:]))

@@ -106,6 +106,19 @@ def compare_grads(got, want, rel_l2=3e-2):
     return bad, float(np.median(rels))
 
 
+def grad_rel_errors(got, truth):
+    """{name: relative L2 error of got's sample vs truth's} for the tensors whose true gradient is not noise."""
+    top = float(truth["norms"].max())
+    out = {}
+    for n, tn in zip(truth["names"], truth["norms"]):
+        n = str(n)
+        if tn < 1e-6 * top or n == "conv1.2.bias":
+            continue
+        t, g = truth["g:" + n].astype(np.float64), got["g:" + n].astype(np.float64)
+        out[n] = float(np.linalg.norm(t - g) / np.linalg.norm(t))
+    return out
+
+
 RUNNING_STAT_SAMPLES = ("grd_efficientnet._bn0", "grd_efficientnet._blocks.3._bn1", "grd_efficientnet._blocks.15._bn2",
                         "sat_efficientnet._blocks.0._bn1", "sat_efficientnet._blocks.9._bn0", "sat_efficientnet._bn1")
 

@@ -35,7 +35,15 @@ def test_full_backward_vs_reference_autograd(synth_sd):
     got = G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()])
     bad, med = G.compare_grads(got, want)
     assert not bad, "%d/%d parameter gradients off: %s" % (len(bad), len(want["names"]), bad[:12])
-    assert med < 6e-3, med
+    # accuracy against the round-off-free gradient (float64 oracle, tools/make_golden_f64.py): the HIP path must be as
+    # accurate as the reference's own fp32 autograd, up to a factor for the different summation orders
+    truth = G.load("grad_vigor_trainmode_f64")
+    e_ref, e_got = G.grad_rel_errors(want, truth), G.grad_rel_errors(got, truth)
+    m_ref, m_got = float(np.median(list(e_ref.values()))), float(np.median(list(e_got.values())))
+    worst = sorted(((e_got[n] / max(e_ref[n], 1e-3), n, e_got[n], e_ref[n]) for n in e_got), reverse=True)[:5]
+    print("median rel err vs f64: reference %.3e, hip %.3e; vs reference %.3e; worst ratios %s" % (m_ref, m_got, med, worst))
+    assert m_got <= 3.0 * m_ref + 1e-3, (m_got, m_ref)
+    assert all(e_got[n] <= max(3e-2, 4.0 * e_ref[n]) for n in e_got), worst
 
 
 def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
