@@ -35,9 +35,15 @@ def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None):
         raise _lib.CcvpeError("ccvpe_conv_wgrad_scratch_floats rejected the shape")
     scratch = torch.empty((nfl,), device=x0.device, dtype=torch.float32)
     dw = torch.empty((n, kh * kw, ctot), device=x0.device, dtype=torch.float32)
+    rec = ops._recorder
+    ev0 = rec.begin() if rec is not None else None
     check(lib.ccvpe_conv_wgrad_f32(ops._ptr(x0), c0, ld0, ops._ptr(x1), c1, ld1, ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
                                    ops._ptr(scratch), b, h, w, kh, kw, stride, pad, n, ops._stream()),
           "ccvpe_conv_wgrad_f32")
+    if rec is not None:
+        m = dy.numel() // dy.shape[-1]
+        rec.end("conv_wgrad", "%dx%d s%d M%d N%d C%d" % (kh, kw, stride, m, n, ctot), 2.0 * m * n * kh * kw * ctot,
+                4.0 * (x0.numel() + (x1.numel() if x1 is not None else 0) + dy.numel()), ev0)
     return dw.reshape(n, kh, kw, ctot).permute(0, 3, 1, 2)                 # OIHW view
 
 

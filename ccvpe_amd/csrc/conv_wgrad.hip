@@ -220,11 +220,13 @@ using namespace ccvpe;
 
 static int wgrad_splits(int M, int tiles, int taps) {
   (void)taps;
-  int S = 2048 / (tiles > 0 ? tiles : 1);
+  // ~4 K workgroups: the stage loop is a chain of (global load -> LDS -> 8 MFMAs) with one stage of prefetch, so the
+  // narrow layers (1-3 tiles, millions of pixels) need many co-resident workgroups to hide the load latency
+  int S = 4096 / (tiles > 0 ? tiles : 1);
   if (S < 1) S = 1;
   const int maxS = (M + WG_BP * 8 - 1) / (WG_BP * 8);
   if (S > maxS) S = maxS;
-  if (S > 256) S = 256;
+  if (S > 1024) S = 1024;
   return S < 1 ? 1 : S;
 }
 

@@ -20,7 +20,7 @@ struct MatchOffsetsB {
   int off[CCVPE_MAX_SHIFTS];
 };
 
-constexpr int MBK = 32;
+constexpr int MBK = 16;   // channels per staged tile: two tiles (x, ddst) + the a_i table must leave room for >= 3 workgroups per CU
 
 template <int NPAD>
 __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ g,
