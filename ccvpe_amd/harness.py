@@ -75,7 +75,51 @@ class GradientAllReducer:
             self.buckets.append(cur)
         self._flat = None
 
+    # ---- overlapped mode: reduce inside the model's backward --------------------------------------------
+    def attach(self, model):
+        """Start the all-reduce of each gradient group as soon as the model's backward has produced it
+        (ccvpe_amd/train.py calls ready() after the decoders, after the aerial encoder and at the end): the
+        decoder group (~80 % of the bytes) travels over xGMI while the encoders' backward is still computing.
+        With the reducer attached, calling it after loss.backward() is a no-op for that step."""
+        model._grad_sync = self
+        return self
+
+    @staticmethod
+    def active():
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+    def begin(self):
+        self._pending, self._sent = [], set()
+
+    def ready(self, grads):
+        names = [n for n in grads if n not in self._sent and grads[n] is not None]
+        if not names:
+            return
+        self._sent.update(names)
+        shapes = [tuple(grads[n].shape) for n in names]
+        flat = torch.cat([grads[n].reshape(-1) for n in names])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((work, flat, names, shapes))
+
+    def finish(self, grads):
+        world = dist.get_world_size()
+        for work, flat, names, shapes in self._pending:
+            work.wait()
+            flat.mul_(1.0 / world)
+            off = 0
+            for n, shp in zip(names, shapes):
+                cnt = 1
+                for d in shp:
+                    cnt *= d
+                grads[n] = flat[off:off + cnt].view(shp)
+                off += cnt
+        self._pending = []
+        self._done_in_backward = True
+
     def __call__(self):
+        if getattr(self, "_done_in_backward", False):      # already averaged inside the backward of this step
+            self._done_in_backward = False
+            return
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
             return
         world = dist.get_world_size()

@@ -286,9 +286,12 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
                           ld0=dcat2.shape[-1])
 
 
-def backward_train(model, tape, gout):
+def backward_train(model, tape, gout, on_ready=None):
     """gout = gradients w.r.t. (logits, heatmap, x_ori, sc_1..sc_6) (None where unused).
-    Returns {parameter name: gradient in the parameter's own layout}."""
+    Returns {parameter name: gradient in the parameter's own layout}.
+    on_ready(grads): called three times with the dict of gradients finished so far — after the decoders / matching /
+    aerial descriptor (~80 % of the parameter bytes), after the aerial encoder, and at the end — so that a
+    data-parallel caller can start reducing them while the encoders' backward is still running."""
     spec = MODEL_SPECS[model.kind]
     n_rot = spec["n_rot"]
     pk = model._packed()
@@ -360,7 +363,11 @@ def backward_train(model, tape, gout):
     grads["sat_feature_to_descriptors.1.weight"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0).reshape(w_lin.shape)
     grads["sat_feature_to_descriptors.1.bias"] = bw.bias_grad(dsdesc)
     dsvol = bw.conv2x2s2_dgrad(dsdesc, w4)
+    if on_ready is not None:
+        on_ready(grads)
     encoder_backward(pk.sat, live, "sat_efficientnet", tape["sat"], dsvol, dfeats, False, grads)
+    if on_ready is not None:
+        on_ready(grads)
 
     # ---- ground descriptors (models.py:57-97,153-165) ---------------------------------------------------------
     y1, gfeat = tape["y1"], tape["gfeat"]
@@ -384,6 +391,8 @@ def backward_train(model, tape, gout):
     wpad[:n] = wcat
     dgfeat = ops.conv_igemm(dy1, ld, bw._pack_conv(wpad.permute(1, 0, 2, 3)), 1280, batch=b, in_h=gh, in_w=gw)
     encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], grads)
+    if on_ready is not None:
+        on_ready(grads)
     return grads
 
 
@@ -402,8 +411,14 @@ class CVMFunction(torch.autograd.Function):
         model, tape, names = ctx.model, ctx.tape, ctx.names
         if tape is None:
             raise RuntimeError("ccvpe_amd: backward through the same forward twice is not supported")
+        sync = getattr(model, "_grad_sync", None)          # harness.GradientAllReducer.attach(model)
         with torch.no_grad():
-            grads = backward_train(model, tape, gout)
+            if sync is not None and sync.active():
+                sync.begin()
+                grads = backward_train(model, tape, gout, on_ready=sync.ready)
+                sync.finish(grads)
+            else:
+                grads = backward_train(model, tape, gout)
         ctx.tape = None
         live = model.state_dict(keep_vars=True)
         out = []

@@ -86,3 +86,38 @@ def test_two_rank_gradient_allreduce(tmp_path):
     for i in (0, 2, 3):
         assert torch.allclose(res[i], torch.full_like(res[i], 1.5 * (i + 1)))     # mean of (1, 2) * (i + 1)
     assert res[1] is None and res[4] is None
+
+
+def _overlap_worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from ccvpe_amd import harness
+    red = harness.GradientAllReducer([])
+    assert red.active()
+    red.begin()
+    grads = {}
+    # three groups arriving one after the other, with a permuted (non-contiguous) gradient and a None in between
+    grads["a"] = torch.full((4, 3), float(rank + 1))
+    grads["b"] = torch.arange(24.0).reshape(2, 3, 4).permute(0, 2, 1) * (rank + 1)
+    red.ready(grads)
+    grads["c"] = None
+    grads["d"] = torch.full((7,), 10.0 * (rank + 1))
+    red.ready(grads)
+    red.ready(grads)                                  # nothing new: must be a no-op
+    red.finish(grads)
+    if rank == 0:
+        torch.save(grads, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_overlapped_gradient_groups(tmp_path):
+    """The in-backward (overlapped) path of GradientAllReducer: groups are reduced as they become ready."""
+    out = str(tmp_path / "ov.pt")
+    mp.spawn(_overlap_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    g = torch.load(out, weights_only=False)
+    assert torch.allclose(g["a"], torch.full((4, 3), 1.5))
+    assert torch.allclose(g["b"], torch.arange(24.0).reshape(2, 3, 4).permute(0, 2, 1) * 1.5)
+    assert g["c"] is None and torch.allclose(g["d"], torch.full((7,), 15.0))
