@@ -81,53 +81,29 @@ def cpu_baseline(sd, batch=8, reps=3):
                 sample="oracle forward, CVM_VIGOR_ori_prior(0), B=%d fp32, 1 warm-up + median of %d" % (batch, reps))
 
 
-def synthetic_targets(batch, n_rot, seed, dev):
-    """Ground truth of the shapes the training scripts build (datasets.py:145-166,489-501): a Gaussian (sigma 4 px) at a
-    seeded offset on the 512x512 grid, the (cos, sin) map of a seeded heading and its orientation bin."""
-    import math
-    import torch
-    from ccvpe_amd import synth
-    u = synth.uniform((batch, 3), seed)
-    ys = torch.arange(512, dtype=torch.float32).view(1, 512, 1)
-    xs = torch.arange(512, dtype=torch.float32).view(1, 1, 512)
-    cy = (64 + 384 * u[:, 0]).view(-1, 1, 1)
-    cx = (64 + 384 * u[:, 1]).view(-1, 1, 1)
-    gt = torch.exp(-((ys - cy) ** 2 + (xs - cx) ** 2) / (2 * 4.0 ** 2))
-    gt = (gt / gt.sum(dim=(1, 2), keepdim=True)).unsqueeze(1)                      # [B,1,512,512]
-    ang = 2 * math.pi * u[:, 2]
-    gt_ori = torch.stack([torch.cos(ang), torch.sin(ang)], 1).view(batch, 2, 1, 1).expand(batch, 2, 512, 512).contiguous()
-    bins = torch.clamp((u[:, 2] * n_rot).long(), max=n_rot - 1)
-    return gt.to(dev), gt_ori.to(dev), bins.to(dev)
-
-
 def train_main(args, net, grd, sat, dev, world, rank, n_rot):
     """One training step as train_VIGOR.py:193-229 / train_KITTI.py run it: forward (train mode), the three losses on
     all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam."""
     import torch
-    import torch.nn.functional as F
-    from ccvpe_amd import harness, losses
+    from ccvpe_amd import harness, losses, optim, synth, targets
     net.train()
-    gt, gt_ori, bins = synthetic_targets(args.batch, n_rot, 99 + rank, dev)
-    gt_flat = gt.reshape(args.batch, -1)
-    # per-level matching labels: the heat-map pooled to the level's grid, placed in the true orientation bin
-    labels = []
-    for lvl in range(6):
-        hw = 8 << lvl
-        pooled = F.adaptive_avg_pool2d(gt, hw) * (512 // hw) ** 2                   # [B,1,hw,hw], sums to 1
-        lab = torch.zeros((args.batch, n_rot, hw, hw), device=dev)
-        lab[torch.arange(args.batch, device=dev), bins] = pooled[:, 0]
-        labels.append(lab.reshape(args.batch, -1))
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    # ground truth as datasets.py builds it (Gaussian sigma 4 px at a seeded offset, orientation bins, (cos, sin) map) and
+    # train_VIGOR.py:120-128 pools it — generated on the device from 3 scalars per sample (ccvpe_train_targets_f32)
+    u = synth.uniform((args.batch, 3), 99 + rank)
+    center = ((u[:, :2] - 0.5) * 384.0).to(dev)
+    angle = (u[:, 2] * 359.99).to(dev)
+    opt = optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))                 # train_VIGOR.py:104, one launch per step
     reducer = harness.GradientAllReducer(net.parameters()).attach(net)     # all-reduce overlapped with the backward
     last = {}
 
     def step():
         opt.zero_grad(set_to_none=True)
+        gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, n_rot)
         out = net(grd, sat)
-        loss = losses.cross_entropy_loss(out[0], gt_flat) + losses.orientation_loss(out[2], gt_ori, gt)
-        for lvl in range(6):
-            sc = out[3 + lvl]
-            loss = loss + losses.infoNCELoss(sc.reshape(args.batch, -1), labels[lvl]) / 6.0
+        nce = 0.0
+        for lvl in range(6):                                                        # train_VIGOR.py:137-146
+            nce = nce + losses.infoNCELoss(torch.flatten(out[3 + lvl], start_dim=1), torch.flatten(labels[lvl], start_dim=1))
+        loss = losses.cross_entropy_loss(out[0], gt_flat) + 1e4 * nce / 6 + 1e1 * losses.orientation_loss(out[2], gt_ori, gt)
         loss.backward()
         reducer()
         opt.step()
@@ -141,8 +117,8 @@ def train_main(args, net, grd, sat, dev, world, rank, n_rot):
             "unit": "img-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %s training step (train-mode forward, CE + orientation + 6x infoNCE losses, "
-                                   "backward, gradient all-reduce, Adam lr 1e-4)" % type(net).__name__,
+            "config": {"workload": "C3: %s training step (device-side ground truth, train-mode forward, loss = CE + 1e4 * mean of 6 "
+                                   "infoNCE + 10 * orientation, backward, gradient all-reduce, Adam lr 1e-4)" % type(net).__name__,
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d (RCCL all-reduce of gradients in 3 groups, overlapped with the backward)" % world,
                        "loss_after_last_step": round(float(last["loss"]), 5),

@@ -103,6 +103,10 @@ PROTOTYPES = {
     "ccvpe_infonce_loss_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_cross_entropy_loss_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_orientation_loss_bwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "ccvpe_train_targets_nblk": (c_int, [c_int, c_int]),
+    "ccvpe_train_targets_f32": (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_adam_chunk_elems": (c_int, []),
+    "ccvpe_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [ctypes.c_double] * 4 + [c_int, c_void_p]),
     "ccvpe_conv_igemm_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "ccvpe_stem_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
@@ -114,6 +118,9 @@ PROTOTYPES = {
 }
 
 _lib = None
+# bumped by anything that rewrites parameters behind torch's back (ccvpe_amd.optim.Adam updates them in place with a HIP
+# kernel, which does not touch torch's version counters); the models' packed-weight cache keys on it
+weights_epoch = 0
 
 
 def build(verbose=False):

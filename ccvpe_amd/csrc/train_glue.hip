@@ -1,0 +1,161 @@
+// Training-step glue on the device: the ground-truth tensors the training scripts build on the
+// host and copy over (24 MB per sample) are generated here from 3 scalars per sample, and Adam runs as ONE launch
+// over all parameter tensors.
+//
+// Targets (datasets.py:145-166 VIGOR, :470-501 KITTI; train_VIGOR.py:120-128):
+//   x_j = -W/2 + cx + j*W/(W-1),  y_i = -H/2 + cy + i*H/(H-1)         (np.linspace, both ends included)
+//   gt[b,0,i,j]        = exp(-(x_j^2 + y_i^2) / (2 sigma^2))            (VIGOR: cx = col_offset, cy = -row_offset;
+//                                                                        KITTI: cx = x_offset,  cy = y_offset)
+//   gt_norm[b, i*W+j]  = gt / sum(gt)                                   (train_VIGOR.py:120-121)
+//   gt_ori[b,{0,1},:,:] = cos / sin (angle)                             (datasets.py:163-164)
+//   label_l[b,bin,Y,X] = w_bin * max_{k x k cell} gt,  k = 64 >> l      (MaxPool2d(k,k) of gt_with_ori, never materialised)
+//     bins: index = floor(angle / width), ratio = (angle mod width)/width;
+//           index == 0: w[0] = 1-ratio, w[n-1] = ratio;  else w[n-index] = 1-ratio, w[n-index-1] = ratio
+//   The cell maximum is separable (exp and fl(x^2+y^2) are monotone): exp(-(min_j x_j^2 + min_i y_i^2)/(2 sigma^2)),
+//   which equals the max-pool of the fp32 gt values exactly.
+#include "common.h"
+
+namespace ccvpe {
+
+__device__ __forceinline__ float coord(int j, int n, float c) { return -0.5f * n + c + j * ((float)n / (float)(n - 1)); }
+
+constexpr int TG_PIX = 1024;   // pixels per workgroup of the gt kernel
+
+__global__ __launch_bounds__(256) void targets_gt_kernel(const float* __restrict__ center, const float* __restrict__ angle,
+                                                         float inv2s2, float* __restrict__ gt, float* __restrict__ gt_ori,
+                                                         float* __restrict__ part, int H, int W, int nblk) {
+  __shared__ float sh[4];
+  const int b = blockIdx.y;
+  const float cx = center[2 * b], cy = center[2 * b + 1];
+  const float a = angle[b] * 0.017453292519943295f;
+  const float ca = cosf(a), sa = sinf(a);
+  const int hw = H * W;
+  float s = 0.f;
+  for (int p = blockIdx.x * TG_PIX + threadIdx.x; p < min((blockIdx.x + 1) * TG_PIX, hw); p += 256) {
+    const int i = p / W, j = p - i * W;
+    const float x = coord(j, W, cx), y = coord(i, H, cy);
+    const float v = expf(-(x * x + y * y) * inv2s2);
+    gt[(size_t)b * hw + p] = v;
+    gt_ori[(size_t)b * 2 * hw + p] = ca;
+    gt_ori[(size_t)b * 2 * hw + hw + p] = sa;
+    s += v;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[(size_t)b * nblk + blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+__global__ __launch_bounds__(256) void targets_norm_kernel(const float* __restrict__ gt, const float* __restrict__ part,
+                                                           float* __restrict__ gt_norm, int hw, int nblk) {
+  const int b = blockIdx.y;
+  float tot = 0.f;
+  for (int k = 0; k < nblk; ++k) tot += part[(size_t)b * nblk + k];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p < hw) gt_norm[(size_t)b * hw + p] = gt[(size_t)b * hw + p] / tot;
+}
+
+struct PyramidPtrs {
+  float* lab[6];
+};
+
+__global__ __launch_bounds__(256) void targets_pyramid_kernel(const float* __restrict__ center, const float* __restrict__ angle,
+                                                              float inv2s2, int n_bins, float bin_width,
+                                                              const PyramidPtrs out, int H, int W) {
+  const int b = blockIdx.y, l = blockIdx.z;
+  const int k = 64 >> l;
+  const int hl = H / k, wl = W / k;
+  const int cell = blockIdx.x * 256 + threadIdx.x;
+  if (cell >= hl * wl) return;
+  const int Y = cell / wl, X = cell - Y * wl;
+  const float cx = center[2 * b], cy = center[2 * b + 1];
+  float mx = 3.0e38f, my = 3.0e38f;
+  for (int t = 0; t < k; ++t) {
+    const float x = coord(X * k + t, W, cx), y = coord(Y * k + t, H, cy);
+    mx = fminf(mx, x * x);
+    my = fminf(my, y * y);
+  }
+  const float v = expf(-(mx + my) * inv2s2);
+  const float ang = angle[b];
+  const int index = (int)floorf(ang / bin_width);
+  const float ratio = (ang - index * bin_width) / bin_width;
+  const int b0 = index == 0 ? 0 : n_bins - index;
+  const int b1 = index == 0 ? n_bins - 1 : n_bins - index - 1;
+  float* o = out.lab[l] + (size_t)b * n_bins * hl * wl + cell;
+  for (int q = 0; q < n_bins; ++q) {
+    float w = 0.f;
+    if (q == b0) w = 1.0f - ratio;
+    if (q == b1) w = (b1 == b0) ? w : ratio;
+    o[(size_t)q * hl * wl] = w * v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics, train_VIGOR.py:104: lr, betas=(0.9, 0.999), eps 1e-8, no weight decay,
+// no amsgrad) over a table of tensors: one launch updates every parameter.
+//   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// ---------------------------------------------------------------------------------------------
+constexpr int ADAM_CHUNK = 4096;   // elements per workgroup
+
+__global__ __launch_bounds__(256) void adam_kernel(const long long* __restrict__ table /*[n][5]: p, g, m, v, numel*/,
+                                                   const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_off,
+                                                   float lr, float b1, float b2, float omb1, float omb2, float eps, float bc1,
+                                                   float bc2_sqrt) {
+  const int t = chunk_tensor[blockIdx.x];
+  const long long* row = table + (size_t)t * 5;
+  float* p = reinterpret_cast<float*>(row[0]);
+  const float* g = reinterpret_cast<const float*>(row[1]);
+  float* m = reinterpret_cast<float*>(row[2]);
+  float* v = reinterpret_cast<float*>(row[3]);
+  const long long n = row[4];
+  if (g == nullptr) return;
+  const long long base = (long long)chunk_off[blockIdx.x] * ADAM_CHUNK;
+  const float step = lr / bc1;       // torch: step_size = lr / bias_correction1
+  for (long long i = base + threadIdx.x; i < min(base + ADAM_CHUNK, n); i += 256) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + omb1 * gi;          // 1 - beta computed in double on the host, as torch does
+    const float vi = b2 * v[i] + omb2 * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+  }
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+extern "C" int ccvpe_train_targets_nblk(int h, int w) { return (h * w + TG_PIX - 1) / TG_PIX; }
+
+extern "C" int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
+                                       float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
+                                       float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream) {
+  if (batch <= 0 || h < 64 || w < 64 || h % 64 || w % 64) return fail(CCVPE_EINVAL, "train_targets: h, w must be multiples of 64");
+  if (n_bins < 2 || sigma <= 0.f) return fail(CCVPE_EINVAL, "train_targets: bad n_bins / sigma");
+  hipStream_t st = (hipStream_t)stream;
+  const float inv2s2 = 1.0f / (2.0f * sigma * sigma);
+  const int nblk = ccvpe_train_targets_nblk(h, w);
+  hipLaunchKernelGGL(targets_gt_kernel, dim3(nblk, batch), dim3(256), 0, st, center_xy, angle_deg, inv2s2, gt, gt_ori, scratch, h,
+                     w, nblk);
+  hipLaunchKernelGGL(targets_norm_kernel, dim3((h * w + 255) / 256, batch), dim3(256), 0, st, gt, scratch, gt_norm, h * w, nblk);
+  PyramidPtrs pp;
+  pp.lab[0] = lab1; pp.lab[1] = lab2; pp.lab[2] = lab3; pp.lab[3] = lab4; pp.lab[4] = lab5; pp.lab[5] = lab6;
+  const int cells = (h / 2) * (w / 2);
+  hipLaunchKernelGGL(targets_pyramid_kernel, dim3((cells + 255) / 256, batch, 6), dim3(256), 0, st, center_xy, angle_deg, inv2s2,
+                     n_bins, 360.0f / n_bins, pp, h, w);
+  return check_launch("train_targets");
+}
+
+extern "C" int ccvpe_adam_chunk_elems(void) { return ADAM_CHUNK; }
+
+extern "C" int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* chunk_off, int n_chunks, double lr,
+                                   double beta1, double beta2, double eps, int step, void* stream) {
+  if (n_chunks <= 0 || step < 1) return fail(CCVPE_EINVAL, "adam_step: bad args");
+  // bias corrections in double on the host, as torch.optim.Adam does with Python floats
+  const double bc1 = 1.0 - pow(beta1, (double)step);
+  const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(table),
+                     chunk_tensor, chunk_off, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
+                     (float)eps, (float)bc1, (float)bc2s);
+  return check_launch("adam_kernel");
+}

@@ -329,7 +329,8 @@ class _CVMBase(nn.Module):
 
     # -- weight version tracking -------------------------------------------------------------
     def _weights_key(self):
-        key = []
+        from . import _lib
+        key = [_lib.weights_epoch]
         for t in list(self.parameters()) + list(self.buffers()):
             key.append((t.data_ptr(), t._version))
         return tuple(key)

@@ -342,6 +342,29 @@ int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const 
                                    float* dori, int batch, int hw, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Training-step glue on the device (csrc/train_glue.hip).
+ *   ccvpe_train_targets_f32: the ground-truth tensors of datasets.py:145-166 (VIGOR) / :470-501 (KITTI) and
+ *     train_VIGOR.py:120-128 from 3 scalars per sample instead of 24 MB of host tensors:
+ *       center_xy [B][2] = (cx, cy) with x_j = -W/2 + cx + j*W/(W-1), y_i = -H/2 + cy + i*H/(H-1)
+ *                          (VIGOR: cx = col_offset, cy = -row_offset; KITTI: cx = x_offset, cy = y_offset)
+ *       angle_deg [B] in [0, 360);  n_bins 20 (VIGOR) / 16 (KITTI);  sigma 4
+ *     writes gt [B,1,H,W], gt_norm [B,H*W] (= gt / sum gt), gt_ori [B,2,H,W] (cos, sin) and the six max-pooled
+ *     orientation-binned label maps lab_l [B,n_bins,H/k,W/k], k = 64,32,16,8,4,2 (gt_with_ori is never materialised).
+ *     scratch: batch * ccvpe_train_targets_nblk(h, w) floats.
+ *   ccvpe_adam_step_f32: torch.optim.Adam (no weight decay / amsgrad; train_VIGOR.py:104) for ALL parameter tensors in
+ *     one launch.  table [n_tensors][5] int64 device array of (param, grad, exp_avg, exp_avg_sq, numel) — a NULL grad
+ *     skips the tensor; chunk_tensor / chunk_off [n_chunks] map each workgroup to (tensor, chunk of
+ *     ccvpe_adam_chunk_elems() elements).  step = 1-based step count.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_train_targets_nblk(int h, int w);
+int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
+                            float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
+                            float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream);
+int ccvpe_adam_chunk_elems(void);
+int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* chunk_off, int n_chunks, double lr,
+                        double beta1, double beta2, double eps, int step, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers

@@ -286,6 +286,44 @@ def orientation_loss(ori, gt_orientation, gt):
 
 
 # ----------------------------------------------------------------------------------------
+# training ground truth (what the datasets build per sample and the training loop max-pools)
+# ----------------------------------------------------------------------------------------
+def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0):
+    """datasets.py:145-166 (VIGOR: 20 bins of 18 deg; cx = col_offset, cy = -row_offset) and :470-501 (KITTI: 16 bins of
+    22.5 deg; cx = x_offset, cy = y_offset), then train_VIGOR.py:120-128: gt, gt / sum(gt), the (cos, sin) map and
+    MaxPool2d(k, k)(gt_with_ori) for k = 64..2.  numpy float64 -> float32 exactly as the reference does."""
+    import numpy as np
+    bw = 360.0 / n_bins
+    gts, oris, gwo = [], [], []
+    for (cx, cy), ang in zip(np.asarray(center_xy, dtype=np.float64), np.asarray(angle_deg, dtype=np.float64)):
+        x, y = np.meshgrid(np.linspace(-width / 2 + cx, width / 2 + cx, width),
+                           np.linspace(-height / 2 + cy, height / 2 + cy, height))
+        d = np.sqrt(x * x + y * y)
+        g = np.exp(-(d ** 2 / (2.0 * sigma ** 2))).astype(np.float32)
+        w = np.zeros([n_bins, height, width], dtype=np.float32)
+        index = int(ang // bw)
+        ratio = (ang % bw) / bw
+        if index == 0:
+            w[0] = g * (1 - ratio)
+            w[n_bins - 1] = g * ratio
+        else:
+            w[n_bins - index] = g * (1 - ratio)
+            w[n_bins - index - 1] = g * ratio
+        gts.append(g[None])
+        gwo.append(w)
+        o = np.empty([2, height, width], dtype=np.float32)
+        o[0] = np.cos(ang * np.pi / 180)
+        o[1] = np.sin(ang * np.pi / 180)
+        oris.append(o)
+    gt = torch.tensor(np.stack(gts))
+    gt_with_ori = torch.tensor(np.stack(gwo))
+    flat = torch.flatten(gt, start_dim=1)
+    flat = flat / torch.sum(flat, dim=1, keepdim=True)
+    labs = [F.max_pool2d(gt_with_ori, k, stride=k) for k in (64, 32, 16, 8, 4, 2)]
+    return gt, flat, torch.tensor(np.stack(oris)), labs
+
+
+# ----------------------------------------------------------------------------------------
 # evaluation post-processing
 # ----------------------------------------------------------------------------------------
 def eval_postprocess(heatmap, ori):

@@ -47,6 +47,8 @@ def test_ctypes_prototypes_match_header_signatures():
                 assert a is ctypes.c_void_p or issubclass(a, ctypes._Pointer), (name, q, a)
             elif q.startswith("float"):
                 assert a is ctypes.c_float, (name, q, a)
+            elif q.startswith("double"):
+                assert a is ctypes.c_double, (name, q, a)
             else:
                 assert a is ctypes.c_int, (name, q, a)
 

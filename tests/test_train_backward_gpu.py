@@ -60,6 +60,21 @@ def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
     opt.step()
     changed = sum(int(not torch.equal(before[n], p.detach())) for n, p in net1.named_parameters())
     assert changed >= 480          # 520 tensors receive a gradient, 26 of them exactly zero
+    # the one-launch HIP Adam (ccvpe_amd.optim) on the twin model: same update, and the packed weights are refreshed
+    from ccvpe_amd import optim
+    c = G.TRAIN_CASE
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    with torch.no_grad():
+        pre = net2.eval()(grd.cuda(), sat.cuda())[0].clone()
+    optim.Adam(net2.parameters(), lr=1e-4, betas=(0.9, 0.999)).step()
+    for (n, p), (_, q) in zip(net1.named_parameters(), net2.named_parameters()):
+        assert torch.allclose(p.detach(), q.detach(), rtol=1e-5, atol=1e-7), n
+    with torch.no_grad():
+        post2 = net2.eval()(grd.cuda(), sat.cuda())[0]
+        post1 = net1.eval()(grd.cuda(), sat.cuda())[0]
+    scale = post1.abs().max().item()
+    assert (post2 - pre).abs().max().item() > 1e-3 * scale            # the step is visible in the next forward
+    assert (post2 - post1).abs().max().item() < 1e-3 * scale          # and equals torch.optim.Adam's step
 
 
 @pytest.mark.parametrize("kind,ori_noise,circular", [("kitti", None, False), ("vigor", 36, True)])

@@ -1,0 +1,65 @@
+"""Training-step glue on the device: ground-truth construction and the one-launch Adam."""
+import numpy as np
+import pytest
+import torch
+
+from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_bins,angles", [(20, [0.0, 7.5, 18.0, 200.25, 359.9]), (16, [0.0, 22.5, 100.0, 337.6, 359.0])])
+def test_train_targets_vs_dataset_restatement(n_bins, angles):
+    from ccvpe_amd import targets
+    centers = [[0.0, 0.0], [37.0, -120.0], [-200.0, 55.0], [255.0, 255.0], [-3.0, 1.0]]
+    want = O.train_targets(centers, angles, n_bins)
+    got = targets.train_targets(torch.tensor(centers).cuda(), torch.tensor(angles).cuda(), n_bins)
+    names = ("gt", "gt_flattened", "gt_orientation")
+    for nm, g, w in zip(names, got[:3], want[:3]):
+        g = g.cpu()
+        assert g.shape == w.shape, nm
+        assert (g - w).abs().max().item() <= 2e-6 * w.abs().max().item() + 1e-12, nm
+    for l, (g, w) in enumerate(zip(got[3], want[3])):
+        g = g.cpu()
+        assert g.shape == w.shape
+        assert (g - w).abs().max().item() <= 1e-5, "pyramid level %d" % (l + 1)
+        assert torch.equal(g.amax(dim=(2, 3)) > 0, w.amax(dim=(2, 3)) > 0)             # same orientation bins are populated
+    # the device pyramid is the max-pool of the device gt (separable cell maximum): check the dominant bin of level 6
+    for b in range(len(angles)):
+        pooled = torch.nn.functional.max_pool2d(got[0], 2, 2)[b, 0]
+        lab = got[3][5][b]
+        top = int(lab.amax(dim=(1, 2)).argmax())
+        w = lab[top].max() / pooled.max()
+        assert torch.allclose(lab[top], pooled * w, rtol=2e-6, atol=1e-30)
+
+
+def test_adam_matches_torch_adam():
+    from ccvpe_amd import optim
+    shapes = [(640, 1344, 3, 3), (17,), (1, 10, 1, 1), (4099,), (96, 1, 5, 5)]
+    ref_p = [torch.nn.Parameter(synth.normal(s, 2000 + i, 0.1)) for i, s in enumerate(shapes)]
+    our_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ref = torch.optim.Adam(ref_p, lr=1e-4, betas=(0.9, 0.999))
+    ours = optim.Adam(our_p, lr=1e-4, betas=(0.9, 0.999))
+    for step in range(5):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 1:                      # a parameter that never receives a gradient is left untouched
+                continue
+            g = synth.normal(tuple(a.shape), 3000 + 10 * step + i, 1e-3 * (1 + i))
+            a.grad = g.clone()
+            b.grad = g.permute(*reversed(range(g.dim()))).contiguous().permute(*reversed(range(g.dim()))).cuda() if i == 0 else g.cuda()
+        ref.step()
+        ours.step()
+    torch.cuda.synchronize()
+    for i, (a, b) in enumerate(zip(ref_p, our_p)):
+        d = (a.detach() - b.detach().cpu()).abs().max().item()
+        moved = (a.detach() - synth.normal(shapes[i], 2000 + i, 0.1)).abs().max().item()
+        assert d <= 2e-3 * moved + 1e-9, (i, d, moved)
+    assert torch.equal(our_p[1].detach().cpu(), synth.normal(shapes[1], 2001, 0.1))
+    sd = ours.state_dict()
+    assert set(sd["state"].keys()) == {0, 2, 3, 4} and float(sd["state"][0]["step"]) == 5.0
+    rs = ref.state_dict()["state"]
+    assert torch.allclose(sd["state"][3]["exp_avg_sq"].cpu(), rs[3]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
+    twin = optim.Adam(our_p, lr=1e-4)
+    twin.load_state_dict(sd)
+    assert twin.steps == ours.steps and torch.equal(twin.exp_avg[0], ours.exp_avg[0])
