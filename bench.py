@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--graph", action="store_true", help="replay the forward from a captured hipGraph")
     ap.add_argument("--precision", choices=["fp32", "bf16"], default="fp32",
                     help="fp32 = BASELINE C1 (default, the headline); bf16 = the C2/C4 storage path")
-    ap.add_argument("--model", choices=["prior0", "vigor20", "prior180_fov180", "kitti"], default="prior0",
+    ap.add_argument("--model", choices=["prior0", "vigor20", "prior180_fov180", "kitti", "oxford"], default="prior0",
                     help="prior0 = C1 (default); vigor20 = C2 (N_rot=20); prior180_fov180 = C4; kitti = C3 forward")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
     ap.add_argument("--no-extra", action="store_true",
@@ -149,7 +149,7 @@ def main():
     from ccvpe_amd import models, ops, synth, _lib
     _lib.load()                                             # fails loudly if the HIP library is missing
 
-    kind = "kitti" if args.model == "kitti" else "vigor"
+    kind = args.model if args.model in ("kitti", "oxford") else "vigor"
     sd = synth.synthetic_state_dict(kind, 0)                # identical on every rank
     if args.model == "prior0":
         net, gshape = models.CVM_VIGOR_ori_prior(dev, 0, True), "vigor"
@@ -157,6 +157,8 @@ def main():
         net, gshape = models.CVM_VIGOR(dev, True), "vigor"
     elif args.model == "prior180_fov180":
         net, gshape = models.CVM_VIGOR_ori_prior(dev, 180, False), "vigor_fov180"
+    elif args.model == "oxford":
+        net, gshape = models.CVM_OxfordRobotCar(dev), "oxford"
     else:
         net, gshape = models.CVM_KITTI(dev), "kitti"
     net.load_state_dict(sd, strict=True)
@@ -208,12 +210,19 @@ def main():
                                     "prior180_fov180": "C4: CVM_VIGOR_ori_prior(180, circular_padding=False) eval "
                                                        "forward, FoV 180: grd 3x320x320 + sat 3x512x512",
                                     "kitti": "C3 (forward only): CVM_KITTI eval forward, grd 3x256x1024 + sat "
-                                             "3x512x512"}[args.model],
+                                             "3x512x512",
+                                    "oxford": "CVM_OxfordRobotCar eval forward (SURVEY 8(f)-3), grd 3x154x231 + sat "
+                                              "3x512x512, N_rot=20"}[args.model],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
                        "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per kernel)",
                        "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
         }
+        if args.model == "oxford" and args.batch == 1 and world == 1:
+            # the reference's only published rate for this path family: "14 FPS" per-frame pose estimation with the Oxford
+            # RobotCar variant, hardware not stated (/root/reference/README.md:21)
+            line["vs_baseline"] = round(value / 14.0, 2)
+            line["config"]["baseline"] = "14 FPS per frame (reference README, hardware not stated)"
         roof = None
         if rec is not None:
             summ = rec.summary()

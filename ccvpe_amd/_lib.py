@@ -61,7 +61,7 @@ PROTOTYPES = {
     "ccvpe_ground_descriptor_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),
                                             c_void_p, c_int, c_int, c_int, c_void_p]),
     "ccvpe_match_level_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int),
-                                      c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                      c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ccvpe_head_conv3x3_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "ccvpe_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -98,7 +98,7 @@ PROTOTYPES = {
     "ccvpe_stem_conv_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
     "ccvpe_match_bwd_nblk": (c_int, [c_int]),
     "ccvpe_match_level_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int,
-                                          c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
+                                          c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                           c_int, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ccvpe_infonce_loss_bwd_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_cross_entropy_loss_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
@@ -112,7 +112,7 @@ PROTOTYPES = {
     "ccvpe_dwconv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "ccvpe_mbconv_front_bf16": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
     "ccvpe_match_level_bf16": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int),
-                                       c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
+                                       c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                        c_int, c_int, c_void_p]),
     "ccvpe_head_conv3x3_bf16": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
 }

@@ -273,7 +273,7 @@ def stem_conv_wgrad(img, dy, circular):
     return dw
 
 
-def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, ddst, channels, dg_out):
+def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, ddst, channels, dg_out, window_offset=0):
     """Backward of ops.match_level.  x [B,H,W,ldx]; g [B,ldg] view; scores/dscores [B,n,H,W]; ddst [B,H,W,ldo];
     dg_out [B,ldg'] view that receives dg (first L entries per row).  Returns dx [B,H,W,channels]."""
     lib = _lib.load()
@@ -285,7 +285,7 @@ def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, dds
     sh = (ctypes.c_int * n)(*shifts)
     dx = torch.empty((b, h, w, channels), device=x.device, dtype=torch.float32)
     scratch = torch.empty((b * lib.ccvpe_match_bwd_nblk(hw) * (L + 1),), device=x.device, dtype=torch.float32)
-    check(lib.ccvpe_match_level_bwd_f32(ops._ptr(x), ldx, ops._ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride,
+    check(lib.ccvpe_match_level_bwd_f32(ops._ptr(x), ldx, ops._ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, window_offset,
                                         ops._ptr(scores), ops._ptr(dscores), ops._ptr(ddst), ddst.shape[-1], ops._ptr(dx),
                                         channels, ops._ptr(dg_out), dg_out.stride(0), ops._ptr(scratch), b, hw, channels,
                                         ops._stream()), "ccvpe_match_level_bwd_f32")

@@ -354,16 +354,16 @@ extern "C" int ccvpe_add_cols_f32(const float* src, int ld_src, int col_off, flo
 }
 
 extern "C" int ccvpe_stem_wgrad_nblk(int batch, int in_h, int in_w) {
-  const long total = (long)batch * (in_h / 2) * (in_w / 2);
+  const long total = (long)batch * ((in_h - 2) / 2 + 1) * ((in_w - 2) / 2 + 1);   // (H + 1 - 3) / 2 + 1, also for odd sizes
   return (int)((total + SW_PX - 1) / SW_PX);
 }
 
 extern "C" int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, float* dw, float* scratch, int batch, int in_h,
                                          int in_w, int circular, void* stream) {
-  if (batch <= 0 || in_h <= 0 || in_w <= 0 || (in_h & 1) || (in_w & 1)) return fail(CCVPE_EINVAL, "stem_wgrad: bad shape");
+  if (batch <= 0 || in_h < 2 || in_w < 2) return fail(CCVPE_EINVAL, "stem_wgrad: bad shape");
   const int nblk = ccvpe_stem_wgrad_nblk(batch, in_h, in_w);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x_nchw, dy, scratch, batch, in_h, in_w, in_h / 2, in_w / 2,
+  hipLaunchKernelGGL(stem_wgrad_kernel, dim3(nblk), dim3(256), 0, st, x_nchw, dy, scratch, batch, in_h, in_w, (in_h - 2) / 2 + 1, (in_w - 2) / 2 + 1,
                      circular);
   launch_sum_parts(scratch, nblk, 27 * 32, 27 * 32, dw, st);
   return check_launch("stem_wgrad_kernel");

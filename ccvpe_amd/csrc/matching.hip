@@ -107,10 +107,12 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
         if (VEC == 4) {
           const f32x4 t = *reinterpret_cast<const f32x4*>(gg + k);
           gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];
-        } else {
+        } else if (VEC == 2) {
           const f32x2 t0 = *reinterpret_cast<const f32x2*>(gg + k);
           const f32x2 t1 = *reinterpret_cast<const f32x2*>(gg + k + 2);
           gv[0] = t0[0]; gv[1] = t0[1]; gv[2] = t1[0]; gv[3] = t1[1];
+        } else {      // odd table offsets (centred windows of CVM_OxfordRobotCar, models.py:1094)
+          gv[0] = gg[k]; gv[1] = gg[k + 1]; gv[2] = gg[k + 2]; gv[3] = gg[k + 3];
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i] = fmaf(xv[j], gv[j], acc[i]);
@@ -119,10 +121,12 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
           if (VEC == 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(ww + k);
             wv[0] = t[0]; wv[1] = t[1]; wv[2] = t[2]; wv[3] = t[3];
-          } else {
+          } else if (VEC == 2) {
             const f32x2 t0 = *reinterpret_cast<const f32x2*>(ww + k);
             const f32x2 t1 = *reinterpret_cast<const f32x2*>(ww + k + 2);
             wv[0] = t0[0]; wv[1] = t0[1]; wv[2] = t1[0]; wv[3] = t1[1];
+          } else {
+            wv[0] = ww[k]; wv[1] = ww[k + 1]; wv[2] = ww[k + 2]; wv[3] = ww[k + 3];
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) nrm[PARTIAL ? i : 0] = fmaf(x2[j], wv[j], nrm[PARTIAL ? i : 0]);
@@ -190,34 +194,40 @@ static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, co
 
 template <typename TX>
 static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts, int n_max,
-                     int n_tail, int stride, float* scores, TX* dstx, int ldo, int B, int hw, int C, void* stream) {
+                     int n_tail, int stride, int window_offset, float* scores, TX* dstx, int ldo, int B, int hw, int C,
+                     void* stream) {
   if (n_shifts < 1 || n_shifts > CCVPE_MAX_SHIFTS) return fail(CCVPE_EINVAL, "match_level: n_shifts %d out of range", n_shifts);
   if (n_max < 1 || n_max > n_shifts || n_tail < 0 || n_tail > n_shifts) return fail(CCVPE_EINVAL, "match_level: bad n_max/n_tail");
   if (C % 8 || ldx % 4 || ldo % 4 || ldo < C + 1 + n_tail) return fail(CCVPE_EINVAL, "match_level: C%%8, ldx%%4, ldo%%4, ldo>=C+1+n_tail required");
   if (L < 1 || L > C || L > ldg) return fail(CCVPE_EINVAL, "match_level: bad L");
-  if (stride % 2) return fail(CCVPE_EINVAL, "match_level: odd stride unsupported");
   if (!aligned16(x) || !aligned16(dstx)) return fail(CCVPE_EINVAL, "match_level: x/dstx must be 16-byte aligned");
   MatchOffsets mo;
   for (int i = 0; i < CCVPE_MAX_SHIFTS; ++i) {
     long o = 0;
     if (i < n_shifts) {
-      o = (-(long)shifts[i] * stride) % C;
+      o = (-((long)shifts[i] * stride + window_offset)) % C;
       if (o < 0) o += C;
     }
     mo.off[i] = (int)o;
   }
   const bool partial = L < C;
-  const int vec = (stride % 4 == 0) ? 4 : 2;
+  int vec = 4;                                   // widest aligned read of the doubled descriptor table
+  for (int i = 0; i < n_shifts; ++i) {
+    if (mo.off[i] % 4 && vec > 2) vec = 2;
+    if (mo.off[i] % 2) vec = 1;
+  }
   hipStream_t st = (hipStream_t)stream;
 #define M_ARGS x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dstx, ldo, B, hw, C, st
 #define M_DISPATCH(NP)                                              \
   if (n_shifts <= NP) {                                             \
     if (partial) {                                                  \
       if (vec == 4) return launch_match<TX, NP, true, 4>(M_ARGS);   \
-      return launch_match<TX, NP, true, 2>(M_ARGS);                 \
+      if (vec == 2) return launch_match<TX, NP, true, 2>(M_ARGS);   \
+      return launch_match<TX, NP, true, 1>(M_ARGS);                 \
     }                                                               \
     if (vec == 4) return launch_match<TX, NP, false, 4>(M_ARGS);    \
-    return launch_match<TX, NP, false, 2>(M_ARGS);                  \
+    if (vec == 2) return launch_match<TX, NP, false, 2>(M_ARGS);    \
+    return launch_match<TX, NP, false, 1>(M_ARGS);                  \
   }
   M_DISPATCH(1) M_DISPATCH(8) M_DISPATCH(16) M_DISPATCH(24) M_DISPATCH(48)
 #undef M_DISPATCH
@@ -226,14 +236,14 @@ static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const
 }
 
 extern "C" int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                                     int n_shifts, int n_max, int n_tail, int stride, float* scores, float* dstx,
-                                     int ldo, int B, int hw, int C, void* stream) {
-  return match_any<float>(x, ldx, g, ldg, L, shifts, n_shifts, n_max, n_tail, stride, scores, dstx, ldo, B, hw, C,
-                          stream);
+                                     int n_shifts, int n_max, int n_tail, int stride, int window_offset, float* scores,
+                                     float* dstx, int ldo, int B, int hw, int C, void* stream) {
+  return match_any<float>(x, ldx, g, ldg, L, shifts, n_shifts, n_max, n_tail, stride, window_offset, scores, dstx, ldo, B,
+                          hw, C, stream);
 }
 extern "C" int ccvpe_match_level_bf16(const void* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                                      int n_shifts, int n_max, int n_tail, int stride, float* scores, void* dstx,
-                                      int ldo, int B, int hw, int C, void* stream) {
+                                      int n_shifts, int n_max, int n_tail, int stride, int window_offset, float* scores,
+                                      void* dstx, int ldo, int B, int hw, int C, void* stream) {
   return match_any<cc_bf16>(reinterpret_cast<const cc_bf16*>(x), ldx, g, ldg, L, shifts, n_shifts, n_max, n_tail,
-                            stride, scores, reinterpret_cast<cc_bf16*>(dstx), ldo, B, hw, C, stream);
+                            stride, window_offset, scores, reinterpret_cast<cc_bf16*>(dstx), ldo, B, hw, C, stream);
 }

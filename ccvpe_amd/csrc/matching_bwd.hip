@@ -281,8 +281,8 @@ static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, in
 }
 
 extern "C" int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                                         int n_shifts, int n_max, int n_tail, int stride, const float* scores,
-                                         const float* dscores, const float* ddst, int ldo, float* dx, int lddx, float* dg,
+                                         int n_shifts, int n_max, int n_tail, int stride, int window_offset,
+                                         const float* scores, const float* dscores, const float* ddst, int ldo, float* dx, int lddx, float* dg,
                                          int ldg_out, float* scratch, int B, int hw, int C, void* stream) {
   if (n_shifts < 1 || n_shifts > CCVPE_MAX_SHIFTS) return fail(CCVPE_EINVAL, "match_level_bwd: n_shifts %d out of range", n_shifts);
   if (n_max < 1 || n_max > n_shifts || n_tail < 0 || n_tail > n_shifts) return fail(CCVPE_EINVAL, "match_level_bwd: bad n_max/n_tail");
@@ -294,7 +294,7 @@ extern "C" int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g
   for (int i = 0; i < CCVPE_MAX_SHIFTS; ++i) {
     long o = 0;
     if (i < n_shifts) {
-      o = (-(long)shifts[i] * stride) % C;
+      o = (-((long)shifts[i] * stride + window_offset)) % C;
       if (o < 0) o += C;
     }
     mo.off[i] = (int)o;

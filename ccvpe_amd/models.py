@@ -26,7 +26,14 @@ from .synth import B0_BLOCKS, MODEL_SPECS, state_dict_spec, synthetic_state_dict
 BN_EPS = 1e-3                      # efficientnet_pytorch/utils.py:666
 SKIP_BLOCKS = (15, 10, 4, 2, 0)    # models.py:167-171 (decoder levels 6..2)
 MATCH_STRIDES = {"vigor": (64, 32, 16, 8, 4, 2),       # models.py:192,217,239,261,283,305
-                 "kitti": (128, 64, 32, 16, 8, 8)}     # models.py:794,818,841,864,887,910
+                 "kitti": (128, 64, 32, 16, 8, 8),     # models.py:794,818,841,864,887,910
+                 "oxford": (64, 32, 16, 8, 4, 2)}      # models.py:1093,1116,1140,1163,1186,1209
+
+
+def window_offset(kind, channels, length):
+    """First channel of the matching window inside the rolled volume: 0 for VIGOR / KITTI (models.py:193), the centred
+    int(C/2 - L/2) of CVM_OxfordRobotCar (models.py:1094)."""
+    return int(channels / 2 - length / 2) if kind == "oxford" else 0
 
 
 def _round_up(v, m):
@@ -417,7 +424,7 @@ class _CVMBase(nn.Module):
         spec = MODEL_SPECS[self.kind]
         n_rot = spec["n_rot"]
         strides = MATCH_STRIDES[self.kind]
-        circular = bool(self.circular_padding) and self.kind != "kitti"   # models.py:660
+        circular = bool(self.circular_padding) and self.kind == "vigor"   # models.py:660 (KITTI), :959 (Oxford)
         with torch.no_grad():
             pk = self._packed()
             grd = grd.contiguous().float()
@@ -466,7 +473,8 @@ class _CVMBase(nn.Module):
                     n_tail = n_rot
                 else:
                     shifts, n_max, n_tail = loc_shifts, len(loc_shifts), 0
-                sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c)
+                sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c,
+                                          window_offset=window_offset(self.kind, lv.c, L))
                 if j == 0:
                     cat6 = cat
                     scores_out.append(sc if self.ori_noise is None else sc[:, n_max:])
@@ -518,6 +526,15 @@ class CVM_VIGOR_ori_prior(_CVMBase):
 
     def __init__(self, device, ori_noise, circular_padding=True):
         super().__init__(device, circular_padding, ori_noise)
+
+
+class CVM_OxfordRobotCar(_CVMBase):
+    """models.py:954-1246 — the VIGOR network on 154x231 ground images (4 x 7 ground feature map, descriptor lengths
+    224 ... 7), zero padding, and a matching window CENTRED in the rolled aerial volume (models.py:1094)."""
+    kind = "oxford"
+
+    def __init__(self, device):
+        super().__init__(device, False)
 
 
 class CVM_KITTI(_CVMBase):

@@ -277,7 +277,7 @@ def ground_descriptor(y1, wh, bh, cd):
     return out
 
 
-def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None):
+def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None, window_offset=0):
     """Fused rotational matching.  x [B,H,W,ldx]; g [B,ldg] view with row stride ldg.
     Returns (scores [B,n_shifts,H,W], dstx [B,H,W,ldo])."""
     lib = _lib.load()
@@ -292,8 +292,8 @@ def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None):
     scores = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
     dstx = torch.empty((b, h, w, ldo), device=x.device, dtype=dt)
     fn = lib.ccvpe_match_level_f32 if dt == torch.float32 else lib.ccvpe_match_level_bf16
-    check(fn(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, _ptr(scores), _ptr(dstx), ldo, b,
-             h * w, c, _stream()), "ccvpe_match_level")
+    check(fn(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, window_offset, _ptr(scores), _ptr(dstx),
+             ldo, b, h * w, c, _stream()), "ccvpe_match_level")
     return scores, dstx
 
 

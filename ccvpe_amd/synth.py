@@ -67,7 +67,8 @@ def normal(shape, seed, std=1.0, mean=0.0):
 # ----------------------------------------------------------------------------------------
 # inputs
 # ----------------------------------------------------------------------------------------
-GRD_SHAPES = {"vigor": (320, 640), "vigor_fov180": (320, 320), "kitti": (256, 1024)}
+GRD_SHAPES = {"vigor": (320, 640), "vigor_fov180": (320, 320), "kitti": (256, 1024),
+              "oxford": (154, 231)}          # train_OxfordRobotCar.py:50 (transforms.Resize([154, 231]))
 
 
 def synthetic_pair(batch, kind="vigor", seed=1234, grd_hw=None, sat_hw=(512, 512)):
@@ -111,6 +112,14 @@ MODEL_SPECS = {
         loc=((2049, 1024, 1344, 512), (513, 256, 368, 256), (257, 128, 168, 128),
              (129, 64, 88, 128), (129, 32, 48, 32), (33, 16, 16, 16)),
         ori=((2064, 1024, 1344, 512), (512, 256, 368, 256), (256, 128, 168, 128),
+             (128, 64, 88, 64), (64, 32, 48, 32), (32, 16, 16, 16)),
+    ),
+    # /root/reference/models.py:954-1047 (CVM_OxfordRobotCar: the VIGOR decoders, a 4 x 7 ground feature map)
+    "oxford": dict(
+        cd=(32, 16, 8, 4, 2, 1), grd_h=4, sat_desc=1280, n_rot=20,
+        loc=((1281, 1024, 1344, 640), (641, 320, 432, 320), (321, 160, 200, 160),
+             (161, 80, 104, 80), (81, 40, 56, 40), (41, 16, 16, 16)),
+        ori=((1300, 1024, 1344, 640), (640, 256, 368, 256), (256, 128, 168, 128),
              (128, 64, 88, 64), (64, 32, 48, 32), (32, 16, 16, 16)),
     ),
 }

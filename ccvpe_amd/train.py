@@ -111,9 +111,9 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     score volume of every level (the model slices level 6 for ori_prior afterwards)."""
     spec = MODEL_SPECS[model.kind]
     n_rot = spec["n_rot"]
-    from .models import MATCH_STRIDES
+    from .models import MATCH_STRIDES, window_offset
     strides = MATCH_STRIDES[model.kind]
-    circular = bool(model.circular_padding) and model.kind != "kitti"
+    circular = bool(model.circular_padding) and model.kind == "vigor"
     pk = model._packed()
     live = model.state_dict(keep_vars=True)
     grd = grd.contiguous().float()
@@ -155,10 +155,11 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
             n_tail = n_rot
         else:
             shifts, n_max, n_tail = loc_shifts, len(loc_shifts), 0
-        sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c)
+        woff = window_offset(model.kind, lv.c, L)
+        sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c, window_offset=woff)
         if rec:
             tape["match"].append(dict(x=x, goff=goff, L=L, shifts=shifts, n_max=n_max, n_tail=n_tail, stride=strides[j],
-                                      sc=sc, c=lv.c))
+                                      sc=sc, c=lv.c, woff=woff))
         goff += L
         if j == 0:
             cat6 = cat
@@ -353,7 +354,7 @@ def backward_train(model, tape, gout, on_ready=None):
         g = tape["gdesc"][:, mt["goff"]:mt["goff"] + mt["L"]]
         dg = dgdesc[:, mt["goff"]:mt["goff"] + mt["L"]]
         d = bw.match_level_bwd(mt["x"], g, mt["L"], mt["shifts"], mt["n_max"], mt["n_tail"], mt["stride"], mt["sc"],
-                               _c(g_scores[j]), dcat, c, dg)
+                               _c(g_scores[j]), dcat, c, dg, window_offset=mt["woff"])
     dsdesc = d
 
     # ---- aerial descriptor: Linear(5120 -> N) == conv 2x2 stride 2 (models.py:102-104,173-184) ------------

@@ -174,10 +174,12 @@ int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const 
  *   dstx[b,p,C+1+n_tail : ldo] = 0
  * X [B,H*W,ldx]; g [B,ldg] (first L entries); scores [B,n_shifts,H*W] (NCHW, returned to caller).
  * The first n_max shifts feed the max; the last n_tail shifts are also copied into dstx.
+ * window_offset: first channel of the L-wide window inside the rolled volume — 0 for VIGOR / KITTI, int(C/2 - L/2)
+ * for CVM_OxfordRobotCar's centred window (models.py:1094): window_i[c] = X[(c + window_offset + shift_i*stride) mod C].
  * ----------------------------------------------------------------------------------------- */
 int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                          int n_shifts, int n_max, int n_tail, int stride, float* scores, float* dstx,
-                          int ldo, int batch, int hw, int channels, void* stream);
+                          int n_shifts, int n_max, int n_tail, int stride, int window_offset, float* scores,
+                          float* dstx, int ldo, int batch, int hw, int channels, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Final 3x3 conv to 1 or 2 channels, NCHW out (models.py:125-127 conv1.2, :146-148 conv1_ori.2);
@@ -328,7 +330,7 @@ int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, float* dw, f
                               int in_w, int circular, void* stream);
 int ccvpe_match_bwd_nblk(int hw);
 int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts,
-                              int n_max, int n_tail, int stride, const float* scores, const float* dscores,
+                              int n_max, int n_tail, int stride, int window_offset, const float* scores, const float* dscores,
                               const float* ddst, int ldo, float* dx, int lddx, float* dg, int ldg_out, float* scratch,
                               int batch, int hw, int channels, void* stream);
 
@@ -384,7 +386,7 @@ int ccvpe_mbconv_front_bf16(const void* x, const void* w_exp, int kpad, const fl
                             int batch, int in_h, int in_w, int cin, int mid, int k, int stride, int circular,
                             void* stream);
 int ccvpe_match_level_bf16(const void* x, int ldx, const float* g, int ldg, int L, const int* shifts,
-                           int n_shifts, int n_max, int n_tail, int stride, float* scores, void* dstx, int ldo,
+                           int n_shifts, int n_max, int n_tail, int stride, int window_offset, float* scores, void* dstx, int ldo,
                            int batch, int hw, int channels, void* stream);
 int ccvpe_head_conv3x3_bf16(const void* x, const float* w, const float* bias, float* out_nchw, int batch, int h,
                             int w_, int cout, int normalize, void* stream);

@@ -155,7 +155,7 @@ def aerial_descriptor(vol, sd):
 # ----------------------------------------------------------------------------------------
 # rotational matching
 # ----------------------------------------------------------------------------------------
-def rotational_matching(x, g, shifts, stride):
+def rotational_matching(x, g, shifts, stride, win_off=0):
     """One matching block (models.py:186-202 and the five that follow; ori_prior :484-511;
     KITTI :788-804): for shift i, window[c] = x[(c + i*stride) mod C] for c < L
     (= roll(x, -i*stride, 1)[:, :L]); score_i = <g, window> / (||window|| * ||g||), no eps.
@@ -166,7 +166,7 @@ def rotational_matching(x, g, shifts, stride):
     base = torch.arange(L)
     out = []
     for i in shifts:
-        idx = (base + i * stride) % C
+        idx = (base + win_off + i * stride) % C      # win_off: CVM_OxfordRobotCar's centred window (models.py:1094)
         win = x.index_select(1, idx)                                     # [B,L,H,W]
         num = torch.einsum("bl,blhw->bhw", g, win)
         out.append(num / (win.norm(dim=1) * gn))
@@ -198,6 +198,8 @@ MODEL_CFG = {
     "vigor": dict(strides=(64, 32, 16, 8, 4, 2), n_rot=20),
     # models.py:794,818,841,864,887,910
     "kitti": dict(strides=(128, 64, 32, 16, 8, 8), n_rot=16),
+    # models.py:1093,1116,1140,1163,1186,1209 (CVM_OxfordRobotCar)
+    "oxford": dict(strides=(64, 32, 16, 8, 4, 2), n_rot=20),
 }
 
 
@@ -205,12 +207,13 @@ def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
             return_intermediates=False, train_stats=None, drop_scales=None):
     """CVM_VIGOR.forward (models.py:150-343) when kind='vigor' and ori_noise is None;
     CVM_VIGOR_ori_prior.forward (models.py:448-652) when ori_noise is a number;
-    CVM_KITTI.forward (models.py:752-950) when kind='kitti'.
+    CVM_KITTI.forward (models.py:752-950) when kind='kitti'; CVM_OxfordRobotCar.forward (models.py:1049-1246)
+    when kind='oxford' (VIGOR's network with a centred matching window and a 4 x 7 ground feature map).
     Returns the reference's 9-tuple."""
     cfg = MODEL_CFG[kind]
     n_rot = cfg["n_rot"]
-    if kind == "kitti":
-        circular_padding = False                       # models.py:660
+    if kind in ("kitti", "oxford"):
+        circular_padding = False                       # models.py:660, :959
     if ori_noise is None:
         loc_shifts = list(range(n_rot))                # models.py:191
     else:
@@ -231,8 +234,11 @@ def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
 
     scores = []
     x = sdesc
+    def woff(xv, gv):       # models.py:1094: int(sat_des_len/2 - grd_des_len/2), window centred in the rolled volume
+        return int(xv.shape[1] / 2 - gv.shape[1] / 2) if kind == "oxford" else 0
+
     for lvl in range(6):                               # level index 0..5 == reference 1..6
-        sc = rotational_matching(x, gdesc[lvl], loc_shifts, cfg["strides"][lvl])
+        sc = rotational_matching(x, gdesc[lvl], loc_shifts, cfg["strides"][lvl], woff(x, gdesc[lvl]))
         scores.append(sc)
         x = up(lmu_input(x, sc), sd, "deconv%d" % (6 - lvl))
         if lvl < 5:
@@ -246,7 +252,7 @@ def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
     if ori_noise is None:
         score1 = scores[0]
     else:
-        score1 = rotational_matching(sdesc, gdesc[0], list(range(n_rot)), cfg["strides"][0])
+        score1 = rotational_matching(sdesc, gdesc[0], list(range(n_rot)), cfg["strides"][0], woff(sdesc, gdesc[0]))
         scores[0] = score1
     xo = torch.cat([score1, F.normalize(sdesc, p=2, dim=1)], dim=1)
     for lvl in range(6):

@@ -18,6 +18,9 @@ FORWARD_CASES = {
                                   pseed=78, batch=1, grd="vigor_fov180"),
     "kitti": dict(kind="kitti", ori_noise=None, circular=False, wseed=1, pseed=5,
                   batch=1, grd="kitti"),
+    # CVM_OxfordRobotCar: 154x231 ground image, centred matching window
+    "oxford": dict(kind="oxford", ori_noise=None, circular=False, wseed=2, pseed=9,
+                   batch=1, grd="oxford"),
 }
 
 

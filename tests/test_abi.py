@@ -75,10 +75,11 @@ def test_missing_library_fails_loudly(monkeypatch):
         _lib.load()
 
 
-@pytest.mark.parametrize("kind", ["vigor", "kitti"])
+@pytest.mark.parametrize("kind", ["vigor", "kitti", "oxford"])
 def test_state_dict_layout_and_roundtrip(kind, synth_sd):
     from ccvpe_amd import models
-    net = models.CVM_KITTI("cpu") if kind == "kitti" else models.CVM_VIGOR("cpu", True)
+    net = {"kitti": lambda: models.CVM_KITTI("cpu"), "oxford": lambda: models.CVM_OxfordRobotCar("cpu"),
+           "vigor": lambda: models.CVM_VIGOR("cpu", True)}[kind]()
     spec = synth.state_dict_spec(kind)
     sd = net.state_dict()
     assert list(sd.keys()) == [k for k, _, _ in spec]
@@ -137,9 +138,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.ccvpe_dwconv_f32(256, 256, 256, 256, 256, 256, 1, 8, 8, 6, 3, 1, 0, None) == EINVAL      # C % 4
     assert lib.ccvpe_dwconv_f32(256, 256, 256, 256, 256, 256, 1, 8, 8, 8, 4, 1, 0, None) == EINVAL      # k = 4
     sh = (ctypes.c_int * 2)(0, 1)
-    assert lib.ccvpe_match_level_f32(256, 40, 256, 40, 40, sh, 2, 2, 0, 3, 256, 256, 48, 1, 64, 40, None) == EINVAL
-    assert b"odd stride" in lib.ccvpe_last_error()
-    assert lib.ccvpe_match_level_f32(256, 40, 256, 40, 40, sh, 99, 2, 0, 2, 256, 256, 48, 1, 64, 40, None) == EINVAL
+    assert lib.ccvpe_match_level_f32(256, 40, 256, 48, 48, sh, 2, 2, 0, 2, 0, 256, 256, 48, 1, 64, 40, None) == EINVAL
+    assert b"bad L" in lib.ccvpe_last_error()                                                           # window wider than C
+    assert lib.ccvpe_match_level_f32(256, 40, 256, 40, 40, sh, 99, 2, 0, 2, 0, 256, 256, 48, 1, 64, 40, None) == EINVAL
     assert lib.ccvpe_head_conv3x3_f32(256, 256, 256, 256, 1, 8, 8, 3, 0, None) == EINVAL               # cout = 3
     assert lib.ccvpe_softmax_rows_f32(256, 256, 0, 8, None) == EINVAL
     assert lib.ccvpe_mbconv_front_nblk(8, 8, 16, 96, 4, 1) == EINVAL

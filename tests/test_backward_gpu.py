@@ -308,3 +308,26 @@ def test_loss_gradients_vs_oracle_autograd():
     od = ori.detach().cuda().requires_grad_(True)
     losses.orientation_loss(od, gto.cuda(), gt.cuda()).backward()
     close(od.grad, ori.grad, 1e-5, "ori grad")
+
+
+def test_match_level_bwd_centred_window(bw):
+    """Backward with CVM_OxfordRobotCar's centred window (odd channel offset)."""
+    from ccvpe_amd import ops
+    from oracle import ccvpe_oracle as orc
+    b, c, L, hw, stride, woff = 2, 80, 14, 16, 4, 33
+    shifts = list(range(20))
+    x = synth.normal((b, c, hw, hw), 1100).double().requires_grad_(True)
+    g = synth.normal((b, L), 1101).double().requires_grad_(True)
+    sc = orc.rotational_matching(x, g, shifts, stride, woff)
+    dst = torch.cat([F.normalize(x, p=2, dim=1), sc.max(dim=1, keepdim=True)[0]], dim=1)
+    ldo = ((c + 1 + 7) // 8) * 8
+    dsc = synth.normal(tuple(sc.shape), 1102).double()
+    ddst = synth.normal((b, hw, hw, ldo), 1103).double()
+    ((sc * dsc).sum() + (nhwc(dst) * ddst[..., :c + 1]).sum()).backward()
+    xd, gd = nhwc(x.detach().float()).cuda(), g.detach().float().cuda()
+    scores, _ = ops.match_level(xd, gd, L, shifts, 20, 0, stride, ldo, channels=c, window_offset=woff)
+    dg = torch.zeros((b, L), device="cuda")
+    dx = bw.match_level_bwd(xd, gd, L, shifts, 20, 0, stride, scores, dsc.float().cuda(), ddst.float().cuda(), c, dg,
+                            window_offset=woff)
+    close(dx, nhwc(x.grad), 2e-4, "centred match dx")
+    close(dg, g.grad, 2e-4, "centred match dg")

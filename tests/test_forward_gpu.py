@@ -18,6 +18,8 @@ def build(case, synth_sd):
     c = G.FORWARD_CASES[case] if isinstance(case, str) else case
     if c["kind"] == "kitti":
         net = models.CVM_KITTI("cuda")
+    elif c["kind"] == "oxford":
+        net = models.CVM_OxfordRobotCar("cuda")
     elif c["ori_noise"] is None:
         net = models.CVM_VIGOR("cuda", c["circular"])
     else:
@@ -58,6 +60,7 @@ def test_forward_vs_reference_golden(name, synth_sd):
     dict(kind="vigor", ori_noise=None, circular=True, wseed=0, grd="vigor"),
     dict(kind="vigor", ori_noise=72, circular=False, wseed=0, grd="vigor_fov180"),
     dict(kind="kitti", ori_noise=None, circular=False, wseed=1, grd="kitti"),
+    dict(kind="oxford", ori_noise=None, circular=False, wseed=2, grd="oxford"),
 ])
 def test_forward_vs_oracle_batch2(case, synth_sd):
     """B=2 on fresh inputs: every output tensor in full against the oracle."""

@@ -377,3 +377,17 @@ def test_eval_postprocess(ops):
     close(got[:, 2:4], want[:, 2:4], 1e-6, "cos/sin")
     assert (got[:, 4] - want[:, 4]).abs().max() < 1e-2   # degrees (acosf vs libm acos in fp64)
     close(got[:, 5], want[:, 5], 1e-6, "prob")
+
+
+@pytest.mark.parametrize("C,L,stride,hw,woff", [(1280, 224, 64, 8, 528), (160, 28, 8, 16, 66), (80, 14, 4, 16, 33),
+                                                (40, 7, 2, 24, 16)])
+def test_match_level_centred_window(ops, C, L, stride, hw, woff):
+    """CVM_OxfordRobotCar's window (models.py:1094): channels [woff, woff+L) of the rolled volume, odd offsets included."""
+    shifts = list(range(20))
+    x = synth.normal((2, C, hw, hw), 4100 + C)
+    g = synth.normal((2, L), 4101)
+    ldo = (C + 1 + 20 + 7) // 8 * 8
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g), L, shifts, 20, 20, stride, ldo, window_offset=woff)
+    want = O.rotational_matching(x, g, shifts, stride, woff)
+    close(sc, want, 1e-5, "centred-window scores")
+    close(cat[..., C], want.max(dim=1)[0], 1e-5, "max column")

@@ -30,7 +30,8 @@ def test_vigor_ori_prior_live(synth_sd):
 def test_state_dict_layout_matches_reference():
     ref_models, _ = import_reference()
     for kind, net in (("vigor", ref_models.CVM_VIGOR("cpu", True)),
-                      ("kitti", ref_models.CVM_KITTI("cpu"))):
+                      ("kitti", ref_models.CVM_KITTI("cpu")),
+                      ("oxford", ref_models.CVM_OxfordRobotCar("cpu"))):
         ref = net.state_dict()
         spec = synth.state_dict_spec(kind)
         assert [k for k, _, _ in spec] == list(ref.keys())

@@ -77,7 +77,7 @@ def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
     assert (post2 - post1).abs().max().item() < 1e-3 * scale          # and equals torch.optim.Adam's step
 
 
-@pytest.mark.parametrize("kind,ori_noise,circular", [("kitti", None, False), ("vigor", 36, True)])
+@pytest.mark.parametrize("kind,ori_noise,circular", [("kitti", None, False), ("vigor", 36, True), ("oxford", None, False)])
 def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise, circular):
     """CVM_KITTI and CVM_VIGOR_ori_prior (5 localisation shifts + the recomputed 20-shift level-6 volume): no reference
     golden is stored for these, so the gradients are compared with autograd through the oracle on the CPU."""
@@ -86,6 +86,8 @@ def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise
     sd = synth_sd(kind, 3)
     if kind == "kitti":
         net = models.CVM_KITTI("cuda")
+    elif kind == "oxford":
+        net = models.CVM_OxfordRobotCar("cuda")
     else:
         net = models.CVM_VIGOR_ori_prior("cuda", ori_noise, circular)
     net.load_state_dict(sd, strict=True)

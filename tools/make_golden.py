@@ -34,13 +34,18 @@ def main():
     with torch.no_grad():
         # ---- full forwards --------------------------------------------------------------
         only_train = "--only-train" in sys.argv
+        only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only-case=")]
         for name, c in ({} if only_train else G.FORWARD_CASES).items():
+            if only and name not in only:
+                continue
             key = (c["kind"], c["wseed"])
             if key not in sds:
                 sds[key] = synth.synthetic_state_dict(*key)
             sd = sds[key]
             if c["kind"] == "kitti":
                 net = ref_models.CVM_KITTI("cpu")
+            elif c["kind"] == "oxford":
+                net = ref_models.CVM_OxfordRobotCar("cpu")
             elif c["ori_noise"] is None:
                 net = ref_models.CVM_VIGOR("cpu", c["circular"])
             else:
@@ -62,6 +67,8 @@ def main():
                 d["grd_desc%d" % l] = getattr(net, "grd_feature_to_descriptor%d" % l)(gf).numpy()
             save("fwd_" + name, d)
 
+        if only:
+            return
         # ---- train-mode forward (batch-stat BN, injected drop_connect draws) ----------------------------
         import efficientnet_pytorch.model as effmodel
         c = G.TRAIN_CASE
