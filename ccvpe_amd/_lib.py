@@ -50,6 +50,9 @@ PROTOTYPES = {
     "ccvpe_last_error": (ctypes.c_char_p, []),
     "ccvpe_abi_version": (c_int, []),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
+    "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
+    "ccvpe_conv_igemm_splitk_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "ccvpe_upconv3x3_f32": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
     "ccvpe_upconv3x3_bf16": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
     "ccvpe_stem_conv_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),

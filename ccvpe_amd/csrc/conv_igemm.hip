@@ -99,6 +99,11 @@ struct IgemmParams {
   int M;
   int tiles_n, tiles_total;
   int tiles_x, tiles_y;  // conv3x3: spatial tiles per sample
+  // split-K (igemm_kernel only; small-batch GEMMs with a handful of tiles and thousands of K stages): workgroup
+  // (tile, blockIdx.y) walks stages [y*sps, (y+1)*sps) and writes its raw fp32 accumulators to
+  // partial[y][M][Npad]; splitk_finish_kernel adds the slices in order and applies the epilogue.
+  int ksplit, sps;
+  float* partial;
 };
 
 constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad)
@@ -207,11 +212,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     a_x[it] = ox * p.stride - p.pad;
   }
   // chunk cursor of this thread: kc = CPS*stage + chunk_in_stage, decoded as (ky, kx, r)
-  int kc = chunk_in_stage;
-  int r = chunk_in_stage, ky = 0, kx = 0;
-  while (r >= p.cpt) {
-    r -= p.cpt;
-    if (++kx == p.kw) { kx = 0; ++ky; }
+  const int s_begin = p.ksplit > 1 ? blockIdx.y * p.sps : 0;
+  const int s_end = p.ksplit > 1 ? min(p.stages, s_begin + p.sps) : p.stages;
+  int kc = CPS * s_begin + chunk_in_stage;
+  int r, ky, kx;
+  {
+    const int tap = kc / p.cpt;
+    r = kc - tap * p.cpt;
+    ky = tap / p.kw;
+    kx = tap - ky * p.kw;
   }
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
@@ -271,13 +280,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int frow = lane & 15;
   const int fk = (lane >> 4) * 4;
 
-  load_stage(0);
+  load_stage(s_begin);
   store_stage(0);
   __syncthreads();
 
-  for (int s = 0; s < p.stages; ++s) {
-    const int buf = s & 1;
-    const bool more = s + 1 < p.stages;
+  for (int s = s_begin; s < s_end; ++s) {
+    const int buf = (s - s_begin) & 1;
+    const bool more = s + 1 < s_end;
     if (more) load_stage(s + 1);
 
     f32x4 af[MT], bf[NT];
@@ -309,6 +318,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // ---- epilogue: swapped roles => D rows = channels ((lane>>4)*4 + reg), D cols = pixels (lane&15)
   const int epix = lane & 15;
   const int en = (lane >> 4) * 4;
+  if (p.ksplit > 1) {      // raw partial sums; the epilogue runs in splitk_finish_kernel
+    float* part = p.partial + (size_t)blockIdx.y * p.M * p.Npad;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int m = m0 + (wm * MT + i) * 16 + epix;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + (wn * NT + j) * 16 + en;
+        if (n < p.Npad) *reinterpret_cast<f32x4*>(part + (size_t)m * p.Npad + n) = acc[i][j];
+      }
+    }
+    return;
+  }
   float sc[NT][4], sh[NT][4];
 #pragma unroll
   for (int j = 0; j < NT; ++j)
@@ -564,8 +587,54 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   }
 }
 
+// split-K second pass: thread = (pixel m, 4 channels); adds the K slices in index order (deterministic) and applies
+// the same epilogue as the one-pass kernel (scale/shift, activation, residual, NHWC or pixel-shuffle addressing)
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p) {
+  const int n4 = p.Npad >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)p.M * n4) return;
+  const int m = (int)(idx / n4);
+  const int n = (int)(idx - (long)m * n4) * 4;
+  if (n >= p.N) return;
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.partial + (size_t)m * p.Npad + n);
+  for (int k = 1; k < p.ksplit; ++k) v += *reinterpret_cast<const f32x4*>(p.partial + ((size_t)k * p.M + m) * p.Npad + n);
+  float sc[4], sh[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const bool ok = n + q < p.N;
+    sc[q] = (ok && p.scale) ? p.scale[n + q] : 1.0f;
+    sh[q] = (ok && p.shift) ? p.shift[n + q] : 0.0f;
+  }
+  size_t obase;
+  if (p.out_mode == CCVPE_OUT_NHWC) {
+    obase = (size_t)m * p.ldd + n;
+  } else {
+    const int hw = p.Ho * p.Wo;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    const int y = rem / p.Wo;
+    const int x = rem - y * p.Wo;
+    const size_t pbase = ((size_t)(b * 2 * p.Ho + 2 * y) * (2 * p.Wo) + 2 * x) * p.ldd;
+    const int quad = n / p.cout;
+    const int co = n - quad * p.cout;
+    obase = pbase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
+  }
+  store4<T>(p, v, n, obase, (size_t)m * p.ldres, sc, sh);
+}
+
+// K slices for a GEMM with `tiles` workgroups and `stages` K stages (1 = no split): only when the launch cannot fill
+// the 256 CUs and the serial K walk is long; each slice keeps >= 12 stages
+static int splitk_slices(int tiles, int stages) {
+  if (tiles >= 128 || stages < 24) return 1;
+  int s = (512 + tiles - 1) / tiles;
+  if (s > stages / 12) s = stages / 12;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : s;
+}
+
 template <typename T, int MT, int NT, int WN>
-static int launch(const IgemmParams& p0, hipStream_t stream) {
+static int launch(const IgemmParams& p0, hipStream_t stream, float* scratch = nullptr, long* want_floats = nullptr) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
@@ -573,6 +642,23 @@ static int launch(const IgemmParams& p0, hipStream_t stream) {
   const int tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Npad + BN - 1) / BN;
   p.tiles_total = tiles_m * p.tiles_n;
+  p.ksplit = 1;
+  p.sps = p.stages;
+  p.partial = nullptr;
+  const int S = splitk_slices(p.tiles_total, p.stages);
+  if (want_floats) {                       // planning call: report the scratch a split-K run needs, launch nothing
+    *want_floats = S > 1 ? (long)S * p.M * p.Npad : 0;
+    return CCVPE_OK;
+  }
+  if (scratch && S > 1) {
+    p.sps = (p.stages + S - 1) / S;
+    p.ksplit = (p.stages + p.sps - 1) / p.sps;
+    p.partial = scratch;
+    hipLaunchKernelGGL((igemm_kernel<T, MT, NT, WN>), dim3(p.tiles_total, p.ksplit), dim3(256), 0, stream, p);
+    const long n = (long)p.M * (p.Npad / 4);
+    hipLaunchKernelGGL((splitk_finish_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, p);
+    return check_launch("igemm_kernel (split-K)");
+  }
   hipLaunchKernelGGL((igemm_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
   return check_launch("igemm_kernel");
 }
@@ -1130,7 +1216,8 @@ static int pick_cfg(int npad16) {
 using namespace ccvpe;
 
 template <typename T>
-static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32) {
+static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, float* scratch = nullptr,
+                          long* want_floats = nullptr) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;
   if (!d) return fail(CCVPE_EINVAL, "conv_igemm: null desc");
@@ -1172,10 +1259,14 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32) {
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
   const bool is3x3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
                      d->out_mode == CCVPE_OUT_NHWC && !d->gate;
-#define CCVPE_CASE(MT_, NT_, WN_)                                       \
-  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                      \
-    if (is3x3) return launch3x3<T, MT_, NT_, WN_>(p, d->batch, st);     \
-    return launch<T, MT_, NT_, WN_>(p, st);                             \
+  // split-K mode (planning or with scratch): everything, 3x3 included, goes through the generic gather kernel
+  const bool sk = scratch != nullptr || want_floats != nullptr;
+  if (scratch && !aligned16(scratch)) return fail(CCVPE_EINVAL, "conv_igemm: scratch must be 16-byte aligned");
+#define CCVPE_CASE(MT_, NT_, WN_)                                                  \
+  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                                 \
+    if (sk) return launch<T, MT_, NT_, WN_>(p, st, scratch, want_floats);          \
+    if (is3x3) return launch3x3<T, MT_, NT_, WN_>(p, d->batch, st);                \
+    return launch<T, MT_, NT_, WN_>(p, st);                                        \
   }
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)
   CCVPE_CASE(4, 5, 1) CCVPE_CASE(4, 3, 1) CCVPE_CASE(4, 1, 1) CCVPE_CASE(2, 7, 1)
@@ -1222,6 +1313,22 @@ static int upconv_any(const ccvpe_upconv_desc* d, void* stream) {
 
 extern "C" int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* d, void* stream) { return upconv_any<float>(d, stream); }
 extern "C" int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* d, void* stream) { return upconv_any<bf16_t>(d, stream); }
+
+extern "C" int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* d, int is_bf16) {
+  long want = 0;
+  const int rc = is_bf16 ? conv_igemm_any<bf16_t>(d, nullptr, 0, nullptr, &want)
+                         : conv_igemm_any<float>(d, nullptr, 0, nullptr, &want);
+  if (want > 0x7fffffffL) want = 0;          // would not fit the int return: do not split
+  return rc ? rc : (int)want;
+}
+extern "C" int ccvpe_conv_igemm_splitk_bf16(const ccvpe_conv_desc* d, int out_f32, float* scratch, void* stream) {
+  if (!scratch) return fail(CCVPE_EINVAL, "conv_igemm_splitk: scratch is NULL");
+  return conv_igemm_any<bf16_t>(d, stream, out_f32, scratch);
+}
+extern "C" int ccvpe_conv_igemm_splitk_f32(const ccvpe_conv_desc* d, float* scratch, void* stream) {
+  if (!scratch) return fail(CCVPE_EINVAL, "conv_igemm_splitk: scratch is NULL");
+  return conv_igemm_any<float>(d, stream, 0, scratch);
+}
 
 extern "C" int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* d, void* stream) {
   return conv_igemm_any<float>(d, stream, 1);

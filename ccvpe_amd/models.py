@@ -138,6 +138,10 @@ _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image fo
 # 6-2 41.95, all six 41.7 -> all levels by default (CCVPE_FOLD_LEVELS overrides, e.g. "" to disable).
 OVERLAP_DECODERS = __import__("os").environ.get("CCVPE_OVERLAP_DECODERS", "0") == "1"
 FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
+# Below this many low-res pixels (batch * h * w) the folded GEMM has too few output tiles to fill the chip and walks
+# K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
+# instead.  B = 64 keeps every level folded (level 6 has 4096 low-res pixels).
+FOLD_MIN_PIXELS = 4096
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
@@ -376,7 +380,7 @@ class _CVMBase(nn.Module):
             ov = pk.ori[j]
             hw = xo.shape[1]
             skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
-            if j in FOLD_LEVELS:
+            if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:
                 y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
                                   src1=skip, c1=ov.c1, act=ops.ACT_RELU)
             else:
@@ -489,7 +493,7 @@ class _CVMBase(nn.Module):
                 else:
                     scores_out.append(sc)
                 skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
-                if j in FOLD_LEVELS:   # deconv folded into conv.0: one GEMM per output parity on the low-res input
+                if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:   # deconv folded into conv.0: one GEMM per output parity
                     y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,
                                       src1=skip, c1=lv.c1, act=ops.ACT_RELU)
                 else:

@@ -12,6 +12,8 @@ from . import _lib
 from ._lib import ConvDesc, check
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+SPLIT_K_CALLS = 0        # number of conv_igemm calls that took the split-K path (tests / diagnostics)
+SPLIT_K = __import__("os").environ.get("CCVPE_SPLIT_K", "1") == "1"      # split-K for small-batch GEMMs (0 disables)
 OUT_NHWC, OUT_DECONV2X = 0, 1
 
 # Optional launch recorder (bench.py): when set, every library call is bracketed by HIP events on
@@ -132,7 +134,19 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     d.act, d.out_mode = act, out_mode
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
-    if dt == torch.float32:
+    want = lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), int(dt != torch.float32)) if SPLIT_K else 0
+    if want < 0:
+        check(int(want), "ccvpe_conv_igemm_splitk_floats")
+    if want > 0:          # small-batch GEMM: K cut into slices + deterministic second pass (csrc/conv_igemm.hip)
+        global SPLIT_K_CALLS
+        SPLIT_K_CALLS += 1
+        scratch = torch.empty((want,), device=src0.device, dtype=torch.float32)
+        if dt == torch.float32:
+            check(lib.ccvpe_conv_igemm_splitk_f32(ctypes.byref(d), _ptr(scratch), _stream()), "ccvpe_conv_igemm_splitk_f32")
+        else:
+            check(lib.ccvpe_conv_igemm_splitk_bf16(ctypes.byref(d), int(bool(out_f32)), _ptr(scratch), _stream()),
+                  "ccvpe_conv_igemm_splitk_bf16")
+    elif dt == torch.float32:
         check(lib.ccvpe_conv_igemm_f32(ctypes.byref(d), _stream()), "ccvpe_conv_igemm_f32")
     else:
         check(lib.ccvpe_conv_igemm_bf16(ctypes.byref(d), int(bool(out_f32)), _stream()), "ccvpe_conv_igemm_bf16")

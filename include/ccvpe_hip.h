@@ -84,6 +84,16 @@ typedef struct ccvpe_conv_desc {
 
 int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* desc, void* stream);
 
+/* Split-K form for small-batch GEMMs (a handful of output tiles, thousands of K stages: decoder levels 6-5 and the late
+ * encoder 1x1s at batch <= 8 leave most of the 256 CUs idle and walk K serially).  K is cut into slices, each slice
+ * is its own workgroup row writing raw fp32 partial sums to `scratch`, and a second kernel adds the slices in index
+ * order (deterministic) and applies the epilogue.  3x3 convs take the generic gather kernel in this mode.
+ *   ccvpe_conv_igemm_splitk_floats: floats of scratch a split-K run of `desc` wants; 0 = splitting would not help
+ *       (call ccvpe_conv_igemm_* instead); negative = error.
+ *   ccvpe_conv_igemm_splitk_f32 / _bf16: same contract as ccvpe_conv_igemm_f32 / _bf16, with that scratch. */
+int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* desc, int is_bf16);
+int ccvpe_conv_igemm_splitk_f32(const ccvpe_conv_desc* desc, float* scratch, void* stream);
+
 /* -------------------------------------------------------------------------------------------
  * ConvTranspose2d(k=2,s=2) folded into the 3x3 conv that follows it (models.py:207-209 and the same
  * pair at every decoder level of both branches: x = deconvK(x); x = cat[x, skip]; x = convK.0(x)).
@@ -376,6 +386,7 @@ int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* c
  * Matching scores, heat-map logits and the orientation field are always fp32.
  * ----------------------------------------------------------------------------------------- */
 int ccvpe_conv_igemm_bf16(const ccvpe_conv_desc* desc, int out_f32, void* stream);
+int ccvpe_conv_igemm_splitk_bf16(const ccvpe_conv_desc* desc, int out_f32, float* scratch, void* stream);
 int ccvpe_stem_conv_bf16(const float* x_nchw, const float* w, const float* scale, const float* shift, void* y,
                          int batch, int in_h, int in_w, int circular, void* stream);
 int ccvpe_dwconv_bf16(const void* x, const float* w, const float* scale, const float* shift, void* y,

@@ -391,3 +391,43 @@ def test_match_level_centred_window(ops, C, L, stride, hw, woff):
     want = O.rotational_matching(x, g, shifts, stride, woff)
     close(sc, want, 1e-5, "centred-window scores")
     close(cat[..., C], want.max(dim=1)[0], 1e-5, "max column")
+
+
+@pytest.mark.parametrize("kind,c0,c1,n,hw,k", [("3x3", 1024, 320, 640, 16, 3), ("1x1", 1152, 0, 192, 10, 1),
+                                               ("2x2s2", 1280, 0, 1280, 16, 2), ("deconv", 1288, 0, 4096, 8, 1)])
+def test_conv_igemm_split_k_matches_one_pass(ops, kind, c0, c1, n, hw, k):
+    """Small-batch GEMMs take the split-K path (K slices + deterministic second pass): same result as the one-pass
+    kernels (bias, ReLU, residual, two sources, pixel-shuffle output), and the planner engages on these shapes."""
+    import ctypes
+    from ccvpe_amd import _lib
+    from ccvpe_amd.models import _pack_conv, _pack_deconv
+    b = 1
+    x0 = dev(synth.normal((b, hw, hw, c0), 5000 + c0))
+    x1 = dev(synth.normal((b, hw, hw, c1), 5001)) if c1 else None
+    bias = dev(synth.normal((n if kind != "deconv" else n // 4,), 5002, 0.1))
+    kw = dict(batch=b, in_h=hw, in_w=hw)
+    if kind == "deconv":
+        w = synth.normal((c0, n // 4, 2, 2), 5003, c0 ** -0.5)
+        wp, bp = _pack_deconv(dev(w), bias, [(0, 0, c0)], c0)
+        args = dict(shift=bp, out_mode=ops.OUT_DECONV2X, **kw)
+    else:
+        w = synth.normal((n, c0 + c1, k, k), 5003, ((c0 + c1) * k * k) ** -0.5)
+        wp = _pack_conv(dev(w))
+        st, pad = (2, 0) if kind == "2x2s2" else (1, k // 2)
+        args = dict(kh=k, kw=k, stride=st, pad=pad, src1=x1, c1=c1, shift=bias, act=ops.ACT_RELU if k == 3 else ops.ACT_NONE,
+                    **kw)
+        if kind == "1x1":
+            args["residual"] = dev(synth.normal((b, hw, hw, n), 5004))
+    old = ops.SPLIT_K
+    try:
+        ops.SPLIT_K = False
+        ref = ops.conv_igemm(x0, c0, wp, n, **args)
+        ops.SPLIT_K = True
+        calls = ops.SPLIT_K_CALLS
+        got = ops.conv_igemm(x0, c0, wp, n, **args)
+        assert ops.SPLIT_K_CALLS == calls + 1, "the split-K planner did not engage on a small-batch shape"
+    finally:
+        ops.SPLIT_K = old
+    close(got, ref, 2e-5, "split-K vs one pass")
+    got2 = ops.conv_igemm(x0, c0, wp, n, **args)
+    assert torch.equal(got, got2), "split-K result must be deterministic"
