@@ -99,7 +99,7 @@ PROTOTYPES = {
     "ccvpe_add_cols_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "ccvpe_stem_wgrad_nblk": (c_int, [c_int] * 3),
     "ccvpe_stem_conv_wgrad_f32": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p]),
-    "ccvpe_match_bwd_nblk": (c_int, [c_int]),
+    "ccvpe_match_bwd_nblk": (c_int, [c_int, c_int, c_int]),
     "ccvpe_match_level_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, ctypes.POINTER(c_int), c_int, c_int,
                                           c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p,
                                           c_int, c_void_p, c_int, c_int, c_int, c_void_p]),

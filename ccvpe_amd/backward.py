@@ -284,7 +284,7 @@ def match_level_bwd(x, g, L, shifts, n_max, n_tail, stride, scores, dscores, dds
     n = len(shifts)
     sh = (ctypes.c_int * n)(*shifts)
     dx = torch.empty((b, h, w, channels), device=x.device, dtype=torch.float32)
-    scratch = torch.empty((b * lib.ccvpe_match_bwd_nblk(hw) * (L + 1),), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((b * lib.ccvpe_match_bwd_nblk(hw, b, channels) * (L + 1),), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_match_level_bwd_f32(ops._ptr(x), ldx, ops._ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, window_offset,
                                         ops._ptr(scores), ops._ptr(dscores), ops._ptr(ddst), ddst.shape[-1], ops._ptr(dx),
                                         channels, ops._ptr(dg_out), dg_out.stride(0), ops._ptr(scratch), b, hw, channels,

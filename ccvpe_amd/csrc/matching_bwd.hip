@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
                                                         int n_tail, const float* __restrict__ scores,
                                                         const float* __restrict__ dscores, const float* __restrict__ ddst,
                                                         int ldo, float* __restrict__ dx, int lddx,
-                                                        float* __restrict__ part, int nblk, int hw, int C) {
+                                                        float* __restrict__ part, int nblk, int hw, int C, int nslice) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int TPB = blockDim.x;
   const int XLD = TPB + 1;
@@ -146,7 +146,11 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
   const float k2 = xn > 1e-12f ? xd * k1 * k1 * k1 : 0.f;
 
   // ---- pass B: dx and the dg partials -------------------------------------------------------------------
-  for (int c0 = 0; c0 < C; c0 += MBK) {
+  // blockIdx.z = channel slice: with few pixels per sample (decoder levels 6-5: one workgroup per sample) the channel
+  // walk is split over nslice workgroups; each recomputes the (cheap) pass A and owns tiles [t0, t1) of pass B
+  const int ntile = (C + MBK - 1) / MBK;
+  const int t0 = (int)((long)ntile * blockIdx.z / nslice), t1 = (int)((long)ntile * (blockIdx.z + 1) / nslice);
+  for (int c0 = t0 * MBK; c0 < min(t1 * MBK, C); c0 += MBK) {
     const int ck = min(MBK, C - c0);
     for (int idx = tid; idx < TPB * F4; idx += TPB) {
       const int pp = idx / F4;
@@ -218,12 +222,12 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
   T = wave_sum(T);
   if (lane == 0) red[wv] = T;
   __syncthreads();
-  float* out = part + ((size_t)b * nblk + blockIdx.x) * (L + 1);
+  float* out = part + (((size_t)b * nblk + blockIdx.x) * nslice + blockIdx.z) * (L + 1);
   for (int k = tid; k < L; k += TPB) out[k] = dgw[k];
   if (tid == 0) {
     float t = 0.f;
     for (int w = 0; w < NW; ++w) t += red[w];
-    out[L] = t;
+    out[L] = blockIdx.z == 0 ? t : 0.f;          // the scalar term is the same in every slice: count it once
   }
 }
 
@@ -257,9 +261,20 @@ using namespace ccvpe;
 
 static int match_bwd_tpb(int hw) { return hw >= 256 ? 256 : ((hw + 63) / 64) * 64; }
 
-extern "C" int ccvpe_match_bwd_nblk(int hw) {
+// channel slices per pixel workgroup: enough workgroups to cover the chip, at least 4 tiles (64 channels) per slice
+static int match_bwd_slices(int hw, int batch, int C) {
   const int tpb = match_bwd_tpb(hw);
-  return (hw + tpb - 1) / tpb;
+  const long wgs = (long)((hw + tpb - 1) / tpb) * batch;
+  int s = (int)((512 + wgs - 1) / wgs);
+  const int smax = C / (4 * MBK);
+  if (s > smax) s = smax;
+  if (s > 32) s = 32;
+  return s < 1 ? 1 : s;
+}
+
+extern "C" int ccvpe_match_bwd_nblk(int hw, int batch, int channels) {
+  const int tpb = match_bwd_tpb(hw);
+  return ((hw + tpb - 1) / tpb) * match_bwd_slices(hw, batch, channels);
 }
 
 template <int NPAD>
@@ -268,6 +283,7 @@ static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, in
                             float* dx, int lddx, float* part, int B, int hw, int C, hipStream_t st) {
   const int tpb = match_bwd_tpb(hw);
   const int nblk = (hw + tpb - 1) / tpb;
+  const int nslice = match_bwd_slices(hw, B, C);
   const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 1) + (size_t)n_shifts * (tpb + MBK) + (L + 1) + 4);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level_bwd: C=%d needs %zu B of LDS", C, smem);
   auto kern = match_bwd_kernel<NPAD>;
@@ -275,8 +291,8 @@ static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, in
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "match_level_bwd: set smem attr: %s", hipGetErrorString(e));
   }
-  hipLaunchKernelGGL(kern, dim3(nblk, B), dim3(tpb), smem, st, x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores,
-                     dscores, ddst, ldo, dx, lddx, part, nblk, hw, C);
+  hipLaunchKernelGGL(kern, dim3(nblk, B, nslice), dim3(tpb), smem, st, x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores,
+                     dscores, ddst, ldo, dx, lddx, part, nblk, hw, C, nslice);
   return check_launch("match_bwd_kernel");
 }
 
@@ -308,6 +324,6 @@ extern "C" int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g
   else
     rc = launch_match_bwd<48>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(match_dg_finish_kernel, dim3(B), dim3(256), 0, st, scratch, ccvpe_match_bwd_nblk(hw), g, ldg, L, dg, ldg_out);
+  hipLaunchKernelGGL(match_dg_finish_kernel, dim3(B), dim3(256), 0, st, scratch, ccvpe_match_bwd_nblk(hw, B, C), g, ldg, L, dg, ldg_out);
   return check_launch("match_dg_finish_kernel");
 }

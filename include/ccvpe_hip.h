@@ -322,7 +322,7 @@ int ccvpe_gate_mul_f32(const float* u, const float* gate, float* v, int batch, i
  *       [B,n_shifts,HW] (may be NULL) is the gradient arriving at the returned score volume, ddst [B,HW,ldo]
  *       the gradient arriving at dstx (normalised features, max column, tail columns).  Writes dx [B,HW,lddx]
  *       (first `channels` columns) and dg [B,ldg_out] (first L entries).  The max routes its gradient to the
- *       first maximal shift, as torch.max does.  scratch: batch * ccvpe_match_bwd_nblk(hw) * (L+1) floats.
+ *       first maximal shift, as torch.max does.  scratch: batch * ccvpe_match_bwd_nblk(hw, batch, channels) * (L+1) floats.
  * ----------------------------------------------------------------------------------------- */
 #define CCVPE_HEAD_WGRAD_BLOCKS 1024
 #define CCVPE_HEAD_BWD_SCRATCH ((CCVPE_HEAD_WGRAD_BLOCKS + 1) * 2 * 145)
@@ -338,7 +338,7 @@ int ccvpe_add_cols_f32(const float* src, int ld_src, int col_off, float* dst, in
 int ccvpe_stem_wgrad_nblk(int batch, int in_h, int in_w);
 int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, float* dw, float* scratch, int batch, int in_h,
                               int in_w, int circular, void* stream);
-int ccvpe_match_bwd_nblk(int hw);
+int ccvpe_match_bwd_nblk(int hw, int batch, int channels);
 int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts,
                               int n_max, int n_tail, int stride, int window_offset, const float* scores, const float* dscores,
                               const float* ddst, int ldo, float* dx, int lddx, float* dg, int ldg_out, float* scratch,
