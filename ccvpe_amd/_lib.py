@@ -110,6 +110,9 @@ PROTOTYPES = {
     "ccvpe_train_targets_f32": (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "ccvpe_adam_chunk_elems": (c_int, []),
     "ccvpe_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [ctypes.c_double] * 4 + [c_int, c_void_p]),
+    "ccvpe_preprocess_u8_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
+                                        c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
+                                        c_void_p]),
     "ccvpe_conv_igemm_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p]),
     "ccvpe_stem_conv_bf16": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_bf16": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

@@ -134,7 +134,7 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
                            kh=2, kw=2, stride=2, shift=pk.sd_bias)
     if rec:
         tape.update(grd=gt, sat=st, gfeat=gfeat, y1=y1, gdesc=gdesc, svol=svol, gw=gw, circular=circular,
-                    match=[], loc=[], ori=[])
+                    match=[], loc=[], ori=[], pk=pk, live=live)
 
     loc_shifts = model._loc_shifts()
     scores_out = []
@@ -295,8 +295,7 @@ def backward_train(model, tape, gout, on_ready=None):
     data-parallel caller can start reducing them while the encoders' backward is still running."""
     spec = MODEL_SPECS[model.kind]
     n_rot = spec["n_rot"]
-    pk = model._packed()
-    live = model.state_dict(keep_vars=True)
+    pk, live = tape["pk"], tape["live"]          # the forward's packed weights / parameter table (nothing changed since)
     grads = {}
     dfeats = {}
     g_logits, g_heat, g_ori = gout[0], gout[1], gout[2]
@@ -420,8 +419,8 @@ class CVMFunction(torch.autograd.Function):
                 sync.finish(grads)
             else:
                 grads = backward_train(model, tape, gout)
+        live = tape["live"]
         ctx.tape = None
-        live = model.state_dict(keep_vars=True)
         out = []
         for nm in names:
             g = grads.get(nm)

@@ -377,6 +377,20 @@ int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* c
                         double beta1, double beta2, double eps, int step, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Input pipeline after JPEG decoding (csrc/preprocess.hip): transforms.Resize on a PIL image
+ * (= Pillow's antialiased 8-bit BILINEAR resampler, reproduced bit for bit), ToTensor, Normalize
+ * (train_VIGOR.py:57-70), torch.roll along W (datasets.py:112-121) and the FoV crop (train_VIGOR.py:177-178).
+ *   src [in_h][in_w][3] uint8 (device), tmp [in_h][out_w][3] uint8 scratch, dst [3][out_h][keep_w] fp32 (one sample
+ *   of the NCHW batch).  xbounds/ybounds [out][2] = (first source index, count), xcoef/ycoef [out][ksize] = Pillow's
+ *   22-bit fixed-point coefficients (ccvpe_amd/preprocess.py builds them as precompute_coeffs() does).
+ *   mean / std: HOST pointers to 3 floats.  roll: columns, as torch.roll's shift; keep_w <= out_w.
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_preprocess_u8_f32(const unsigned char* src, int in_h, int in_w, const int* xbounds, const int* xcoef,
+                            int xksize, const int* ybounds, const int* ycoef, int yksize, unsigned char* tmp, float* dst,
+                            int out_h, int out_w, int keep_w, int roll, const float* mean, const float* stdv,
+                            void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * bf16 storage variants (BASELINE configs C2 / C4).  Same kernels instantiated for bf16 NHWC
  * activations and bf16 packed weights (kpad a multiple of 32), fp32 accumulation on
  * v_mfma_f32_16x16x32_bf16, fp32 scale/shift/gate/bias, round-to-nearest-even on store.  Pointers

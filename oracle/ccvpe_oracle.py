@@ -330,6 +330,24 @@ def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0
 
 
 # ----------------------------------------------------------------------------------------
+# input pipeline after JPEG decoding
+# ----------------------------------------------------------------------------------------
+def preprocess_reference(img_u8, out_hw, roll=0, keep_w=None, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """train_VIGOR.py:57-70 transform (Resize -> ToTensor -> Normalize) with the arithmetic torchvision performs —
+    Resize on a PIL image IS PIL.Image.resize(BILINEAR) (third-party dependency: Pillow, 12.2.0 in this image; its
+    resampler is the algorithm ccvpe_amd/preprocess.py + csrc/preprocess.hip restate) — then the panorama roll of
+    datasets.py:121 and the FoV crop of train_VIGOR.py:177-178.  img_u8: numpy [H,W,3] uint8."""
+    import numpy as np
+    from PIL import Image
+    h, w = out_hw
+    im = Image.fromarray(np.ascontiguousarray(img_u8), "RGB").resize((w, h), Image.BILINEAR)
+    t = torch.from_numpy(np.asarray(im).copy()).permute(2, 0, 1).float().div(255)                     # ToTensor
+    t = (t - torch.tensor(mean).view(3, 1, 1)) / torch.tensor(std).view(3, 1, 1)                      # Normalize
+    t = torch.roll(t, int(roll), dims=2)
+    return t if keep_w is None else t[:, :, :keep_w]
+
+
+# ----------------------------------------------------------------------------------------
 # evaluation post-processing
 # ----------------------------------------------------------------------------------------
 def eval_postprocess(heatmap, ori):
