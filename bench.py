@@ -81,11 +81,17 @@ def cpu_baseline(sd, batch=8, reps=3):
                 sample="oracle forward, CVM_VIGOR_ori_prior(0), B=%d fp32, 1 warm-up + median of %d" % (batch, reps))
 
 
-def train_main(args, net, grd, sat, dev, world, rank, n_rot):
-    """One training step as train_VIGOR.py:193-229 / train_KITTI.py run it: forward (train mode), the three losses on
-    all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam."""
+def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot):
+    """Times `steps` training steps as train_VIGOR.py:193-229 / train_KITTI.py run them: ground truth, forward (train mode),
+    the three losses on all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam.
+    Returns (max-over-ranks seconds, last loss, peak HBM GiB)."""
     import torch
     from ccvpe_amd import harness, losses, optim, synth, targets
+
+    class _A(object):
+        pass
+    args = _A()
+    args.batch, args.steps, args.warmup = batch, steps, warmup
     net.train()
     # ground truth as datasets.py builds it (Gaussian sigma 4 px at a seeded offset, orientation bins, (cos, sin) map) and
     # train_VIGOR.py:120-128 pools it — generated on the device from 3 scalars per sample (ccvpe_train_targets_f32)
@@ -111,6 +117,12 @@ def train_main(args, net, grd, sat, dev, world, rank, n_rot):
 
     torch.cuda.reset_peak_memory_stats(dev)
     elapsed = harness.timed_steps(step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=dev)
+    return elapsed, float(last["loss"]), torch.cuda.max_memory_allocated(dev) / 2 ** 30
+
+
+def train_main(args, net, grd, sat, dev, world, rank, n_rot):
+    import torch
+    elapsed, loss, peak = train_measure(net, grd, sat, dev, args.batch, args.steps, args.warmup, rank, n_rot)
     if rank == 0:
         line = {
             "metric": "train image-pairs/sec", "value": round(args.batch * world * args.steps / elapsed, 2),
@@ -121,8 +133,7 @@ def train_main(args, net, grd, sat, dev, world, rank, n_rot):
                                    "infoNCE + 10 * orientation, backward, gradient all-reduce, Adam lr 1e-4)" % type(net).__name__,
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "dp%d (RCCL all-reduce of gradients in 3 groups, overlapped with the backward)" % world,
-                       "loss_after_last_step": round(float(last["loss"]), 5),
-                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 2)},
+                       "loss_after_last_step": round(loss, 5), "peak_hbm_gib": round(peak, 2)},
             "roofline": None, "cpu_baseline": None,
         }
         print(json.dumps(line))
@@ -291,6 +302,24 @@ def main():
                                                        "oracle, scores within 2e-2"}}
             except Exception as ex:      # the headline must not depend on the side measurement
                 line["extra"] = {"C2_bf16": {"error": repr(ex)}}
+            # second side measurement: BASELINE.json's metric string also names "(fwd+bwd) VIGOR bs=64" — the full training
+            # step of CVM_VIGOR (N_rot = 20) at batch 64: ground truth, train-mode forward, losses, backward, Adam
+            try:
+                del net2, g2, s2
+                del net
+                torch.cuda.empty_cache()
+                net3 = models.CVM_VIGOR(dev, True)
+                net3.load_state_dict(sd, strict=True)
+                net3 = net3.to(dev)
+                e3, loss3, peak3 = train_measure(net3, grd, sat, dev, args.batch, 3, 1, rank, 20)
+                line["extra"]["train_fwd_bwd_vigor_b64"] = {
+                    "workload": "CVM_VIGOR training step (device-side ground truth, train-mode forward, CE + 1e4 * mean infoNCE "
+                                "+ 10 * orientation, backward, Adam), batch %d, fp32" % args.batch,
+                    "value": round(args.batch * 3 / e3, 2), "unit": "img-pairs/s", "ms_per_step": round(1e3 * e3 / 3, 3),
+                    "steps": 3, "dtype": "f32", "peak_hbm_gib": round(peak3, 2),
+                    "parity": "tests/test_train_backward_gpu.py: gradients vs the reference's autograd golden (520 tensors)"}
+            except Exception as ex:
+                line["extra"]["train_fwd_bwd_vigor_b64"] = {"error": repr(ex)}
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
