@@ -1,5 +1,5 @@
-"""Backward building blocks for the dense convolutions of the path (fp32).  NOT yet wired into autograd:
-these are the tested pieces the training path will be assembled from.
+"""Backward building blocks of the path (fp32): thin wrappers over the backward entry points of libccvpe_hip.so.
+ccvpe_amd/train.py assembles them into the model's single autograd node.
 
   * weight gradients: ccvpe_conv_wgrad_f32 (MFMA pixel-reduction GEMM, csrc/conv_wgrad.hip);
   * input gradients: the FORWARD kernels with re-packed weights —

@@ -231,8 +231,8 @@ int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const floa
  * momentum 0.01, eps 1e-3; utils.py:129-154 drop_connect).  In train mode the conv kernels write their
  * raw output (ccvpe_conv_igemm_f32 with scale = shift = NULL, ccvpe_stem_conv_raw_f32,
  * ccvpe_dwconv_raw_f32), then:
- *   ccvpe_bn_stats_f32 : per-channel mean and BIASED variance of x [rows, channels] (Welford partials per
- *       256-row workgroup merged with Chan's formula: deterministic); if run_mean/run_var are given they
+ *   ccvpe_bn_stats_f32 : per-channel mean and BIASED variance of x [rows, channels] (shifted-sum partials per
+ *       workgroup merged in two levels with Chan's formula: deterministic); if run_mean/run_var are given they
  *       are updated in place: run = (1-momentum)*run + momentum*(mean | UNBIASED variance).
  *       scratch: 3 * channels * ccvpe_bn_stats_nblk(rows) floats.
  *   ccvpe_bn_act_f32   : y = act((x-mean)/sqrt(var+eps)*gamma+beta) [* dc_scale[b]] [+ residual]; with
@@ -252,7 +252,7 @@ int ccvpe_bn_act_f32(const float* x, const float* mean, const float* var, const 
                      float* se_partial, int batch, int rows_per_sample, int channels, void* stream);
 
 /* -------------------------------------------------------------------------------------------
- * Backward building blocks (the autograd wiring is not built yet).
+ * Backward building blocks (wired into one torch.autograd.Function for the whole model by ccvpe_amd/train.py).
  *   ccvpe_conv_wgrad_f32: weight gradient of any dense conv of the path,
  *       dw[n][tap][c] = sum_pixels dy[pixel][n] * x[pixel*stride - pad + tap][c]     (layout O,kh,kw,I)
  *     x given as one or two concatenated NHWC sources (like the forward), dy [batch,Ho,Wo,ldy].
