@@ -156,6 +156,11 @@ def se_bwd(se_partial, hw, dgate_partial, w1, b1, w2t, b2):
 
 
 def dwconv_dgrad(dy, w, in_h, in_w, k, stride, circular):
+    """w: packed depthwise weights [k*k, C] or [k, k, C].  Stride 1 is the forward depthwise kernel with the taps
+    reversed (symmetric SAME padding, zero or circular): the register-sliding strip kernel instead of a gather."""
+    if stride == 1:
+        c = dy.shape[-1]
+        return ops.dwconv_raw(dy, w.reshape(k * k, c).flip(0).contiguous(), k, 1, circular)
     lib = _lib.load()
     ops._chk(dy, "dy")
     ops._chk(w, "w")

@@ -31,46 +31,52 @@ struct WgradParams {
 
 constexpr int WG_T = 64;    // tile: 64 output channels x 64 input channels
 constexpr int WG_BP = 32;   // pixels per stage
-constexpr int WG_LD = 68;   // LDS row stride (floats): 64 + 4
 
-// TN = output channels per tile (64, 32 or 16: the decoder's last levels have N = 16..32 and millions of pixels, a
-// 64-row tile would spend 4-16x the MFMA work on padding).  The 64 tile columns index (tap, input channel) jointly:
-// col = tap*Ctot + c, so narrow layers (Ctot = 16..48) fill the tile with several taps instead of zero columns.
-template <int TN>
+// TN x TC = output channels x columns per tile.  TN = 16 / 32 for the decoder's last levels (N = 16..32 and millions of
+// pixels: a 64-row tile would spend 4-16x the MFMA work on padding); 128 x 128 for the wide layers, where a 64 x 64 tile
+// (16 FLOP per byte staged) is bound by L2 -> LDS bandwidth: every dY panel is re-read by each column tile and vice versa.
+// The tile columns index (tap, input channel) jointly: col = tap*Ctot + c, so narrow layers (Ctot = 16..48) fill the
+// tile with several taps instead of zero columns.
+template <int TN, int TC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  constexpr int NI = TN >= 32 ? 2 : 1;              // 16-row MFMA tiles per wave along n
-  constexpr int NJ = TN == 64 ? 2 : 1;              // 16-col MFMA tiles per wave along columns
-  __shared__ __attribute__((aligned(16))) float Ys[2][WG_BP][TN + 4];   // dY  [pixel][n]
-  __shared__ __attribute__((aligned(16))) float Xs[2][WG_BP][WG_LD];    // X   [pixel][col]
+  constexpr bool SQ = TN >= 64;                       // 2 x 2 waves of (TN/2) x (TC/2); else 4 waves of TN x (TC/4)
+  constexpr int NI = (SQ ? TN / 2 : TN) / 16;         // 16-row MFMA tiles per wave along n
+  constexpr int NJ = (SQ ? TC / 2 : TC / 4) / 16;     // 16-col MFMA tiles per wave along columns
+  constexpr int YP = (TN + 31) / 32;                  // float4 pieces per thread per stage (dY): columns (tid&7)*4 + 32*q
+  constexpr int XP = TC / 32;                         // float4 pieces per thread per stage (X)
+  constexpr int YLD = TN + 4, XLD = TC + 4;
+  extern __shared__ __attribute__((aligned(16))) float wsm[];
+  float* Ys = wsm;                                    // [2][WG_BP][YLD]   dY [pixel][n]
+  float* Xs = wsm + 2 * WG_BP * YLD;                  // [2][WG_BP][XLD]   X  [pixel][col]
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wn = TN == 64 ? wave >> 1 : 0;          // TN == 64: 2 x 2 waves of 32 x 32;  else 4 waves of TN x 16
-  const int wc = TN == 64 ? wave & 1 : wave;
+  const int wn = SQ ? wave >> 1 : 0;
+  const int wc = SQ ? wave & 1 : wave;
   int bid = blockIdx.x;
   const int tc = bid % p.tiles_c; bid /= p.tiles_c;
   const int tn = bid % p.tiles_n;
   const int split = bid / p.tiles_n;
-  const int n0 = tn * TN, cc0 = tc * WG_T;
+  const int n0 = tn * TN, cc0 = tc * TC;
   const int ctot = p.c0 + p.c1;
   const int ncols = p.taps * ctot;
   const int m_begin = split * p.pix_per_split;
   const int m_end = min(m_begin + p.pix_per_split, p.M);
 
-  // staging: thread -> (pixel row = tid >> 3 (0..31), two float4 pieces at tile column (tid & 7) * 8 + {0, 4})
+  // staging: thread -> pixel row tid >> 3 (0..31), float4 pieces at tile column (tid & 7) * 4 + 32 * q
   const int prow = tid >> 3;
-  const int pc = (tid & 7) * 8;
-  int pky[2], pkx[2], pch[2];                        // per piece: tap offsets and input channel (stage-invariant)
-  bool pok[2];
+  const int pc = (tid & 7) * 4;
+  int pky[XP], pkx[XP], pch[XP];                     // per X piece: tap offsets and input channel (stage-invariant)
+  bool pok[XP];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int col = cc0 + pc + q * 4;
+  for (int q = 0; q < XP; ++q) {
+    const int col = cc0 + pc + 32 * q;
     pok[q] = col < ncols;
     const int tap = pok[q] ? col / ctot : 0;
     pch[q] = col - tap * ctot;
     pky[q] = tap / p.kw;
     pkx[q] = tap - pky[q] * p.kw;
   }
-  f32x4 yr[2], xr[2];
+  f32x4 yr[YP], xr[XP];
 
   auto load_stage = [&](int m0) {
     const int m = m0 + prow;
@@ -84,17 +90,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       ox = rem - oy * p.Wo;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (pc + q * 4 < TN) {
-        const int n = n0 + pc + q * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int q = 0; q < YP; ++q) {
+      const int nl = pc + 32 * q;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nl < TN) {
+        const int n = n0 + nl;
         if (ok && n < p.N) {
           if (n + 3 < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + n);
           else
             for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
         }
-        yr[q] = v;
       }
+      yr[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < XP; ++q) {
       const int iy = oy * p.stride - p.pad + pky[q], ix = ox * p.stride - p.pad + pkx[q];
       f32x4 u = {0.f, 0.f, 0.f, 0.f};
       if (ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
@@ -108,10 +118,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (pc + q * 4 < TN) *reinterpret_cast<f32x4*>(&Ys[buf][prow][pc + q * 4]) = yr[q];
-      *reinterpret_cast<f32x4*>(&Xs[buf][prow][pc + q * 4]) = xr[q];
-    }
+    for (int q = 0; q < YP; ++q)
+      if (pc + 32 * q < TN) *reinterpret_cast<f32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = yr[q];
+#pragma unroll
+    for (int q = 0; q < XP; ++q) *reinterpret_cast<f32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = xr[q];
   };
 
   f32x4 acc[NI][NJ];
@@ -134,10 +144,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
     for (int g = 0; g < WG_BP / 4; ++g) {
       float a[NI], bb[NJ];
+      const float* yrow = &Ys[(buf * WG_BP + g * 4 + fq) * YLD + wn * NI * 16 + fi];
+      const float* xrow = &Xs[(buf * WG_BP + g * 4 + fq) * XLD + wc * NJ * 16 + fi];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = Ys[buf][g * 4 + fq][(wn * NI + i) * 16 + fi];
+      for (int i = 0; i < NI; ++i) a[i] = yrow[i * 16];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bb[j] = Xs[buf][g * 4 + fq][(wc * NJ + j) * 16 + fi];
+      for (int j = 0; j < NJ; ++j) bb[j] = xrow[j * 16];
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -231,14 +243,23 @@ static int wgrad_splits(int M, int tiles, int taps) {
 }
 
 static int wgrad_tn(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
+// the 128 x 128 tile pays when both dimensions fill it and enough tiles remain to split the pixels over
+static bool wgrad_big(int n, int ncols) {
+  const int padded = (n + 127) / 128 * 128;
+  return n >= 128 && ncols >= 512 && (padded - n) * 4 <= n;        // at most 25 % of the MFMA rows are padding
+}
+static int wgrad_tile_count(int n, int ncols) {
+  if (wgrad_big(n, ncols)) return ((n + 127) / 128) * ((ncols + 127) / 128);
+  const int tn = wgrad_tn(n);
+  return ((n + tn - 1) / tn) * ((ncols + WG_T - 1) / WG_T);
+}
 
 extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad,
                                                int ctot, int n) {
   const int Ho = (in_h + 2 * pad - kh) / stride + 1, Wo = (in_w + 2 * pad - kw) / stride + 1;
   const long M = (long)batch * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL || ctot <= 0 || n <= 0) return CCVPE_EINVAL;
-  const int tn = wgrad_tn(n);
-  const int tiles = ((n + tn - 1) / tn) * ((kh * kw * ctot + WG_T - 1) / WG_T);
+  const int tiles = wgrad_tile_count(n, kh * kw * ctot);
   const int S = wgrad_splits((int)M, tiles, kh * kw);
   const long fl = (long)S * n * kh * kw * ctot;
   return fl > 0x7fffffffL ? CCVPE_EINVAL : (int)fl;
@@ -262,16 +283,27 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   if (M <= 0 || M > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv_wgrad: bad M");
   p.M = (int)M;
   const int ctot = c0 + c1;
-  const int tn = wgrad_tn(n);
+  const bool big = wgrad_big(n, p.taps * ctot);
+  const int tn = big ? 128 : wgrad_tn(n);
+  const int tcw = big ? 128 : WG_T;
   p.tiles_n = (n + tn - 1) / tn;
-  p.tiles_c = (p.taps * ctot + WG_T - 1) / WG_T;
+  p.tiles_c = (p.taps * ctot + tcw - 1) / tcw;
   p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps);
   p.pix_per_split = ((p.M + p.S - 1) / p.S + WG_BP - 1) / WG_BP * WG_BP;
   hipStream_t st = (hipStream_t)stream;
   const long blocks = (long)p.tiles_n * p.tiles_c * p.S;
-  if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32>), dim3((unsigned)blocks), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((conv_wgrad_kernel<64>), dim3((unsigned)blocks), dim3(256), 0, st, p);
+  const size_t lds = sizeof(float) * 2 * WG_BP * ((size_t)(tn + 4) + (tcw + 4));
+  if (big) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)conv_wgrad_kernel<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "conv_wgrad: set smem attr: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  } else if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   const long n_elem = (long)n * p.taps * ctot;
   launch_sum_parts(scratch, p.S, n_elem, (int)n_elem, dw, st);
   return check_launch("conv_wgrad");
