@@ -626,7 +626,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
 // K slices for a GEMM with `tiles` workgroups and `stages` K stages (1 = no split): only when the launch cannot fill
 // the 256 CUs and the serial K walk is long; each slice keeps >= 12 stages
 static int splitk_slices(int tiles, int stages) {
-  if (tiles >= 200 || stages < 24) return 1;
+  if (tiles >= 320 || stages < 24) return 1;
   int s = (640 + tiles - 1) / tiles;
   if (s > stages / 12) s = stages / 12;
   if (s > 32) s = 32;
