@@ -146,3 +146,31 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.ccvpe_mbconv_front_nblk(8, 8, 16, 96, 4, 1) == EINVAL
     assert lib.ccvpe_mbconv_front_nblk(16, 16, 192, 1152, 3, 1) == 0        # valid but unfused shape
     assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 1) == 4          # 64 output rows / 16 per band
+
+
+def test_planning_entry_points_without_a_gpu():
+    """The size / split planners are pure host code: callable on a box without a GPU."""
+    import ctypes
+    EINVAL = -1
+    lib = _lib.load()
+    d = _lib.ConvDesc()
+    d.src0 = d.w = d.dst = 256
+    d.c0, d.ld0, d.batch, d.in_h, d.in_w = 1344, 1344, 1, 16, 16
+    d.kh = d.kw = 3
+    d.stride, d.pad, d.n, d.kpad, d.ldd = 1, 1, 640, 9 * 1344, 640
+    want = lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0)          # B = 1, level-6 3x3: 8 tiles, 756 K stages
+    assert want > 0 and want % (256 * 640) == 0 and 2 <= want // (256 * 640) <= 32
+    d.batch = 64                                                            # B = 64: 512 tiles -> one pass
+    assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0) == 0
+    d.batch, d.c0 = 1, 1343
+    assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0) == EINVAL
+    assert lib.ccvpe_conv_igemm_splitk_f32(ctypes.byref(d), None, None) == EINVAL      # no scratch
+    # matching backward: channel slices only when there are few pixel workgroups
+    assert lib.ccvpe_match_bwd_nblk(64, 8, 2048) > lib.ccvpe_match_bwd_nblk(64, 8, 64) >= 1
+    assert lib.ccvpe_match_bwd_nblk(65536, 64, 32) == 256
+    # BatchNorm statistics: partial rows + one group row per 64 partials, bounded for huge tensors
+    assert lib.ccvpe_bn_stats_nblk(256) == 1
+    assert 4096 <= lib.ccvpe_bn_stats_nblk(64 * 512 * 512) <= 4096 + 64 + 1
+    assert lib.ccvpe_dwconv_wgrad_nblk(64, 64, 3, 1) == 64 and lib.ccvpe_dwconv_wgrad_nblk(256, 256, 3, 2) == 64
+    assert lib.ccvpe_conv_wgrad_scratch_floats(2, 16, 16, 3, 3, 1, 1, 1344, 640) > 0
+    assert lib.ccvpe_adam_chunk_elems() == 4096 and lib.ccvpe_train_targets_nblk(512, 512) == 256
