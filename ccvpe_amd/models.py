@@ -71,6 +71,8 @@ def _pad2(w, dtype=torch.float32, n_mult=16):
     """Zero-pad [N,K] to N%16==0 and K to one 64-byte stage row (16 fp32 / 32 bf16), cast to dtype."""
     k_mult = 16 if dtype == torch.float32 else 32
     n, k = w.shape
+    if n % n_mult == 0 and k % k_mult == 0:          # nothing to pad (most conv weights): one copy kernel instead of three
+        return w.to(dtype).contiguous()
     out = w.new_zeros((_round_up(n, n_mult), _round_up(k, k_mult)))
     out[:n, :k] = w
     return out.to(dtype).contiguous()

@@ -34,7 +34,7 @@ def _round_up(v, m):
 # ------------------------------------------------------------------------------------------------------
 def _bn(model, live, name, x_raw, act, residual=None, dc=None, want_se=False):
     mean, var = ops.bn_stats(x_raw, live[name + ".running_mean"], live[name + ".running_var"], model.BN_MOMENTUM)
-    live[name + ".num_batches_tracked"].add_(1)
+    model._nbt_pending.append(live[name + ".num_batches_tracked"])      # bumped once per forward with one foreach add
     out = ops.bn_act(x_raw, mean, var, live[name + ".weight"].detach(), live[name + ".bias"].detach(), BN_EPS, act,
                      residual=residual, dc_scale=dc, want_se=want_se)
     return out, mean, var
@@ -120,6 +120,7 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     sat = sat.contiguous().float()
     batch = grd.shape[0]
     tape = {} if rec else None
+    model._nbt_pending = []
 
     gfeat, _, gt = encoder_forward(model, pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks, rec)
     _, gh, gw, _ = gfeat.shape
@@ -130,6 +131,8 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
     svol, sfeats, st = encoder_forward(model, pk.sat, live, "sat_efficientnet", sat, False, True, drop_masks, rec)
     model._stats_epoch = getattr(model, "_stats_epoch", 0) + 1      # the folded (eval) pack is stale now
+    torch._foreach_add_(model._nbt_pending, 1)                      # num_batches_tracked += 1 for all 98 BatchNorms
+    model._nbt_pending = []
     sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1], in_w=svol.shape[2],
                            kh=2, kw=2, stride=2, shift=pk.sd_bias)
     if rec:
