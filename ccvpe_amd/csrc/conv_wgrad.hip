@@ -174,15 +174,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
-                                                           long n_elem, int S) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_elem) return;
-  float s = 0.f;
-  for (int k = 0; k < S; ++k) s += part[(size_t)k * n_elem + i];
-  dw[i] = s;
-}
-
 // per-channel column sums (bias gradients): partial per CS_ROWS-row block (all 256 threads busy: channel lanes x
 // row lanes, combined through LDS in lane order), then the fixed-order parallel reduce
 constexpr int CS_ROWS = 1024;

@@ -20,15 +20,6 @@ __device__ __forceinline__ float block_sum_b(float v, float* sh) {
   return t;
 }
 
-static __global__ __launch_bounds__(256) void sum_parts2_kernel(const float* __restrict__ part, int nparts, int n,
-                                                                float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a = 0.f;
-  for (int k = 0; k < nparts; ++k) a += part[(size_t)k * n + i];
-  out[i] = a;
-}
-
 // dlogits = h * (dh - <h, dh>) (+ dlogits_direct)
 __global__ __launch_bounds__(1024) void softmax_bwd_kernel(const float* __restrict__ h, const float* __restrict__ dh,
                                                            const float* __restrict__ dl_direct,

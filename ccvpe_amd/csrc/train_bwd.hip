@@ -104,19 +104,6 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p,
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_merge_kernel(const float* __restrict__ part, int nparts, int C,
-                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  float a = 0.f, b = 0.f;
-  for (int k = 0; k < nparts; ++k) {
-    a += part[(size_t)k * 2 * C + c];
-    b += part[(size_t)k * 2 * C + C + c];
-  }
-  dbeta[c] = a;
-  dgamma[c] = b;
-}
-
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p, const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float inv_m,
                                                            float* __restrict__ dx) {
@@ -411,15 +398,6 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
       __syncthreads();
     }
   }
-}
-
-__global__ __launch_bounds__(256) void sum_parts_kernel(const float* __restrict__ part, int nparts, int n,
-                                                        float* __restrict__ out) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a = 0.f;
-  for (int k = 0; k < nparts; ++k) a += part[(size_t)k * n + i];
-  out[i] = a;
 }
 
 }  // namespace ccvpe

@@ -4,8 +4,10 @@ Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may
 module; the product (`ccvpe_amd/`) never does and fails loudly without its HIP library.
 
 What it is: a functional, fp32, torch-CPU restatement of the reference's algorithm for
-`CVM_VIGOR` / `CVM_VIGOR_ori_prior` / `CVM_KITTI` `forward(grd, sat)` (eval mode) and the
-three losses, written from the reference's behaviour and restructured (no nn.Module tree, BN
+`CVM_VIGOR` / `CVM_VIGOR_ori_prior` / `CVM_KITTI` / `CVM_OxfordRobotCar` `forward(grd, sat)` (eval mode, and train
+mode with batch-statistic BatchNorm + injected drop_connect draws; differentiable, so autograd through it gives
+reference gradients), the three losses, the training ground truth of the datasets and the PIL/torchvision input
+transform, written from the reference's behaviour and restructured (no nn.Module tree, BN
 applied from running statistics, one fused ground-descriptor contraction, the aerial
 descriptor as a 2x2/s2 convolution, rotational matching in closed circulant form).  All
 arithmetic is delegated to torch CPU kernels exactly as the reference delegates to torch
@@ -14,7 +16,8 @@ of its own).
 
 Parity pinning: this oracle is pinned against the reference ITSELF, imported in the build
 container by `tools/make_golden.py`; the resulting vectors are committed under
-`tests/golden/` and re-checked by `tests/test_oracle_golden.py` everywhere, and
+`tests/golden/` (5 eval forwards, a train-mode forward with running statistics, the reference's autograd gradients
+for 520 parameter tensors, per-module outputs, losses) and re-checked by `tests/test_oracle_golden.py` everywhere, and
 `tests/test_oracle_vs_reference.py` compares live whenever /root/reference is present.
 
 Every function cites the reference file:line it follows (paths under /root/reference).
