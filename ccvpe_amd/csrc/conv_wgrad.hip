@@ -179,13 +179,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 constexpr int CS_ROWS = 1024;
 template <int V>   // V = 4: one 16-byte load per (row, 4 channels); V = 1: scalar (unaligned / odd channel counts)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int rows, int C, int ld,
-                                                            float* __restrict__ part) {
+                                                            float* __restrict__ part, int rpb) {
   __shared__ __attribute__((aligned(16))) float red[256 * V];
   const int cgn = C / V;
   const int cw = cgn < 256 ? cgn : 256;
   const int R = 256 / cw;
   const int cl = threadIdx.x % cw, rr = threadIdx.x / cw;
-  const int r0 = blockIdx.x * CS_ROWS, r1 = min(r0 + CS_ROWS, rows);
+  const int r0 = blockIdx.x * rpb, r1 = min(r0 + rpb, rows);
   for (int c0 = 0; c0 < cgn; c0 += cw) {
     const int cg = c0 + cl;
     float s[V];
@@ -303,12 +303,16 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
 extern "C" int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch,
                                 void* stream) {
   if (rows <= 0 || channels <= 0 || ld < channels) return fail(CCVPE_EINVAL, "colsum: bad shape");
-  const int nblk = (rows + CS_ROWS - 1) / CS_ROWS;
+  // rows per workgroup: CS_ROWS for big tensors, fewer for small ones so that at least ~256 workgroups share the walk
+  // (the caller's scratch is sized for ceil(rows / 256) partial rows)
+  int rpb = CS_ROWS;
+  if (rows < CS_ROWS * 256) rpb = rows / 256 < 256 ? 256 : rows / 256;
+  const int nblk = (rows + rpb - 1) / rpb;
   hipStream_t st = (hipStream_t)stream;
   if (channels % 4 == 0 && ld % 4 == 0 && aligned16(x))
-    hipLaunchKernelGGL((colsum_partial_kernel<4>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
+    hipLaunchKernelGGL((colsum_partial_kernel<4>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch, rpb);
   else
-    hipLaunchKernelGGL((colsum_partial_kernel<1>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch);
+    hipLaunchKernelGGL((colsum_partial_kernel<1>), dim3(nblk), dim3(256), 0, st, x, rows, channels, ld, scratch, rpb);
   launch_sum_parts(scratch, nblk, channels, channels, out, st);
   return check_launch("colsum");
 }

@@ -204,6 +204,8 @@ constexpr int BNS_GROUP = 64;
 static void bn_stats_geometry(long rows, int* rpb, int* nblk, int* ngroups) {
   const long mult = (rows + (long)BNS_ROWS * 4096 - 1) / ((long)BNS_ROWS * 4096);
   *rpb = (int)(BNS_ROWS * (mult < 1 ? 1 : mult));
+  if (rows < 65536) *rpb = 32;       // small tensors (late blocks, small batches): more, shorter workgroups — a handful of
+                                     // workgroups walking 256 rows each is pure load latency
   *nblk = (int)((rows + *rpb - 1) / *rpb);
   *ngroups = *nblk > BNS_GROUP ? (*nblk + BNS_GROUP - 1) / BNS_GROUP : 0;
 }
