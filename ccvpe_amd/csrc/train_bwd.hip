@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restr
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int c = tid; c < C; c += 256) {
     float s = 0.f;
+#pragma unroll 8
     for (int k = 0; k < nblk; ++k) s += se_partial[((size_t)b * nblk + k) * C + c];
     m[c] = s * inv_hw;
     m_o[(size_t)b * C + c] = s * inv_hw;
@@ -501,9 +502,11 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restr
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float z = b2[c];
+#pragma unroll 8
     for (int s = 0; s < Cs; ++s) z = fmaf(w2t[(size_t)s * C + c], a[s], z);
     const float g = sigmoidf(z);
     float dg = 0.f;
+#pragma unroll 8
     for (int k = 0; k < ndg; ++k) dg += dg_partial[((size_t)b * ndg + k) * C + c];
     const float d = dg * g * (1.0f - g);
     dz2[c] = d;
@@ -524,6 +527,7 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restr
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dm = 0.f;
+#pragma unroll 8
     for (int s = 0; s < Cs; ++s) dm = fmaf(w1[(size_t)s * C + c], dz1[s], dm);
     dmean_o[(size_t)b * C + c] = dm * inv_hw;
   }
