@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void add_cols_kernel(const float* __restrict__
 
 // stem weight gradient: dw[ky][kx][ci][co] = sum_{b,oy,ox} dy[b,oy,ox,co] * xpad[b,ci,2oy+ky,2ox+kx]
 // 256 threads = 8 pixel lanes x 32 output channels, 27 accumulators each.
-constexpr int SW_PX = 2048;   // output pixels per workgroup
+constexpr int SW_PX = 512;    // output pixels per workgroup (64 per pixel lane: short serial chains, thousands of workgroups)
 __global__ __launch_bounds__(256) void stem_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                          float* __restrict__ part, int B, int H, int W, int Ho, int Wo,
                                                          int circular) {
