@@ -77,8 +77,10 @@ def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
     assert (post2 - post1).abs().max().item() < 1e-3 * scale          # and equals torch.optim.Adam's step
 
 
-@pytest.mark.parametrize("kind,ori_noise,circular", [("kitti", None, False), ("vigor", 36, True), ("oxford", None, False)])
-def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise, circular):
+@pytest.mark.parametrize("kind,ori_noise,circular,grd_key", [("kitti", None, False, "kitti"), ("vigor", 36, True, "vigor"),
+                                                             ("oxford", None, False, "oxford"),
+                                                             ("vigor", None, False, "vigor_fov180")])
+def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise, circular, grd_key):
     """CVM_KITTI and CVM_VIGOR_ori_prior (5 localisation shifts + the recomputed 20-shift level-6 volume): no reference
     golden is stored for these, so the gradients are compared with autograd through the oracle on the CPU."""
     from ccvpe_amd import models
@@ -88,11 +90,13 @@ def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise
         net = models.CVM_KITTI("cuda")
     elif kind == "oxford":
         net = models.CVM_OxfordRobotCar("cuda")
+    elif ori_noise is None:                      # FoV 180: half-width ground image, partial matching windows (L = C/2)
+        net = models.CVM_VIGOR("cuda", circular)
     else:
         net = models.CVM_VIGOR_ori_prior("cuda", ori_noise, circular)
     net.load_state_dict(sd, strict=True)
     net = net.to("cuda:0").train()
-    grd, sat = synth.synthetic_pair(2, kind, 31)
+    grd, sat = synth.synthetic_pair(2, grd_key, 31)
     masks, scales, _ = G.train_drop_masks(2)
     out = net(grd.cuda(), sat.cuda(), drop_masks=masks)
     G.train_loss(out).backward()
