@@ -94,10 +94,13 @@ class _Obj(object):
     pass
 
 
-def _pack_encoder(sd, p, dtype=torch.float32):
+def _pack_encoder(sd, p, dtype=torch.float32, fold_bn=True):
+    """fold_bn=False (train mode): BatchNorm uses batch statistics, the folded scale/shift would be ~800 tiny launches
+    per step for nothing."""
+    fold = _fold_bn if fold_bn else (lambda _sd, _p: (None, None))
     e = _Obj()
     e.stem_w = sd[p + "._conv_stem.weight"].permute(2, 3, 1, 0).contiguous()      # [ky][kx][ci][co]
-    e.stem_scale, e.stem_shift = _fold_bn(sd, p + "._bn0")
+    e.stem_scale, e.stem_shift = fold(sd, p + "._bn0")
     e.blocks = []
     for i, (k, s, ex, cin, cout) in enumerate(B0_BLOCKS):
         b = _Obj()
@@ -105,19 +108,19 @@ def _pack_encoder(sd, p, dtype=torch.float32):
         b.k, b.s, b.expand, b.cin, b.cout, b.mid = k, s, ex != 1, cin, cout, cin * ex
         if b.expand:
             b.w_exp = _pack_conv(sd[bp + "._expand_conv.weight"], dtype)
-            b.s0, b.b0 = _fold_bn(sd, bp + "._bn0")
+            b.s0, b.b0 = fold(sd, bp + "._bn0")
         b.w_dw = sd[bp + "._depthwise_conv.weight"].reshape(b.mid, k, k).permute(1, 2, 0).contiguous()
-        b.s1, b.b1 = _fold_bn(sd, bp + "._bn1")
+        b.s1, b.b1 = fold(sd, bp + "._bn1")
         b.se_w1 = sd[bp + "._se_reduce.weight"].reshape(-1, b.mid).contiguous()
         b.se_b1 = sd[bp + "._se_reduce.bias"].contiguous()
         b.se_w2 = sd[bp + "._se_expand.weight"].reshape(b.mid, -1).t().contiguous()      # [Cs][C]
         b.se_b2 = sd[bp + "._se_expand.bias"].contiguous()
         b.w_proj = _pack_conv(sd[bp + "._project_conv.weight"], dtype)
-        b.s2, b.b2 = _fold_bn(sd, bp + "._bn2")
+        b.s2, b.b2 = fold(sd, bp + "._bn2")
         b.skip = (s == 1 and cin == cout)                                          # model.py:126
         e.blocks.append(b)
     e.w_head = _pack_conv(sd[p + "._conv_head.weight"], dtype)
-    e.head_scale, e.head_shift = _fold_bn(sd, p + "._bn1")
+    e.head_scale, e.head_shift = fold(sd, p + "._bn1")
     return e
 
 
@@ -189,8 +192,8 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True):
     spec = MODEL_SPECS[kind]
     pk = _Obj()
     pk.dtype = dtype
-    pk.grd = _pack_encoder(sd, "grd_efficientnet", dtype)
-    pk.sat = _pack_encoder(sd, "sat_efficientnet", dtype)
+    pk.grd = _pack_encoder(sd, "grd_efficientnet", dtype, fold_bn=fold)
+    pk.sat = _pack_encoder(sd, "sat_efficientnet", dtype, fold_bn=fold)
     # six ground-descriptor heads fused into one 1x1 GEMM (N = sum Cd) + height collapse
     ws, bs, wh, bh = [], [], [], []
     for l in range(1, 7):
