@@ -169,7 +169,7 @@ def test_planning_entry_points_without_a_gpu():
     assert lib.ccvpe_match_bwd_nblk(64, 8, 2048) > lib.ccvpe_match_bwd_nblk(64, 8, 64) >= 1
     assert lib.ccvpe_match_bwd_nblk(65536, 64, 32) == 256
     # BatchNorm statistics: partial rows + one group row per 64 partials, bounded for huge tensors
-    assert lib.ccvpe_bn_stats_nblk(256) == 1
+    assert lib.ccvpe_bn_stats_nblk(256) == 8                               # small tensors: 32-row workgroups
     assert 4096 <= lib.ccvpe_bn_stats_nblk(64 * 512 * 512) <= 4096 + 64 + 1
     assert lib.ccvpe_dwconv_wgrad_nblk(64, 64, 3, 1) == 64 and lib.ccvpe_dwconv_wgrad_nblk(256, 256, 3, 2) == 64
     assert lib.ccvpe_conv_wgrad_scratch_floats(2, 16, 16, 3, 3, 1, 1, 1344, 640) > 0
