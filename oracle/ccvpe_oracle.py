@@ -308,16 +308,17 @@ def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0
         x, y = np.meshgrid(np.linspace(-width / 2 + cx, width / 2 + cx, width),
                            np.linspace(-height / 2 + cy, height / 2 + cy, height))
         d = np.sqrt(x * x + y * y)
-        g = np.exp(-(d ** 2 / (2.0 * sigma ** 2))).astype(np.float32)
+        e = np.exp(-(d ** 2 / (2.0 * sigma ** 2)))            # float64, rounded to float32 once per use like the reference
+        g = e.astype(np.float32)
         w = np.zeros([n_bins, height, width], dtype=np.float32)
         index = int(ang // bw)
         ratio = (ang % bw) / bw
         if index == 0:
-            w[0] = g * (1 - ratio)
-            w[n_bins - 1] = g * ratio
+            w[0] = e * (1 - ratio)
+            w[n_bins - 1] = e * ratio
         else:
-            w[n_bins - index] = g * (1 - ratio)
-            w[n_bins - index - 1] = g * ratio
+            w[n_bins - index] = e * (1 - ratio)
+            w[n_bins - index - 1] = e * ratio
         gts.append(g[None])
         gwo.append(w)
         o = np.empty([2, height, width], dtype=np.float32)

@@ -37,3 +37,55 @@ def test_state_dict_layout_matches_reference():
         assert [k for k, _, _ in spec] == list(ref.keys())
         for k, shape, _ in spec:
             assert tuple(ref[k].shape) == tuple(shape), k
+
+
+def test_dataset_ground_truth_and_input_transform_live(tmp_path):
+    """run the reference's own VIGORDataset.__getitem__ (datasets.py:98-177) on a tiny synthetic dataset
+    directory and compare its ground truth (gt, gt_with_ori, orientation) with oracle.train_targets, and its ground image
+    (Resize -> ToTensor -> Normalize given as the transform, then the dataset's torch.roll) with
+    oracle.preprocess_reference.  torchvision is absent here, so the transform passed in is the PIL + torch arithmetic
+    torchvision performs (PIL is the real dependency)."""
+    import numpy as np
+    import torch.nn.functional as F
+    from PIL import Image
+    from ref_import import import_reference_datasets
+    D = import_reference_datasets()
+    root = tmp_path
+    cities = ["NewYork", "Seattle", "SanFrancisco", "Chicago"]
+    rng = np.random.RandomState(3)
+    deltas = {}
+    for ci, city in enumerate(cities):
+        (root / "splits_new" / city).mkdir(parents=True)
+        (root / city / "satellite").mkdir(parents=True)
+        (root / city / "panorama").mkdir(parents=True)
+        sat = (rng.rand(64, 64, 3) * 255).astype(np.uint8)
+        Image.fromarray(sat, "RGB").save(root / city / "satellite" / "s.png")
+        pano = (rng.rand(96, 192, 3) * 255).astype(np.uint8)
+        Image.fromarray(pano, "RGB").save(root / city / "panorama" / "p.png")
+        (root / "splits_new" / city / "satellite_list.txt").write_text("s.png\n")
+        d = (7.0 * ci - 5.0, -3.0 * ci + 11.0)                  # (row, col) offsets in raw satellite pixels
+        deltas[city] = d
+        line = "p.png " + " ".join("s.png %f %f" % d for _ in range(4)) + "\n"
+        (root / "splits_new" / city / "same_area_balanced_train.txt").write_text(line)
+
+    def tf(hw):
+        return lambda im: O.preprocess_reference(np.asarray(im.convert("RGB")), hw)
+    orient = np.array([0.0, 17.5, 200.25, 359.0])
+    ds = D.VIGORDataset(str(root), split="samearea", train=True, transform=(tf((320, 640)), tf((512, 512))),
+                        pos_only=True, ori_noise=180, random_orientation=orient)
+    assert len(ds) == 4
+    for i, city in enumerate(cities):
+        grd, sat, gt, gt_with_ori, orientation, _, angle = ds[i]
+        assert abs(angle - orient[i]) < 1e-9
+        # ---- ground truth: cx = col_offset, cy = -row_offset (offsets rescaled to the 512 grid as the dataset does)
+        row = np.round(deltas[city][0] / 64 * 512)
+        col = np.round(deltas[city][1] / 64 * 512)
+        g, flat, ori, labs = O.train_targets([[col, -row]], [orient[i]], 20)
+        assert torch.equal(g[0], gt) and torch.equal(ori[0], orientation)
+        for k, lab in zip((64, 32, 16, 8, 4, 2), labs):
+            assert torch.equal(lab[0], F.max_pool2d(gt_with_ori[None], k, stride=k)[0])
+        assert abs(float(flat.sum()) - 1.0) < 1e-5
+        # ---- input transform + panorama roll (datasets.py:121)
+        pano = np.asarray(Image.open(root / city / "panorama" / "p.png").convert("RGB"))
+        roll = int(torch.round(torch.as_tensor(orient[i] / 360) * 640).int())
+        assert torch.equal(O.preprocess_reference(pano, (320, 640), roll=roll), grd)

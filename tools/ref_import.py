@@ -52,3 +52,14 @@ def import_reference():
     import models as ref_models
     import losses as ref_losses
     return ref_models, ref_losses
+
+
+def import_reference_datasets():
+    """The reference's datasets.py (needs one more stub: torchvision.transforms.functional, imported but unused by the
+    VIGOR / KITTI dataset classes)."""
+    import_reference()
+    tv = sys.modules["torchvision"]
+    if not hasattr(tv.transforms, "functional"):
+        tv.transforms.functional = _stub("torchvision.transforms.functional")
+    import datasets as ref_datasets
+    return ref_datasets
