@@ -1,24 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py — CCVPE dense cross-view matching forward on MI355X.
+"""bench.py — CCVPE dense cross-view matching path on MI355X.
 
 Contract: `python bench.py --gpus N --steps K --warmup W`; for N>1 the driver launches it under
-torch.distributed.run (one rank per GPU, RCCL).  A "step" is ONE forward pass of the hot path
+torch.distributed.run (one rank per GPU, RCCL).  A "step" of the headline is ONE forward pass of the hot path
 over one batch of synthetic image pairs resident in HBM.
 
-Workload at N=1 = BASELINE.json configs[1] ("C1"): CVM_VIGOR_ori_prior(ori_noise=0)
-(N_rot=1 in the localisation branch, 20 in the orientation branch), batch 64 per GPU, fp32,
-ground 3x320x640 + aerial 3x512x512, synthetic inputs and seeded random-init weights (no network).
-Inference shards by sample: N>1 runs N replicas with NO data-path collective ("weak" scaling);
-the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
+Workload at N=1 = BASELINE.json configs[1] ("C1"): CVM_VIGOR_ori_prior(ori_noise=0) (N_rot=1 in the localisation
+branch, 20 in the orientation branch), batch 64 per GPU, fp32, ground 3x320x640 + aerial 3x512x512, synthetic inputs
+and seeded random-init weights (no network).  Inference shards by sample: N>1 runs N replicas with NO data-path
+collective ("weak" scaling); the only collectives are the timing barrier and the max-over-ranks of the elapsed time.
 
 One JSON line on rank 0 with, besides the contract fields:
-  roofline     — for the dominant kernel (the fp32-MFMA implicit-GEMM instantiation with the
-                 largest share of the step): achieved = algorithmic FLOPs of its launches in the
-                 timed region / their HIP-event durations; peak = 157.3 TF fp32 matrix
-                 (MI355X_MICROARCH.md); traffic = PMC HBM bytes per launch if a profiles/ pass
-                 recorded them, else null.
-  cpu_baseline — the CPU oracle (oracle/ccvpe_oracle.py, kind "port") on the host cores, bounded
-                 sample, rank 0 / N=1 only.
+  roofline     — for the dominant kernel (largest share of the step among the HIP-event-bracketed dense launches):
+                 achieved = algorithmic FLOPs (fp32: MFMA-bound) or bytes (bf16: HBM-bound) of its launches in the timed
+                 region / their HIP-event durations; peak from MI355X_MICROARCH.md; traffic = PMC HBM bytes per launch from
+                 the committed profiles/ pass (`traffic_source` names it), else null; `whole_step` prices the entire step.
+  cpu_baseline — the CPU oracle (oracle/ccvpe_oracle.py, kind "port") on the host cores, bounded sample, rank 0 / N=1.
+  extra        — side measurements in the SAME line, each with its own roofline (and cpu_baseline where one exists):
+                 train_fwd_bwd_vigor_b64 (BASELINE metric's "(fwd+bwd) VIGOR bs=64": the full training step),
+                 C2_bf16 (configs[2]), C1_bf16 (C1 model in bf16 storage); for N>1 additionally train_dp_kitti_b64
+                 (configs[3]: the data-parallel training step with the RCCL gradient all-reduce), so a multi-GPU run of
+                 the default command exercises the collective path.
+`--train` makes the training step the headline (`--model kitti` = C3).
 """
 import argparse
 import json
@@ -32,8 +35,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MATRIX_PEAK_TFLOPS = 2500.0     # same table: ~2.5 PF dense
 HBM_PEAK_GBS = 8000.0
-GFLOP_PER_PAIR = {"vigor": 56.37}    # BASELINE.md §3 (N_rot=20); reported in config for reference
+# algorithmic forward work per image pair (2 x MACs of every conv / deconv / linear; N_rot = 20 / 16)
+GFLOP_PER_PAIR = {"vigor": 56.37, "kitti": 54.45}
+MB_PER_PAIR_FP32 = {"vigor": 888.0, "kitti": 944.0}
 
 
 def parse():
@@ -49,24 +55,33 @@ def parse():
     ap.add_argument("--model", choices=["prior0", "vigor20", "prior180_fov180", "kitti", "oxford"], default="prior0",
                     help="prior0 = C1 (default); vigor20 = C2 (N_rot=20); prior180_fov180 = C4; kitti = C3 forward")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
-    ap.add_argument("--no-extra", action="store_true",
-                    help="skip the short bf16 C2 side measurement attached as `extra` to the default N=1 line")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements attached as `extra`")
     ap.add_argument("--train", action="store_true",
                     help="time full training steps (forward + losses + backward + gradient all-reduce + Adam) instead "
                          "of the eval forward: BASELINE config C3 with --model kitti")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket igemm launches with HIP events in the timed region")
+                    help="do not bracket the dense launches with HIP events in the timed region")
+    ap.add_argument("--exact-infonce", action="store_true",
+                    help="--train with N>1: all-reduce infoNCE's numerator / label mass so that the loss equals the "
+                         "single-process big-batch loss (losses.py:18) instead of the mean of per-rank losses")
     return ap.parse_args()
 
 
+# ------------------------------------------------------------------------------------------------------
+# CPU baselines (oracle = test infrastructure; used here only as the timed CPU leg)
+# ------------------------------------------------------------------------------------------------------
+def _cpu_threads():
+    """The per-op work of a small-batch forward does not feed more than a few dozen cores (256 threads ran 50x SLOWER
+    than 32 in a first measurement); `cores` reports the threads actually used."""
+    return min(os.cpu_count() or 1, 32)
+
+
 def cpu_baseline(sd, batch=8, reps=3):
-    """Oracle forward on the host cores: bounded sample (~10-30 s).  The thread count is capped:
-    the per-op work of a B=8 forward does not feed more than a few dozen cores (256 threads ran
-    50x SLOWER than 32 in a first measurement); `cores` reports the threads actually used."""
+    """Oracle forward on the host cores: bounded sample (~10-30 s)."""
     import torch
     from ccvpe_amd import synth
     from oracle import ccvpe_oracle as O
-    cores = min(os.cpu_count() or 1, 32)
+    cores = _cpu_threads()
     torch.set_num_threads(cores)
     grd, sat = synth.synthetic_pair(batch, "vigor", 1234)
     times = []
@@ -81,34 +96,182 @@ def cpu_baseline(sd, batch=8, reps=3):
                 sample="oracle forward, CVM_VIGOR_ori_prior(0), B=%d fp32, 1 warm-up + median of %d" % (batch, reps))
 
 
-def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot):
-    """Times `steps` training steps as train_VIGOR.py:193-229 / train_KITTI.py run them: ground truth, forward (train mode),
-    the three losses on all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam.
-    Returns (max-over-ranks seconds, last loss, peak HBM GiB)."""
+def cpu_baseline_train(sd, kind="vigor", batch=2, reps=2):
+    """Oracle training step on the host cores (train-mode forward, the reference's loss mix, autograd backward):
+    train_VIGOR.py:112-150 without the optimizer update.  Bounded sample (~15-30 s)."""
     import torch
-    from ccvpe_amd import harness, losses, optim, synth, targets
+    from ccvpe_amd import synth
+    from oracle import ccvpe_oracle as O
+    cores = _cpu_threads()
+    torch.set_num_threads(cores)
+    n_rot = synth.MODEL_SPECS[kind]["n_rot"]
+    grd, sat = synth.synthetic_pair(batch, kind, 1234)
+    u = synth.uniform((batch, 3), 99)
+    gt, gt_flat, gt_ori, labels = O.train_targets(((u[:, :2] - 0.5) * 384.0).tolist(), (u[:, 2] * 359.99).tolist(), n_rot)
+    params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
+              for k, v in sd.items()}
 
-    class _A(object):
-        pass
-    args = _A()
-    args.batch, args.steps, args.warmup = batch, steps, warmup
+    def step():
+        for v in params.values():
+            if v.grad is not None:
+                v.grad = None
+        out = O.forward(params, grd, sat, kind, True, None, train_stats={})
+        nce = 0.0
+        for lvl in range(6):
+            nce = nce + O.infonce_loss(out[3 + lvl].flatten(1), labels[lvl].flatten(1))
+        loss = O.cross_entropy_loss(out[0], gt_flat) + 1e4 * nce / 6 + 1e1 * O.orientation_loss(out[2], gt_ori, gt)
+        loss.backward()
+
+    step()
+    times = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = statistics.median(times)
+    return dict(value=batch / med, unit="img-pairs/s", cores=cores, kind="port",
+                sample="oracle train-mode forward + loss mix + autograd backward, %s, B=%d fp32, 1 warm-up + median of %d"
+                       % (kind, batch, reps))
+
+
+# ------------------------------------------------------------------------------------------------------
+# roofline from the HIP-event launch records
+# ------------------------------------------------------------------------------------------------------
+def _traffic(name):
+    """PMC HBM bytes per launch of kernel `name` from the committed counter pass, with its provenance."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.isfile(tpath):
+        return None, None
+    try:
+        d = json.load(open(tpath))
+    except Exception:
+        return None, None
+    meta = d.get("#meta", {})
+    src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per MI355X_MICROARCH.md; " \
+          "static file taken at commit %s, not re-measured in this run)" % meta.get("commit", "unknown")
+    return d.get(name), src
+
+
+def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
+    """summ: ops.LaunchRecorder.summary().  Dominant kernel = the largest total time among the recorded dense launches."""
+    if not summ:
+        return None
+    tot_ms = sum(d["ms"] for d in summ.values())
+    name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
+    tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
+    traffic, tsrc = _traffic(name)
+    if precision == "bf16":
+        # bf16 storage: the whole forward is HBM-governed (BASELINE.md §3: 18 k pairs/s HBM vs 44 k MFMA); the dominant
+        # kernel is priced against BOTH roofs, `bound` names the one its arithmetic intensity puts it under
+        ai = d["flops"] / max(d["bytes"], 1.0)
+        bound = "mfma" if ai > BF16_MATRIX_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+        head = {"bound": bound, "kernel": name}
+        if bound == "hbm":
+            head.update(achieved=round(gbs, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(gbs / HBM_PEAK_GBS, 4))
+        else:
+            head.update(achieved=round(tfl, 1), peak=BF16_MATRIX_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=round(tfl / BF16_MATRIX_PEAK_TFLOPS, 4))
+        head["vs_both_roofs"] = {"hbm_frac": round(gbs / HBM_PEAK_GBS, 4), "mfma_bf16_frac": round(tfl / BF16_MATRIX_PEAK_TFLOPS, 4),
+                                 "algo_GBps": round(gbs, 1), "tflops": round(tfl, 1)}
+    else:
+        head = {"bound": "mfma", "kernel": name, "achieved": round(tfl, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(tfl / FP32_MATRIX_PEAK_TFLOPS, 4)}
+    head["traffic"] = traffic
+    head["traffic_source"] = tsrc if traffic is not None else None
+    roof = dict(head)
+    roof.update(launches_per_step=d["calls"] // steps, avg_launch_ms=round(d["ms"] / d["calls"], 4),
+                algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
+                algorithmic_mb_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2),
+                share_of_recorded_time=round(d["ms"] / tot_ms, 3))
+    # the whole step against the governing roof (BASELINE.md §3 figures: forward GFLOP / activation MB per pair;
+    # fwd+bwd = 3 x forward FLOPs)
+    gf = GFLOP_PER_PAIR.get(kind)
+    if gf is not None and ms_step:
+        mult = 3.0 if train else 1.0
+        step_tf = mult * gf * batch / ms_step          # GFLOP / ms = TFLOP/s
+        ws = {"algorithmic_tflop_per_step": round(mult * gf * batch / 1e3, 3), "achieved_tflops": round(step_tf, 2)}
+        if precision == "bf16":
+            step_gbs = MB_PER_PAIR_FP32[kind] / 2 * batch / ms_step        # MB / ms = GB/s
+            ws.update(bound="hbm", algorithmic_gb_per_step=round(MB_PER_PAIR_FP32[kind] / 2 * batch / 1e3, 2),
+                      achieved_GBps=round(step_gbs, 1), frac=round(step_gbs / HBM_PEAK_GBS, 4),
+                      mfma_bf16_frac=round(step_tf / BF16_MATRIX_PEAK_TFLOPS, 4))
+        else:
+            ws.update(bound="mfma", frac=round(step_tf / FP32_MATRIX_PEAK_TFLOPS, 4))
+        roof["whole_step"] = ws
+    roof["all_kernels"] = {k: {"ms_per_step": round(v["ms"] / steps, 3),
+                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                               "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                               "launches_per_step": v["calls"] // steps}
+                           for k, v in sorted(summ.items())}
+    return roof
+
+
+def per_layer_table(rec, steps):
+    agg = {}
+    for name, tag, flops, nbytes, e0, e1 in rec.items:
+        d = agg.setdefault((name, tag), [0, 0.0, 0.0, 0.0])
+        d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += flops; d[3] += nbytes
+    print("%-30s %-34s %5s %9s %8s %8s" % ("kernel", "shape", "n/st", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
+    for (name, tag), d in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print("%-30s %-34s %5d %9.3f %8.1f %8.0f" % (name, tag, d[0] // steps, d[1] / steps,
+              d[2] / d[1] / 1e9, d[3] / d[1] / 1e6), file=sys.stderr)
+
+
+# ------------------------------------------------------------------------------------------------------
+# measurements
+# ------------------------------------------------------------------------------------------------------
+def forward_measure(fwd, grd, sat, dev, steps, warmup, record):
+    """Times `steps` forwards; returns (max-over-ranks seconds, recorder or None)."""
+    import torch
+    from ccvpe_amd import harness, ops
+    rec = ops.LaunchRecorder() if record else None
+    state = {"n": 0}
+
+    def step():
+        # the recorder is switched on after the warm-up steps so that it brackets exactly the launches of the timed region
+        if state["n"] == warmup:
+            ops.set_recorder(rec)
+        state["n"] += 1
+        fwd(grd, sat)
+
+    try:
+        elapsed = harness.timed_steps(step, steps, warmup, sync_fn=torch.cuda.synchronize, device=dev)
+    finally:
+        ops.set_recorder(None)
+    return elapsed, rec
+
+
+def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record=False, exact_infonce=False):
+    """Times `steps` training steps as train_VIGOR.py:112-150 / train_KITTI.py:120-151 run them: ground truth, forward
+    (train mode), the three losses on all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam.
+    Returns dict(elapsed = max-over-ranks seconds, loss, peak_gib, rec)."""
+    import torch
+    from ccvpe_amd import harness, losses, ops, optim, synth, targets
+
     net.train()
     # ground truth as datasets.py builds it (Gaussian sigma 4 px at a seeded offset, orientation bins, (cos, sin) map) and
     # train_VIGOR.py:120-128 pools it — generated on the device from 3 scalars per sample (ccvpe_train_targets_f32)
-    u = synth.uniform((args.batch, 3), 99 + rank)
+    u = synth.uniform((batch, 3), 99 + rank)
     center = ((u[:, :2] - 0.5) * 384.0).to(dev)
     angle = (u[:, 2] * 359.99).to(dev)
     opt = optim.Adam(net.parameters(), lr=1e-4, betas=(0.9, 0.999))                 # train_VIGOR.py:104, one launch per step
-    reducer = harness.GradientAllReducer(net.parameters()).attach(net)     # all-reduce overlapped with the backward
+    reducer = harness.GradientAllReducer(net.parameters()).attach(net, optimizer=opt)     # all-reduce overlapped with the backward
+    nce_fn = losses.infoNCELoss_global if exact_infonce else losses.infoNCELoss
     last = {}
+    rec = ops.LaunchRecorder() if record else None
+    state = {"n": 0}
 
     def step():
+        if state["n"] == warmup:
+            ops.set_recorder(rec)
+        state["n"] += 1
         opt.zero_grad(set_to_none=True)
         gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, n_rot)
         out = net(grd, sat)
         nce = 0.0
         for lvl in range(6):                                                        # train_VIGOR.py:137-146
-            nce = nce + losses.infoNCELoss(torch.flatten(out[3 + lvl], start_dim=1), torch.flatten(labels[lvl], start_dim=1))
+            nce = nce + nce_fn(torch.flatten(out[3 + lvl], start_dim=1), torch.flatten(labels[lvl], start_dim=1))
         loss = losses.cross_entropy_loss(out[0], gt_flat) + 1e4 * nce / 6 + 1e1 * losses.orientation_loss(out[2], gt_ori, gt)
         loss.backward()
         reducer()
@@ -116,28 +279,29 @@ def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot):
         last["loss"] = loss.detach()
 
     torch.cuda.reset_peak_memory_stats(dev)
-    elapsed = harness.timed_steps(step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=dev)
-    return elapsed, float(last["loss"]), torch.cuda.max_memory_allocated(dev) / 2 ** 30
+    try:
+        elapsed = harness.timed_steps(step, steps, warmup, sync_fn=torch.cuda.synchronize, device=dev)
+    finally:
+        ops.set_recorder(None)
+    return dict(elapsed=elapsed, loss=float(last["loss"]), peak_gib=torch.cuda.max_memory_allocated(dev) / 2 ** 30, rec=rec)
 
 
-def train_main(args, net, grd, sat, dev, world, rank, n_rot):
-    import torch
-    elapsed, loss, peak = train_measure(net, grd, sat, dev, args.batch, args.steps, args.warmup, rank, n_rot)
-    if rank == 0:
-        line = {
-            "metric": "train image-pairs/sec", "value": round(args.batch * world * args.steps / elapsed, 2),
-            "unit": "img-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C3: %s training step (device-side ground truth, train-mode forward, loss = CE + 1e4 * mean of 6 "
-                                   "infoNCE + 10 * orientation, backward, gradient all-reduce, Adam lr 1e-4)" % type(net).__name__,
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "dp%d (RCCL all-reduce of gradients in 3 groups, overlapped with the backward)" % world,
-                       "loss_after_last_step": round(loss, 5), "peak_hbm_gib": round(peak, 2)},
-            "roofline": None, "cpu_baseline": None,
-        }
-        print(json.dumps(line))
-        sys.stdout.flush()
+def train_entry(net, kind, grd, sat, dev, batch, steps, warmup, rank, world, n_rot, record, exact_infonce=False):
+    """One training measurement as a JSON-able dict (value = whole-job pairs/s) + its roofline."""
+    m = train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record, exact_infonce)
+    ms = 1e3 * m["elapsed"] / steps
+    out = {"workload": "%s training step (device-side ground truth, train-mode forward, loss = CE + 1e4 * mean of 6 infoNCE + "
+                       "10 * orientation, backward, %sAdam lr 1e-4), batch %d per GPU, fp32"
+                       % (type(net).__name__, "RCCL gradient all-reduce in 3 groups overlapped with the backward, "
+                          if world > 1 else "", batch),
+           "value": round(batch * world * steps / m["elapsed"], 2), "unit": "img-pairs/s", "n_gpus": world,
+           "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+           "loss_after_last_step": round(m["loss"], 5), "peak_hbm_gib": round(m["peak_gib"], 2),
+           "parity": "tests/test_train_backward_gpu.py: gradients vs the reference's autograd golden (520 tensors); "
+                     "tests/test_train_trajectory_gpu.py: 10-step loss trajectory vs the oracle + torch Adam"}
+    if m["rec"] is not None:
+        out["roofline"] = roofline_from(m["rec"].summary(), steps, "fp32", batch, kind, ms, train=True)
+    return out, m
 
 
 def main():
@@ -176,43 +340,59 @@ def main():
     net = net.to(dev).eval().set_precision(args.precision)
     grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank)
     grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
-    if args.train:
-        if args.precision != "fp32" or args.graph:
-            raise SystemExit("--train is fp32, eager only")
-        train_main(args, net, grd, sat, dev, world, rank, synth.MODEL_SPECS[kind]["n_rot"])
+    record = not args.no_kernel_events
+
+    def finish():
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
+
+    # ---------------------------------------------------------------------------------------------------
+    if args.train:
+        if args.precision != "fp32" or args.graph:
+            raise SystemExit("--train is fp32, eager only")
+        n_rot = synth.MODEL_SPECS[kind]["n_rot"]
+        entry, m = train_entry(net, kind, grd, sat, dev, args.batch, args.steps, args.warmup, rank, world, n_rot, record,
+                               args.exact_infonce)
+        if rank == 0:
+            line = {"metric": "train image-pairs/sec (fwd+bwd)", "value": entry["value"], "unit": "img-pairs/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": entry["ms_per_step"], "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": ("C3: " if kind == "kitti" else "") + entry["workload"],
+                               "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                               "parallelism": "dp%d (RCCL all-reduce of gradients in 3 groups, overlapped with the backward; %s)"
+                                              % (world, "exact big-batch infoNCE (2-scalar all-reduce per level)"
+                                                 if args.exact_infonce else "per-rank loss means, as torch DDP"),
+                               "loss_after_last_step": entry["loss_after_last_step"], "peak_hbm_gib": entry["peak_hbm_gib"],
+                               "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
+                    "roofline": entry.get("roofline"), "cpu_baseline": None}
+            if m["rec"] is not None and args.per_layer:
+                per_layer_table(m["rec"], args.steps)
+            if world == 1 and not args.no_cpu_baseline and kind in ("vigor", "kitti"):
+                line["cpu_baseline"] = cpu_baseline_train(sd, kind)
+            print(json.dumps(line))
+            sys.stdout.flush()
+        finish()
         return
 
-    from ccvpe_amd import harness
+    # ---------------------------------------------------------------------------------------------------
     if args.graph:
         from ccvpe_amd.graph import GraphedForward
         fwd = GraphedForward(net, grd, sat)
-        args.no_kernel_events = True            # events cannot be recorded inside a replayed graph
+        record = False                          # events cannot be recorded inside a replayed graph
     else:
         fwd = net
-    rec = None if args.no_kernel_events else ops.LaunchRecorder()
-    state = {"n": 0}
+    elapsed, rec = forward_measure(fwd, grd, sat, dev, args.steps, args.warmup, record)
 
-    def step():
-        # the recorder is switched on after the warm-up steps so that it brackets exactly the
-        # igemm launches of the timed region
-        if state["n"] == args.warmup:
-            ops.set_recorder(rec)
-        state["n"] += 1
-        fwd(grd, sat)
-
-    elapsed = harness.timed_steps(step, args.steps, args.warmup, sync_fn=torch.cuda.synchronize, device=dev)
-    ops.set_recorder(None)
-
+    line = None
     if rank == 0:
         pairs = args.batch * world * args.steps
         value = pairs / elapsed
+        ms_step = 1e3 * elapsed / args.steps
         line = {
             "metric": "image-pairs/sec", "value": round(value, 2), "unit": "img-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "bf16", "data": "synthetic",
             "config": {"workload": {"prior0": "C1: CVM_VIGOR_ori_prior(ori_noise=0) eval forward, "
@@ -234,97 +414,84 @@ def main():
             # RobotCar variant, hardware not stated (/root/reference/README.md:21)
             line["vs_baseline"] = round(value / 14.0, 2)
             line["config"]["baseline"] = "14 FPS per frame (reference README, hardware not stated)"
-        roof = None
-        if rec is not None:
-            summ = rec.summary()
-            tot_ms = sum(d["ms"] for d in summ.values())
-            name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
-            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            if os.path.isfile(tpath):
-                try:
-                    traffic = json.load(open(tpath)).get(name)
-                except Exception:
-                    traffic = None
-            if args.precision == "bf16":
-                # bf16 storage: every kernel is HBM-bound (MFMA is 16x faster than fp32) -> price the
-                # dominant kernel against HBM with its ALGORITHMIC bytes (input + output + weights once)
-                ach = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-                roof_head = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic}
-            else:
-                roof_head = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 2),
-                             "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / FP32_MATRIX_PEAK_TFLOPS, 4), "traffic": traffic}
-            roof = {**roof_head,
-                    "launches_per_step": d["calls"] // args.steps,
-                    "avg_launch_ms": round(d["ms"] / d["calls"], 4),
-                    "algorithmic_gflop_per_launch": round(d["flops"] / d["calls"] / 1e9, 3),
-                    "share_of_igemm_time": round(d["ms"] / tot_ms, 3),
-                    "all_igemm": {k: {"ms_per_step": round(v["ms"] / args.steps, 3),
-                                      "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                      "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                                      "launches_per_step": v["calls"] // args.steps}
-                                  for k, v in sorted(summ.items())}}
-        line["roofline"] = roof
+        line["roofline"] = (roofline_from(rec.summary(), args.steps, args.precision, args.batch, kind, ms_step)
+                            if rec is not None else None)
         if rec is not None and args.per_layer:
-            agg = {}
-            for name, tag, flops, nbytes, e0, e1 in rec.items:
-                d = agg.setdefault((name, tag), [0, 0.0, 0.0, 0.0])
-                d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += flops; d[3] += nbytes
-            print("%-28s %-28s %5s %9s %8s %8s" % ("kernel", "shape", "n/st", "ms/step", "TFLOP/s", "GB/s"), file=sys.stderr)
-            for (name, tag), d in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                print("%-28s %-28s %5d %9.3f %8.1f %8.0f" % (name, tag, d[0] // args.steps, d[1] / args.steps,
-                      d[2] / d[1] / 1e9, d[3] / d[1] / 1e6), file=sys.stderr)
+            per_layer_table(rec, args.steps)
         if world == 1 and not args.no_cpu_baseline and args.model == "prior0":
             line["cpu_baseline"] = cpu_baseline(sd)
         else:
             line["cpu_baseline"] = None
-        default_run = (world == 1 and args.model == "prior0" and args.precision == "fp32" and not args.graph
-                       and not args.no_extra)
-        if default_run:
-            # side measurement, NOT the headline: BASELINE config C2 (CVM_VIGOR, N_rot = 20, batch 32,
-            # bf16 storage path).  Same harness, 5 timed steps.
+
+    default_run = (args.model == "prior0" and args.precision == "fp32" and not args.graph and not args.no_extra)
+    if default_run:
+        extra = {}
+        del fwd
+        # (1) BASELINE configs[2] "C2": CVM_VIGOR, N_rot = 20, batch 32, bf16 storage; (2) the C1 model in bf16 at batch 64
+        #     (the north-star's ">= 10 000 pairs/s forward at batch 64" is a bf16 goal: fp32 MFMA ceiling is 2.8 k)
+        for tag, ctor, b2, seed, what in (
+                ("C2_bf16", lambda: models.CVM_VIGOR(dev, True), 32, 4321,
+                 "C2: CVM_VIGOR eval forward, N_rot=20, batch 32, bf16 storage (fp32 accumulate)"),
+                ("C1_bf16", lambda: models.CVM_VIGOR_ori_prior(dev, 0, True), args.batch, 1234,
+                 "C1 model CVM_VIGOR_ori_prior(0) eval forward, batch %d, bf16 storage (fp32 accumulate)" % args.batch)):
             try:
-                del fwd
-                net2 = models.CVM_VIGOR(dev, True)
+                net2 = ctor()
                 net2.load_state_dict(sd, strict=True)
                 net2 = net2.to(dev).eval().set_precision("bf16")
-                g2, s2 = synth.synthetic_pair(32, "vigor", 4321)
+                g2, s2 = synth.synthetic_pair(b2, "vigor", seed + rank)
                 g2, s2 = g2.to(dev), s2.to(dev)
-                e2 = harness.timed_steps(lambda: net2(g2, s2), 5, 2, sync_fn=torch.cuda.synchronize, device=dev)
-                line["extra"] = {"C2_bf16": {"workload": "CVM_VIGOR eval forward, N_rot=20, batch 32, bf16 storage "
-                                                         "(fp32 accumulate), grd 3x320x640 + sat 3x512x512",
-                                             "value": round(32 * 5 / e2, 2), "unit": "img-pairs/s",
-                                             "ms_per_step": round(1e3 * e2 / 5, 3), "steps": 5, "dtype": "bf16",
-                                             "parity": "tests/test_bf16_gpu.py: logits within 5e-2 of range vs fp32 "
-                                                       "oracle, scores within 2e-2"}}
-            except Exception as ex:      # the headline must not depend on the side measurement
-                line["extra"] = {"C2_bf16": {"error": repr(ex)}}
-            # second side measurement: BASELINE.json's metric string also names "(fwd+bwd) VIGOR bs=64" — the full training
-            # step of CVM_VIGOR (N_rot = 20) at batch 64: ground truth, train-mode forward, losses, backward, Adam
+                e2, r2 = forward_measure(net2, g2, s2, dev, 5, 2, record)
+                if rank == 0:
+                    extra[tag] = {"workload": what + ", grd 3x320x640 + sat 3x512x512", "value": round(b2 * world * 5 / e2, 2),
+                                  "unit": "img-pairs/s", "n_gpus": world, "ms_per_step": round(1e3 * e2 / 5, 3), "steps": 5,
+                                  "warmup": 2, "dtype": "bf16",
+                                  "parity": "tests/test_bf16_gpu.py: heat-map arg-max equal to the fp32 oracle on the golden cases, "
+                                            "logits / scores within the tolerances written there",
+                                  "roofline": (roofline_from(r2.summary(), 5, "bf16", b2, "vigor", 1e3 * e2 / 5)
+                                               if r2 is not None else None)}
+                del net2, g2, s2, r2
+            except Exception as ex:      # the headline must not depend on a side measurement
+                if rank == 0:
+                    extra[tag] = {"error": repr(ex)}
+        # (3) BASELINE.json's metric string names "(fwd+bwd) VIGOR bs=64": the full training step of CVM_VIGOR (N_rot = 20)
+        #     at batch 64 per GPU: ground truth, train-mode forward, losses, backward, (all-reduce,) Adam
+        try:
+            del net
+            torch.cuda.empty_cache()
+            net3 = models.CVM_VIGOR(dev, True)
+            net3.load_state_dict(sd, strict=True)
+            net3 = net3.to(dev)
+            ent, _ = train_entry(net3, "vigor", grd, sat, dev, args.batch, 3, 1, rank, world, 20, record)
+            if rank == 0:
+                if world == 1 and not args.no_cpu_baseline:
+                    ent["cpu_baseline"] = cpu_baseline_train(sd, "vigor")
+                extra["train_fwd_bwd_vigor_b64"] = ent
+            del net3
+        except Exception as ex:
+            if rank == 0:
+                extra["train_fwd_bwd_vigor_b64"] = {"error": repr(ex)}
+        # (4) N > 1: BASELINE configs[3] "C3" — CVM_KITTI data-parallel training step, batch 64 per GPU, gradients averaged by
+        #     RCCL all-reduce over xGMI: a multi-GPU run of the default command exercises the collective path
+        if world > 1:
             try:
-                del net2, g2, s2
-                del net
                 torch.cuda.empty_cache()
-                net3 = models.CVM_VIGOR(dev, True)
-                net3.load_state_dict(sd, strict=True)
-                net3 = net3.to(dev)
-                e3, loss3, peak3 = train_measure(net3, grd, sat, dev, args.batch, 3, 1, rank, 20)
-                line["extra"]["train_fwd_bwd_vigor_b64"] = {
-                    "workload": "CVM_VIGOR training step (device-side ground truth, train-mode forward, CE + 1e4 * mean infoNCE "
-                                "+ 10 * orientation, backward, Adam), batch %d, fp32" % args.batch,
-                    "value": round(args.batch * 3 / e3, 2), "unit": "img-pairs/s", "ms_per_step": round(1e3 * e3 / 3, 3),
-                    "steps": 3, "dtype": "f32", "peak_hbm_gib": round(peak3, 2),
-                    "parity": "tests/test_train_backward_gpu.py: gradients vs the reference's autograd golden (520 tensors)"}
+                sdk = synth.synthetic_state_dict("kitti", 0)
+                net4 = models.CVM_KITTI(dev)
+                net4.load_state_dict(sdk, strict=True)
+                net4 = net4.to(dev)
+                g4, s4 = synth.synthetic_pair(args.batch, "kitti", 1234 + rank)
+                ent, _ = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, 3, 1, rank, world, 16, record)
+                if rank == 0:
+                    extra["train_dp_kitti_b64"] = ent
             except Exception as ex:
-                line["extra"]["train_fwd_bwd_vigor_b64"] = {"error": repr(ex)}
+                if rank == 0:
+                    extra["train_dp_kitti_b64"] = {"error": repr(ex)}
+        if rank == 0:
+            line["extra"] = extra
+    if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    finish()
 
 
 if __name__ == "__main__":

@@ -67,6 +67,7 @@ PROTOTYPES = {
                                       c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_int,
                                       c_int, c_int, c_void_p]),
     "ccvpe_head_conv3x3_f32": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "ccvpe_cast_bf16_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p]),
     "ccvpe_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_eval_postprocess_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "ccvpe_infonce_loss_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
@@ -78,6 +79,7 @@ PROTOTYPES = {
     "ccvpe_bn_stats_f32": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 4 + [c_float, c_void_p, c_void_p]),
     "ccvpe_bn_act_nblk": (c_int, [c_int]),
     "ccvpe_bn_act_f32": (c_int, [c_void_p] * 5 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_conv_wgrad_tile": (c_int, [c_int, c_int]),
     "ccvpe_conv_wgrad_scratch_floats": (c_int, [c_int] * 9),
     "ccvpe_conv_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                      c_void_p] + [c_int] * 8 + [c_void_p]),
@@ -109,7 +111,8 @@ PROTOTYPES = {
     "ccvpe_train_targets_nblk": (c_int, [c_int, c_int]),
     "ccvpe_train_targets_f32": (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "ccvpe_adam_chunk_elems": (c_int, []),
-    "ccvpe_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [ctypes.c_double] * 4 + [c_int, c_void_p]),
+    "ccvpe_adam_hyper_floats": (c_int, []),
+    "ccvpe_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),
     "ccvpe_preprocess_u8_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p,
                                         c_void_p, c_int, c_int, c_int, c_int, ctypes.POINTER(c_float), ctypes.POINTER(c_float),
                                         c_void_p]),

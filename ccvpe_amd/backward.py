@@ -42,8 +42,9 @@ def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None):
           "ccvpe_conv_wgrad_f32")
     if rec is not None:
         m = dy.numel() // dy.shape[-1]
-        rec.end("conv_wgrad", "%dx%d s%d M%d N%d C%d" % (kh, kw, stride, m, n, ctot), 2.0 * m * n * kh * kw * ctot,
-                4.0 * (x0.numel() + (x1.numel() if x1 is not None else 0) + dy.numel()), ev0)
+        tile = lib.ccvpe_conv_wgrad_tile(n, kh * kw * ctot)
+        rec.end("conv_wgrad_kernel<%d,%d>" % (tile >> 16, tile & 0xffff), "%dx%d s%d M%d N%d C%d" % (kh, kw, stride, m, n, ctot),
+                2.0 * m * n * kh * kw * ctot, 4.0 * (b * h * w * ctot + m * n + n * kh * kw * ctot), ev0)
     return dw.reshape(n, kh, kw, ctot).permute(0, 3, 1, 2)                 # OIHW view
 
 

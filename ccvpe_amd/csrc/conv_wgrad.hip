@@ -245,6 +245,14 @@ static int wgrad_tile_count(int n, int ncols) {
   return ((n + tn - 1) / tn) * ((ncols + WG_T - 1) / WG_T);
 }
 
+// which tile the kernel will use for an [n] x [ncols = taps * channels] weight gradient: (rows << 16) | columns
+// (reporting only: bench.py names its launch records after the instantiation that ran)
+extern "C" int ccvpe_conv_wgrad_tile(int n, int ncols) {
+  if (n <= 0 || ncols <= 0) return CCVPE_EINVAL;
+  if (wgrad_big(n, ncols)) return (128 << 16) | 128;
+  return (wgrad_tn(n) << 16) | WG_T;
+}
+
 extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad,
                                                int ctot, int n) {
   const int Ho = (in_h + 2 * pad - kh) / stride + 1, Wo = (in_w + 2 * pad - kw) / stride + 1;

@@ -279,6 +279,19 @@ __global__ __launch_bounds__(1024) void eval_post_kernel(const float* __restrict
 }
 
 // mode 0: -sum(num)/sum(den) ; mode 1: -sum(num)/B ; mode 2: +sum(num)/B
+// bf16 -> fp32 widening of an activation tensor (the bf16 storage path hands its last decoder levels to the fp32
+// kernels so that the heat-map arg-max keeps fp32 resolution: SURVEY.md section 7, "keep the last two levels in fp32")
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const cc_bf16* __restrict__ src, float* __restrict__ dst, long n8) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const cc_bf16x8 v = reinterpret_cast<const cc_bf16x8*>(src)[i];
+  cc_f32x4 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a[j] = (float)v[j]; b[j] = (float)v[j + 4]; }
+  reinterpret_cast<cc_f32x4*>(dst)[2 * i] = a;
+  reinterpret_cast<cc_f32x4*>(dst)[2 * i + 1] = b;
+}
+
 __global__ void loss_finish_kernel(const float* __restrict__ part, float* __restrict__ loss, int B, int mode) {
   float num = 0.f, den = 0.f;
   for (int i = threadIdx.x; i < B; i += 64) {
@@ -297,7 +310,7 @@ using namespace ccvpe;
 thread_local char ccvpe::g_err[512] = "";
 
 extern "C" const char* ccvpe_last_error(void) { return g_err; }
-extern "C" int ccvpe_abi_version(void) { return 1; }
+extern "C" int ccvpe_abi_version(void) { return 2; }
 
 extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
                                            float* out, int B, int h, int w, void* stream) {
@@ -379,4 +392,13 @@ extern "C" int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori,
   hipLaunchKernelGGL(ori_rows_kernel, dim3(B), dim3(1024), 0, st, ori, gt_ori, gt, scratch, hw);
   hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, scratch, loss, B, 2);
   return check_launch("orientation_loss");
+}
+
+extern "C" int ccvpe_cast_bf16_f32(const void* src, float* dst, long n_elems, void* stream) {
+  if (n_elems <= 0 || n_elems % 8) return fail(CCVPE_EINVAL, "cast_bf16_f32: n %% 8");
+  if (!aligned16(src) || !aligned16(dst)) return fail(CCVPE_EINVAL, "cast_bf16_f32: 16-byte alignment required");
+  const long n8 = n_elems / 8;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)((n8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<const cc_bf16*>(src), dst, n8);
+  return check_launch("cast_bf16_f32_kernel");
 }

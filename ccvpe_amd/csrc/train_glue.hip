@@ -76,9 +76,14 @@ __global__ __launch_bounds__(256) void targets_pyramid_kernel(const float* __res
     my = fminf(my, y * y);
   }
   const float v = expf(-(mx + my) * inv2s2);
-  const float ang = angle[b];
-  const int index = (int)floorf(ang / bin_width);
-  const float ratio = (ang - index * bin_width) / bin_width;
+  // datasets.py:154-155: index = int(angle // width), ratio = (angle % width) / width in float64.  The angle is wrapped
+  // into [0, 360) first (the reference's callers do: datasets.py:483-487) so that a caller passing e.g. 90 - random_ori
+  // directly cannot index outside the bins, and index is clamped against a wrap that rounds up to 360.
+  double ang = (double)angle[b];
+  ang -= 360.0 * floor(ang / 360.0);
+  int index = (int)floor(ang / (double)bin_width);
+  index = min(max(index, 0), n_bins - 1);
+  const float ratio = (float)((ang - (double)index * (double)bin_width) / (double)bin_width);
   const int b0 = index == 0 ? 0 : n_bins - index;
   const int b1 = index == 0 ? n_bins - 1 : n_bins - index - 1;
   float* o = out.lab[l] + (size_t)b * n_bins * hl * wl + cell;
@@ -94,13 +99,17 @@ __global__ __launch_bounds__(256) void targets_pyramid_kernel(const float* __res
 // Adam (torch.optim.Adam semantics, train_VIGOR.py:104: lr, betas=(0.9, 0.999), eps 1e-8, no weight decay,
 // no amsgrad) over a table of tensors: one launch updates every parameter.
 //   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+// Every tensor carries its OWN hyper-parameter row (step size with its own bias correction, betas, eps), so tensors
+// that started receiving gradients at different steps, or sit in different param groups, update in the same launch.
+// grad_scale multiplies the gradient on load (data-parallel SUM all-reduce -> mean without a separate pass).
 // ---------------------------------------------------------------------------------------------
 constexpr int ADAM_CHUNK = 4096;   // elements per workgroup
+constexpr int ADAM_HYPER = 8;      // floats per tensor: step_size, b1, b2, 1-b1, 1-b2, eps, sqrt(1-b2^t), reserved
 
 __global__ __launch_bounds__(256) void adam_kernel(const long long* __restrict__ table /*[n][5]: p, g, m, v, numel*/,
+                                                   const float* __restrict__ hyper /*[n][ADAM_HYPER]*/,
                                                    const int* __restrict__ chunk_tensor, const int* __restrict__ chunk_off,
-                                                   float lr, float b1, float b2, float omb1, float omb2, float eps, float bc1,
-                                                   float bc2_sqrt) {
+                                                   float grad_scale) {
   const int t = chunk_tensor[blockIdx.x];
   const long long* row = table + (size_t)t * 5;
   float* p = reinterpret_cast<float*>(row[0]);
@@ -109,10 +118,29 @@ __global__ __launch_bounds__(256) void adam_kernel(const long long* __restrict__
   float* v = reinterpret_cast<float*>(row[3]);
   const long long n = row[4];
   if (g == nullptr) return;
+  const float* hy = hyper + (size_t)t * ADAM_HYPER;
+  const float step = hy[0], b1 = hy[1], b2 = hy[2], omb1 = hy[3], omb2 = hy[4], eps = hy[5], bc2_sqrt = hy[6];
   const long long base = (long long)chunk_off[blockIdx.x] * ADAM_CHUNK;
-  const float step = lr / bc1;       // torch: step_size = lr / bias_correction1
-  for (long long i = base + threadIdx.x; i < min(base + ADAM_CHUNK, n); i += 256) {
-    const float gi = g[i];
+  const long long end = min(base + ADAM_CHUNK, n);
+  if (((n | base) & 3) == 0 && ((((size_t)p | (size_t)g | (size_t)m | (size_t)v) & 15) == 0)) {     // 16-byte path
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (long long i = base + 4 * threadIdx.x; i < end; i += 1024) {
+      f4 gi = *reinterpret_cast<const f4*>(g + i) * grad_scale;
+      f4 mi = *reinterpret_cast<const f4*>(m + i), vi = *reinterpret_cast<const f4*>(v + i), pi = *reinterpret_cast<const f4*>(p + i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        mi[q] = b1 * mi[q] + omb1 * gi[q];
+        vi[q] = b2 * vi[q] + omb2 * gi[q] * gi[q];
+        pi[q] -= step * mi[q] / (sqrtf(vi[q]) / bc2_sqrt + eps);
+      }
+      *reinterpret_cast<f4*>(m + i) = mi;
+      *reinterpret_cast<f4*>(v + i) = vi;
+      *reinterpret_cast<f4*>(p + i) = pi;
+    }
+    return;
+  }
+  for (long long i = base + threadIdx.x; i < end; i += 256) {
+    const float gi = g[i] * grad_scale;
     const float mi = b1 * m[i] + omb1 * gi;          // 1 - beta computed in double on the host, as torch does
     const float vi = b2 * v[i] + omb2 * gi * gi;
     m[i] = mi;
@@ -148,14 +176,12 @@ extern "C" int ccvpe_train_targets_f32(const float* center_xy, const float* angl
 
 extern "C" int ccvpe_adam_chunk_elems(void) { return ADAM_CHUNK; }
 
-extern "C" int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* chunk_off, int n_chunks, double lr,
-                                   double beta1, double beta2, double eps, int step, void* stream) {
-  if (n_chunks <= 0 || step < 1) return fail(CCVPE_EINVAL, "adam_step: bad args");
-  // bias corrections in double on the host, as torch.optim.Adam does with Python floats
-  const double bc1 = 1.0 - pow(beta1, (double)step);
-  const double bc2s = sqrt(1.0 - pow(beta2, (double)step));
+extern "C" int ccvpe_adam_hyper_floats(void) { return ADAM_HYPER; }
+
+extern "C" int ccvpe_adam_step_f32(const void* table, const float* hyper, const int* chunk_tensor, const int* chunk_off,
+                                   int n_chunks, float grad_scale, void* stream) {
+  if (n_chunks <= 0 || !table || !hyper || !chunk_tensor || !chunk_off) return fail(CCVPE_EINVAL, "adam_step: bad args");
   hipLaunchKernelGGL(adam_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(table),
-                     chunk_tensor, chunk_off, (float)lr, (float)beta1, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2),
-                     (float)eps, (float)bc1, (float)bc2s);
+                     hyper, chunk_tensor, chunk_off, grad_scale);
   return check_launch("adam_kernel");
 }

@@ -52,14 +52,49 @@ def aggregate_throughput(units_per_rank_per_step, steps, elapsed_max):
     return units_per_rank_per_step * world * steps / elapsed_max
 
 
+def _avg_supported():
+    """ReduceOp.AVG exists for the nccl (= RCCL) backend only; gloo gets SUM + an explicit scale."""
+    return dist.get_backend() == "nccl" and __import__("os").environ.get("CCVPE_ALLREDUCE_AVG", "1") == "1"
+
+
+def _allreduce_mean(flat, want_async=True):
+    """In-place mean over the ranks of `flat`.  Returns (work handle, post-scale): RCCL averages inside the collective
+    (ncclAvg: no extra pass over the data); elsewhere the caller applies `post-scale` after work.wait()."""
+    world = dist.get_world_size()
+    if _avg_supported():
+        try:
+            return dist.all_reduce(flat, op=dist.ReduceOp.AVG, async_op=want_async), 1.0
+        except (RuntimeError, ValueError):           # a build without ncclAvg: fall back to SUM + scale
+            pass
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=want_async), 1.0 / world
+
+
+# backward production order of the model's single autograd node (ccvpe_amd/train.py: backward_train): the decoders, the
+# matching blocks and the aerial descriptor first (~80 % of the parameter bytes), then the aerial encoder, then the ground
+# descriptor heads + ground encoder
+def grad_group(name):
+    if name.startswith("sat_efficientnet."):
+        return 1
+    if name.startswith("grd_efficientnet.") or name.startswith("grd_feature_to_descriptor"):
+        return 2
+    return 0
+
+
 class GradientAllReducer:
     """Data-parallel training (BASELINE C3): average the parameter gradients over the ranks.
 
-    One process per GPU; `torch.distributed` backend "nccl" is RCCL over xGMI.  Gradients are packed into a few
-    LARGE flat buckets (default 64 MiB: the ~58 M-parameter model is 4 buckets) because xGMI is point-to-point and
-    a ring all-reduce is bound per link — few, large messages amortise the per-collective latency; the buckets are
-    issued asynchronously back to back and unpacked after the last one completes.  The bucket layout is fixed at
-    construction (parameter order), so every rank reduces the same bytes in the same order."""
+    One process per GPU; `torch.distributed` backend "nccl" is RCCL over xGMI.  xGMI is point-to-point and a ring
+    all-reduce is bound per link, so the ~58 M-parameter model travels as a few LARGE flat messages.
+
+    Two modes:
+      * attach(model) — the FLAT GRADIENT ARENA (what bench.py and a training script should use): one flat fp32 buffer holds
+        every parameter's gradient, laid out in the order the model's backward produces them (three contiguous groups).
+        The backward writes each gradient into its slot (that copy replaces the layout-fixing `.contiguous()` it did
+        anyway), the slice of a finished group is all-reduced IN PLACE with ncclAvg while the rest of the backward still
+        runs, and `p.grad` is a view of the arena: no torch.cat, no unpack, no separate scaling pass.
+      * called after loss.backward() without attach (any model / any autograd graph): gradients are packed into fixed
+        flat buckets (default 64 MiB), reduced asynchronously back to back and copied back.
+    The layouts are fixed by parameter order / name, so every rank reduces the same bytes in the same order."""
 
     def __init__(self, params, bucket_bytes=64 << 20):
         self.params = [p for p in params if p.requires_grad]
@@ -74,13 +109,31 @@ class GradientAllReducer:
         if cur:
             self.buckets.append(cur)
         self._flat = None
+        self._arena = None
+        self._done_in_backward = False
+        self.allreduce_calls = 0              # collectives issued so far (tests / diagnostics)
 
-    # ---- overlapped mode: reduce inside the model's backward --------------------------------------------
-    def attach(self, model):
-        """Start the all-reduce of each gradient group as soon as the model's backward has produced it
-        (ccvpe_amd/train.py calls ready() after the decoders, after the aerial encoder and at the end): the
-        decoder group (~80 % of the bytes) travels over xGMI while the encoders' backward is still computing.
-        With the reducer attached, calling it after loss.backward() is a no-op for that step."""
+    # ---- arena mode: reduce inside the model's backward -------------------------------------------------
+    def attach(self, model, optimizer=None):
+        """Build the flat gradient arena for `model` (a ccvpe_amd CVM_* module) and register with it: its backward then
+        calls begin() / ready() (after each of the three gradient groups) / finish().  `optimizer`: a
+        ccvpe_amd.optim.Adam whose grad_scale absorbs the 1/world when the backend cannot average in the collective."""
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and "._fc." not in n]
+        named.sort(key=lambda np_: grad_group(np_[0]))           # stable: keeps parameter order inside a group
+        off, slots, bounds = 0, {}, [[None, None] for _ in range(3)]
+        for n, p in named:
+            g = grad_group(n)
+            if bounds[g][0] is None:
+                bounds[g][0] = off
+            slots[n] = (off, p.numel(), tuple(p.shape), g, p)
+            off += (p.numel() + 3) // 4 * 4                       # every slot 16-byte aligned
+            bounds[g][1] = off
+        dev = named[0][1].device
+        self._arena = dict(flat=torch.zeros((off,), device=dev, dtype=torch.float32), slots=slots, bounds=bounds,
+                           views={n: None for n in slots})
+        for n, (o, cnt, shp, g, p) in slots.items():
+            self._arena["views"][n] = self._arena["flat"][o:o + cnt].view(shp)
+        self._optimizer = optimizer
         model._grad_sync = self
         return self
 
@@ -88,41 +141,91 @@ class GradientAllReducer:
     def active():
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
+    def arena_ok(self):
+        """The arena path needs fresh gradients (p.grad None, or still this arena's view from an earlier step that the
+        caller zeroed): accumulation across several backward passes goes through autograd's own accumulation instead."""
+        if self._arena is None:
+            return False
+        for n, (o, cnt, shp, g, p) in self._arena["slots"].items():
+            if p.grad is not None:
+                return False
+        return True
+
     def begin(self):
         self._pending, self._sent = [], set()
+        self._done_in_backward = False
+        self._group = 0
 
     def ready(self, grads):
+        """Called by the backward after each gradient group with the dict of gradients finished so far.  Arena mode:
+        copy the new ones into their slots and start the group's in-place all-reduce.  Without an arena (legacy callers
+        with plain dicts): concatenate the new ones and reduce that."""
         names = [n for n in grads if n not in self._sent and grads[n] is not None]
         if not names:
             return
         self._sent.update(names)
-        shapes = [tuple(grads[n].shape) for n in names]
-        flat = torch.cat([grads[n].reshape(-1) for n in names])
-        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-        self._pending.append((work, flat, names, shapes))
+        if self._arena is None:
+            shapes = [tuple(grads[n].shape) for n in names]
+            flat = torch.cat([grads[n].reshape(-1) for n in names])
+            if self.active():
+                work, scale = _allreduce_mean(flat)
+                self.allreduce_calls += 1
+            else:
+                work, scale = None, 1.0
+            self._pending.append((work, scale, flat, names, shapes))
+            return
+        ar = self._arena
+        glo, ghi = None, None
+        for n in names:
+            if n not in ar["slots"]:
+                continue                                     # frozen / excluded parameter: stays with autograd
+            o, cnt, shp, g, p = ar["slots"][n]
+            ar["views"][n].copy_(grads[n].reshape(shp))
+            glo = g if glo is None else min(glo, g)
+            ghi = g if ghi is None else max(ghi, g)
+        if glo is None:
+            return
+        lo, hi = ar["bounds"][glo][0], ar["bounds"][ghi][1]
+        if self.active():
+            work, scale = _allreduce_mean(ar["flat"][lo:hi])
+            self.allreduce_calls += 1
+            self._pending.append((work, scale, ar["flat"][lo:hi], None, None))
 
     def finish(self, grads):
-        world = dist.get_world_size()
-        for work, flat, names, shapes in self._pending:
-            work.wait()
-            flat.mul_(1.0 / world)
-            off = 0
-            for n, shp in zip(names, shapes):
-                cnt = 1
-                for d in shp:
-                    cnt *= d
-                grads[n] = flat[off:off + cnt].view(shp)
-                off += cnt
+        """Wait for the collectives; arena mode: hand the arena views to the parameters as their .grad and drop those
+        entries from `grads` (nothing is returned to autograd for them)."""
+        opt = getattr(self, "_optimizer", None)
+        for work, scale, flat, names, shapes in self._pending:
+            if work is not None:
+                work.wait()
+            if scale != 1.0:
+                if opt is not None and self._arena is not None and hasattr(opt, "grad_scale"):
+                    opt.grad_scale = scale               # folded into the Adam kernel's gradient load
+                else:
+                    flat.mul_(scale)
+            if names is not None:
+                off = 0
+                for n, shp in zip(names, shapes):
+                    cnt = 1
+                    for d in shp:
+                        cnt *= d
+                    grads[n] = flat[off:off + cnt].view(shp)
+                    off += cnt
         self._pending = []
+        if self._arena is not None:
+            ar = self._arena
+            for n in list(grads):
+                if n in ar["slots"] and n in self._sent:
+                    ar["slots"][n][4].grad = ar["views"][n]
+                    grads[n] = None
         self._done_in_backward = True
 
     def __call__(self):
-        if getattr(self, "_done_in_backward", False):      # already averaged inside the backward of this step
+        if self._done_in_backward:      # already averaged inside the backward of this step
             self._done_in_backward = False
             return
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self.active():
             return
-        world = dist.get_world_size()
         if self._flat is None:
             self._flat = [torch.empty((sum(p.numel() for p in b),), device=b[0].device, dtype=torch.float32)
                           for b in self.buckets]
@@ -136,13 +239,44 @@ class GradientAllReducer:
                 else:
                     flat[off:off + n].copy_(p.grad.reshape(-1))
                 off += n
-            works.append(dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True))
-        for w, flat, bucket in zip(works, self._flat, self.buckets):
+            works.append(_allreduce_mean(flat))
+            self.allreduce_calls += 1
+        for (w, scale), flat, bucket in zip(works, self._flat, self.buckets):
             w.wait()
-            flat.mul_(1.0 / world)
+            if scale != 1.0:
+                flat.mul_(scale)
             off = 0
             for p in bucket:
                 n = p.numel()
                 if p.grad is not None:
                     p.grad.copy_(flat[off:off + n].view_as(p.grad))
                 off += n
+
+
+class _GlobalRatio(torch.autograd.Function):
+    """loss = (sum over ranks of num_r) / (sum over ranks of den_r) for a per-rank loss given as num_r / den_r.
+
+    infoNCELoss (losses.py:4-20) is such a ratio: -sum(log p * label) over the batch / sum(label) over the batch.  Under
+    data parallelism each rank only sees its own samples; averaging per-rank ratios is NOT the single-process big-batch
+    loss.  Forward: ONE all-reduce of the two scalars (num_r = loss_r * den_r, den_r), returns the global ratio on every
+    rank.  Backward: the gradient averaging of data parallelism computes (1/W) sum_r dL_r, so rank r must backpropagate
+    W * den_r / DEN times its local ratio's gradient — then the averaged parameter gradients equal the big-batch ones."""
+
+    @staticmethod
+    def forward(ctx, loss_local, den_local, group):
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        pair = torch.stack([loss_local.detach().reshape(()) * den_local.detach().reshape(()), den_local.detach().reshape(())])
+        if world > 1:
+            dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
+        ctx.save_for_backward(den_local.detach().reshape(()) * float(world) / pair[1])
+        return pair[0] / pair[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        (k,) = ctx.saved_tensors
+        return g * k, None, None
+
+
+def global_ratio_loss(loss_local, den_local, group=None):
+    """See _GlobalRatio.  loss_local: this rank's ratio loss (differentiable); den_local: its denominator (label mass)."""
+    return _GlobalRatio.apply(loss_local, den_local, group)

@@ -21,10 +21,12 @@ class _InfoNCE(torch.autograd.Function):
         s, l = _flat2(scores), _flat2(labels)
         ctx.save_for_backward(s, l)
         ctx.temperature, ctx.shape = float(temperature), scores.shape
-        return ops.infonce_loss(s, l, temperature).reshape(())
+        loss, den = ops.infonce_loss(s, l, temperature, want_den=True)
+        ctx.mark_non_differentiable(den)
+        return loss.reshape(()), den.reshape(())
 
     @staticmethod
-    def backward(ctx, dloss):
+    def backward(ctx, dloss, _dden=None):
         s, l = ctx.saved_tensors
         lib = _lib.load()
         out = torch.empty_like(s)
@@ -75,7 +77,18 @@ class _Orientation(torch.autograd.Function):
 
 
 def infoNCELoss(scores, labels, temperature=0.1):
-    return _InfoNCE.apply(scores, labels, temperature)
+    return _InfoNCE.apply(scores, labels, temperature)[0]
+
+
+def infoNCELoss_global(scores, labels, temperature=0.1, group=None):
+    """infoNCELoss over the GLOBAL batch of a data-parallel job: losses.py:18 divides by the label mass of the whole
+    batch, so the exact multi-GPU equivalent of the reference's single-process loss all-reduces (numerator, label mass)
+    — two scalars per level — before the division (harness.global_ratio_loss).  Same value on every rank; with the
+    data-parallel gradient averaging the parameter gradients equal those of one process holding all samples.  With one
+    process it is infoNCELoss."""
+    from .harness import global_ratio_loss
+    loss, den = _InfoNCE.apply(scores, labels, temperature)
+    return global_ratio_loss(loss, den, group)
 
 
 def cross_entropy_loss(logits, labels):

@@ -72,7 +72,10 @@ def _pad2(w, dtype=torch.float32, n_mult=16):
     k_mult = 16 if dtype == torch.float32 else 32
     n, k = w.shape
     if n % n_mult == 0 and k % k_mult == 0:          # nothing to pad (most conv weights): one copy kernel instead of three
-        return w.to(dtype).contiguous()
+        out = w.to(dtype).contiguous()
+        # always a COPY, never an alias of the live parameter: every packed weight then goes stale together when a
+        # parameter is edited behind torch's version counter (see _CVMBase.invalidate)
+        return out.clone() if out.data_ptr() == w.data_ptr() else out
     out = w.new_zeros((_round_up(n, n_mult), _round_up(k, k_mult)))
     out[:n, :k] = w
     return out.to(dtype).contiguous()
@@ -188,10 +191,14 @@ def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
     return out.to(dtype).contiguous(), shift9.float().contiguous()
 
 
-def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True):
+def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True, f32_tail=0):
+    """f32_tail (bf16 packs only): the last `f32_tail` levels of the LOCALISATION decoder (and the heat-map head) get fp32
+    weights — the forward widens the activations entering them, so the arg-max of the heat-map is decided in fp32."""
     spec = MODEL_SPECS[kind]
     pk = _Obj()
     pk.dtype = dtype
+    pk.f32_from = 6 - f32_tail if dtype != torch.float32 else 6      # first loc level index (0..5) that runs in fp32
+    base_dtype = dtype
     pk.grd = _pack_encoder(sd, "grd_efficientnet", dtype, fold_bn=fold)
     pk.sat = _pack_encoder(sd, "sat_efficientnet", dtype, fold_bn=fold)
     # six ground-descriptor heads fused into one 1x1 GEMM (N = sum Cd) + height collapse
@@ -219,6 +226,7 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True):
         lvl = 6 - j
         # ---- loc branch -------------------------------------------------------------------
         dc_in, dc_out, c_in, c_out = spec["loc"][j]
+        dtype = torch.float32 if j >= pk.f32_from else base_dtype
         c = dc_in - 1                                  # feature channels entering the level
         ldo = _round_up(c + 1 + (n_tail if j == 0 else 0), 8)
         lv = _Obj()
@@ -242,6 +250,7 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True):
         lv.b_b = sd["conv%d.2.bias" % lvl].contiguous()
         pk.loc.append(lv)
         # ---- ori branch -------------------------------------------------------------------
+        dtype = base_dtype
         dc_in, dc_out, c_in, c_out = spec["ori"][j]
         ov = _Obj()
         if j == 0:
@@ -333,17 +342,35 @@ class _CVMBase(nn.Module):
         self._pack_cache = None
         self._pack_key = None
         self.precision = "fp32"
+        self.fp32_tail_levels = 2
 
-    def set_precision(self, precision):
+    def set_precision(self, precision, fp32_tail_levels=2):
         """'fp32' (default: exact fp32 everywhere) or 'bf16' (BASELINE C2/C4: bf16 NHWC activations and
         packed weights, fp32 accumulation/BN/SE/softmax; scores, logits, heat-map and orientation are
-        returned in fp32 either way)."""
+        returned in fp32 either way).
+        fp32_tail_levels (bf16 only, default 2): the last levels of the localisation decoder — level 2, level 1 and the
+        heat-map head by default — run through the fp32 kernels on widened activations (the arg-max of
+        the heat-map, models.py:319-320, is a logits-ORDERING question; bf16 storage of the 256^2 / 512^2 tensors that
+        directly form the logits reorders near-ties).  0 = bf16 storage everywhere (fastest; arg-max may move to a
+        near-tie pixel)."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
+        if not 0 <= int(fp32_tail_levels) <= 5:
+            raise ValueError("fp32_tail_levels must be in 0..5 (level 6 feeds the bf16 orientation decoder)")
         self.precision = precision
+        self.fp32_tail_levels = int(fp32_tail_levels)
         return self
 
     # -- weight version tracking -------------------------------------------------------------
+    def invalidate(self):
+        """Drop the packed (re-laid-out, BN-folded, bf16) weights so that the next forward re-packs them from the live
+        parameters.  Needed only after editing parameters or buffers through a path that does not bump torch's version
+        counter — `p.data.copy_()/mul_()` (EMA, manual init): optimizer steps, load_state_dict(), in-place ops on the
+        parameter itself and ccvpe_amd.optim.Adam are detected automatically (_weights_key)."""
+        self._pack_cache = None
+        self._pack_key = None
+        return self
+
     def _weights_key(self):
         from . import _lib
         key = [_lib.weights_epoch]
@@ -355,7 +382,7 @@ class _CVMBase(nn.Module):
         # running statistics are updated in place by the HIP kernels (no torch version bump): the eval pack (BN folded
         # from them) additionally depends on how many train-mode forwards have run; the train pack does not use them
         epoch = 0 if self.training else getattr(self, "_stats_epoch", 0)
-        key = (self.precision, self.training, epoch) + self._weights_key()
+        key = (self.precision, self.fp32_tail_levels, self.training, epoch) + self._weights_key()
         if self._pack_cache is None or key != self._pack_key:
             sd = {k: v.detach() for k, v in self.state_dict().items()}
             dev = next(self.parameters()).device
@@ -365,7 +392,8 @@ class _CVMBase(nn.Module):
             dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
             with torch.no_grad():
                 # train mode runs the decoders unfused (ccvpe_amd/train.py): skip the fp64 fold of deconv into conv
-                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training)
+                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training,
+                                               f32_tail=self.fp32_tail_levels)
             self._pack_key = key
         return self._pack_cache
 
@@ -467,8 +495,15 @@ class _CVMBase(nn.Module):
             x = sdesc
             cat6 = None
             goff = 0
+            sfeats_loc = sfeats
             for j in range(6):
                 lv = pk.loc[j]
+                if j == pk.f32_from:
+                    # bf16 storage path: from here on the localisation decoder runs in fp32 (ops dispatch on the
+                    # activation dtype); widen its input and the skips it still needs — the orientation decoder keeps
+                    # reading the bf16 originals
+                    x = ops.cast_f32(x)
+                    sfeats_loc = dict((SKIP_BLOCKS[q], ops.cast_f32(sfeats[SKIP_BLOCKS[q]])) for q in range(j, 5))
                 hw = x.shape[1]
                 cd = spec["cd"][j]
                 L = gw * cd
@@ -497,7 +532,7 @@ class _CVMBase(nn.Module):
                             x_ori = self._ori_decoder(pk, cat6, sfeats, batch)
                 else:
                     scores_out.append(sc)
-                skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+                skip = sfeats_loc[SKIP_BLOCKS[j]] if j < 5 else None
                 if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:   # deconv folded into conv.0: one GEMM per output parity
                     y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,
                                       src1=skip, c1=lv.c1, act=ops.ACT_RELU)
@@ -506,8 +541,10 @@ class _CVMBase(nn.Module):
                                         shift=lv.up_b, out_mode=ops.OUT_DECONV2X, algo_k=lv.c + 1)
                     y = _double_conv(lv, up, skip, batch, 2 * hw)
                 if j < 5:
+                    # the level feeding the fp32 tail writes its output in fp32 directly (no separate widening pass)
                     x = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
-                                       kh=3, kw=3, pad=1, shift=lv.b_b)
+                                       kh=3, kw=3, pad=1, shift=lv.b_b,
+                                       out_f32=(j + 1 == pk.f32_from and y.dtype != torch.float32))
                 else:
                     logits_map = ops.head_conv3x3(y, lv.w_b, lv.b_b, 1, False)      # [B,1,512,512]
             logits = logits_map.reshape(batch, -1)                                   # models.py:319

@@ -327,6 +327,17 @@ def head_conv3x3(x, w, bias, cout, normalize):
     return out
 
 
+def cast_f32(x):
+    """bf16 activation tensor -> fp32 (ccvpe_cast_bf16_f32); an fp32 tensor is returned as is."""
+    if x.dtype == torch.float32:
+        return x
+    lib = _lib.load()
+    _chk(x, "x", torch.bfloat16)
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_cast_bf16_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "ccvpe_cast_bf16_f32")
+    return out
+
+
 def softmax_rows(logits):
     lib = _lib.load()
     _chk(logits, "logits")
@@ -421,12 +432,15 @@ def _loss_common(fn, name, tensors, extra):
     return lib, loss, scratch, b
 
 
-def infonce_loss(scores, labels, temperature=0.1):
-    """losses.py:4 infoNCELoss — forward value only (device scalar)."""
+def infonce_loss(scores, labels, temperature=0.1, want_den=False):
+    """losses.py:4 infoNCELoss — forward value only (device scalar).  want_den: also return the batch's label mass
+    sum(labels > 1e-2) (the loss's denominator, losses.py:18) from the kernel's per-row partials."""
     lib, loss, scratch, b = _loss_common(None, "infonce", (scores, labels), None)
     n = scores.shape[1]
     check(lib.ccvpe_infonce_loss_f32(_ptr(scores), _ptr(labels), float(temperature), _ptr(loss), _ptr(scratch),
                                      b, n, _stream()), "ccvpe_infonce_loss_f32")
+    if want_den:
+        return loss[0], scratch.view(b, 2)[:, 1].sum()
     return loss[0]
 
 

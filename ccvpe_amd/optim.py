@@ -1,8 +1,15 @@
 """Adam for the training step on the MI355X: torch.optim.Adam's arithmetic (train_VIGOR.py:104 / train_KITTI.py:
 `torch.optim.Adam(params, lr, betas=(0.9, 0.999))`, eps 1e-8, no weight decay, no amsgrad) with ONE kernel launch for
-all ~520 parameter tensors (ccvpe_adam_step_f32: a device table of (param, grad, exp_avg, exp_avg_sq, numel) rows and
-a workgroup -> (tensor, chunk) map).  Same constructor / step() / zero_grad() / state_dict() surface as the torch class
-for the options the reference uses; the state dict is in torch's format, so checkpoints interchange."""
+all ~520 parameter tensors (ccvpe_adam_step_f32: a device table of (param, grad, exp_avg, exp_avg_sq, numel) rows, a
+per-tensor hyper-parameter row and a workgroup -> (tensor, chunk) map).
+
+It IS a torch.optim.Optimizer: param groups (per-group lr / betas / eps), `state[p] = {step, exp_avg, exp_avg_sq}` in
+torch.optim.Adam's format, the base class's validated state_dict() / load_state_dict() (checkpoints interchange with
+torch.optim.Adam), add_param_group(), and torch LR schedulers all work.  Like torch, every parameter keeps its own step
+count (a parameter that starts receiving gradients later gets its own bias correction).  Not supported (raises):
+weight_decay, amsgrad, maximize, sparse gradients."""
+import math
+
 import numpy as np
 import torch
 
@@ -10,87 +17,90 @@ from . import _lib, ops
 from ._lib import check
 
 
-class Adam(object):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        self.params = [p for p in params]
-        if not self.params:
-            raise ValueError("optimizer got an empty parameter list")
-        for p in self.params:
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay or amsgrad:
+            raise ValueError("ccvpe_amd.optim.Adam implements the reference's configuration: no weight_decay / amsgrad")
+        if lr < 0 or eps < 0 or not (0 <= betas[0] < 1 and 0 <= betas[1] < 1):
+            raise ValueError("invalid Adam hyper-parameters")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False))
+        self._layout = None
+        self.grad_scale = 1.0        # set by harness.GradientAllReducer when the all-reduce left a SUM in the gradients
+
+    # ---- static launch geometry: rebuilt only when the parameter set changes --------------------------------
+    def _build_layout(self):
+        lib = _lib.load()
+        params = [p for g in self.param_groups for p in g["params"]]
+        for p in params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise ValueError("ccvpe_amd.optim.Adam needs contiguous fp32 parameters on the MI355X (no CPU fallback)")
-        self.param_groups = [dict(params=self.params, lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False)]
-        self.exp_avg = [torch.zeros_like(p) for p in self.params]
-        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
-        self.steps = [0 for _ in self.params]          # per parameter, as torch: a tensor without a gradient does not step
-        lib = _lib.load()
         chunk = lib.ccvpe_adam_chunk_elems()
         ct, co = [], []
-        for t, p in enumerate(self.params):
+        for t, p in enumerate(params):
             n = (p.numel() + chunk - 1) // chunk
             ct.append(np.full((n,), t, dtype=np.int32))
             co.append(np.arange(n, dtype=np.int32))
-        dev = self.params[0].device
-        self._chunk_tensor = torch.from_numpy(np.concatenate(ct)).to(dev)
-        self._chunk_off = torch.from_numpy(np.concatenate(co)).to(dev)
-        self._table_host = np.zeros((len(self.params), 5), dtype=np.int64)
-        for t, p in enumerate(self.params):
-            self._table_host[t] = (p.data_ptr(), 0, self.exp_avg[t].data_ptr(), self.exp_avg_sq[t].data_ptr(), p.numel())
+        dev = params[0].device
+        lay = dict(params=params, ids=tuple(id(p) for p in params),
+                   chunk_tensor=torch.from_numpy(np.concatenate(ct)).to(dev),
+                   chunk_off=torch.from_numpy(np.concatenate(co)).to(dev),
+                   table=np.zeros((len(params), 5), dtype=np.int64),
+                   hyper=np.zeros((len(params), lib.ccvpe_adam_hyper_floats()), dtype=np.float32))
+        self._layout = lay
+        return lay
 
-    def zero_grad(self, set_to_none=True):
-        for p in self.params:
-            if p.grad is not None:
-                if set_to_none:
-                    p.grad = None
-                else:
-                    p.grad.zero_()
+    def _state_of(self, p):
+        st = self.state[p]
+        if len(st) == 0:                                     # lazy, as torch.optim.Adam._init_group
+            st["step"] = torch.tensor(0.0, dtype=torch.float32)
+            st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+        return st
 
     @torch.no_grad()
-    def step(self):
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
         lib = _lib.load()
-        g = self.param_groups[0]
-        keep = []                                       # contiguous copies must outlive the launch
-        stepped = None
-        for t, p in enumerate(self.params):
-            gr = p.grad
-            if gr is None:
-                self._table_host[t, 1] = 0
-                continue
-            if not gr.is_contiguous() or gr.dtype != torch.float32:
-                gr = gr.contiguous().float()
-                keep.append(gr)
-            self._table_host[t, 0] = p.data_ptr()
-            self._table_host[t, 1] = gr.data_ptr()
-            self.steps[t] += 1
-            if stepped is None:
-                stepped = self.steps[t]
-            elif stepped != self.steps[t]:
-                raise RuntimeError("ccvpe_amd.optim.Adam: parameters with different step counts in one step() "
-                                   "(a parameter started receiving gradients later) are not supported")
-        if stepped is None:
-            return
-        table = torch.from_numpy(self._table_host).to(self.params[0].device)
-        check(lib.ccvpe_adam_step_f32(ops._ptr(table), ops._ptr(self._chunk_tensor), ops._ptr(self._chunk_off),
-                                      self._chunk_tensor.numel(), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]),
-                                      float(g["eps"]), stepped, ops._stream()), "ccvpe_adam_step_f32")
+        lay = self._layout
+        if lay is None or lay["ids"] != tuple(id(p) for g in self.param_groups for p in g["params"]):
+            lay = self._build_layout()
+        table, hyper = lay["table"], lay["hyper"]
+        keep, any_grad, t = [], False, 0
+        for g in self.param_groups:
+            lr, (b1, b2), eps = float(g["lr"]), g["betas"], float(g["eps"])
+            if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
+                raise ValueError("ccvpe_amd.optim.Adam: weight_decay / amsgrad / maximize are not implemented")
+            for p in g["params"]:
+                gr = p.grad
+                if gr is None:
+                    table[t, 1] = 0
+                    t += 1
+                    continue
+                if gr.is_sparse:
+                    raise RuntimeError("ccvpe_amd.optim.Adam does not support sparse gradients")
+                if not gr.is_contiguous() or gr.dtype != torch.float32:
+                    gr = gr.contiguous().float()
+                    keep.append(gr)
+                st = self._state_of(p)
+                st["step"] += 1
+                k = float(st["step"])
+                # bias corrections and 1 - beta in double on the host, as torch.optim.Adam does with Python floats
+                hyper[t] = (lr / (1.0 - b1 ** k), b1, b2, 1.0 - b1, 1.0 - b2, eps, math.sqrt(1.0 - b2 ** k), 0.0)
+                table[t] = (p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+                any_grad = True
+                t += 1
+        if not any_grad:
+            return loss
+        dev = lay["params"][0].device
+        tab_d = torch.from_numpy(table).to(dev, non_blocking=False)
+        hyp_d = torch.from_numpy(hyper).to(dev, non_blocking=False)
+        check(lib.ccvpe_adam_step_f32(ops._ptr(tab_d), ops._ptr(hyp_d), ops._ptr(lay["chunk_tensor"]), ops._ptr(lay["chunk_off"]),
+                                      lay["chunk_tensor"].numel(), float(self.grad_scale), ops._stream()), "ccvpe_adam_step_f32")
         _lib.weights_epoch += 1          # parameters changed without a torch version bump: invalidate packed weights
-        table.record_stream(torch.cuda.current_stream())
-        for k in keep:
-            k.record_stream(torch.cuda.current_stream())
-
-    # torch.optim.Adam-compatible state dict -------------------------------------------------------------
-    def state_dict(self):
-        state = {}
-        for t in range(len(self.params)):
-            if self.steps[t]:
-                state[t] = dict(step=torch.tensor(float(self.steps[t])), exp_avg=self.exp_avg[t], exp_avg_sq=self.exp_avg_sq[t])
-        groups = [dict(self.param_groups[0], params=list(range(len(self.params))))]
-        return dict(state=state, param_groups=groups)
-
-    def load_state_dict(self, sd):
-        for t, st in sd["state"].items():
-            t = int(t)
-            self.exp_avg[t].copy_(st["exp_avg"])
-            self.exp_avg_sq[t].copy_(st["exp_avg_sq"])
-            self.steps[t] = int(st["step"])
-        g = sd["param_groups"][0]
-        self.param_groups[0].update(lr=g["lr"], betas=tuple(g["betas"]), eps=g["eps"])
+        cur = torch.cuda.current_stream()
+        for k in keep + [tab_d, hyp_d]:
+            k.record_stream(cur)
+        return loss

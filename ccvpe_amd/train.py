@@ -77,6 +77,7 @@ def encoder_forward(model, e, live, prefix, img, circular, multiscale, drop_mask
             else:                                                                # utils.py:145-150
                 mask = torch.floor(keep + torch.rand((b,), device=x.device, dtype=torch.float32))
             dc = (mask / keep).contiguous()
+            model._last_drop_masks[(prefix, i)] = mask          # diagnostics / tests/test_drop_connect_gpu.py
         x, m2, v2 = _bn(model, live, bp + "._bn2", p_raw, ops.ACT_NONE, residual=x if blk.skip else None, dc=dc)
         if rec:
             s.update(p_raw=p_raw, m2=m2, v2=v2, dc=dc)
@@ -121,6 +122,7 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     batch = grd.shape[0]
     tape = {} if rec else None
     model._nbt_pending = []
+    model._last_drop_masks = {}
 
     gfeat, _, gt = encoder_forward(model, pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks, rec)
     _, gh, gw, _ = gfeat.shape
@@ -416,7 +418,9 @@ class CVMFunction(torch.autograd.Function):
             raise RuntimeError("ccvpe_amd: backward through the same forward twice is not supported")
         sync = getattr(model, "_grad_sync", None)          # harness.GradientAllReducer.attach(model)
         with torch.no_grad():
-            if sync is not None and sync.active():
+            if sync is not None and sync.arena_ok():
+                # flat gradient arena: every finished group is copied into its slots and (with several ranks) all-reduced
+                # in place while the rest of the backward runs; the parameters' .grad become views of the arena
                 sync.begin()
                 grads = backward_train(model, tape, gout, on_ready=sync.ready)
                 sync.finish(grads)

@@ -201,6 +201,9 @@ int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, fl
 
 /* Row softmax over n columns (models.py:319-320: Softmax over the 262144 flattened logits). */
 int ccvpe_softmax_rows_f32(const float* logits, float* out, int rows, int n, void* stream);
+/* bf16 -> fp32 widening of an activation tensor (n_elems % 8 == 0, 16-byte aligned): the bf16 storage path runs its last
+ * localisation-decoder levels through the fp32 kernels (models.py:299-320 decide the heat-map arg-max). */
+int ccvpe_cast_bf16_f32(const void* src, float* dst, long n_elems, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Evaluation post-processing on the device (train_VIGOR.py:294-324, train_KITTI.py:304-343): per
@@ -262,6 +265,7 @@ int ccvpe_bn_act_f32(const float* x, const float* mean, const float* var, const 
  *     (1x1: W^T; 3x3: taps flipped, in/out swapped; deconv <-> conv 2x2 stride 2) — ccvpe_amd/backward.py.
  *   ccvpe_colsum_f32: per-channel column sums (bias gradients); scratch ceil(rows/256)*channels floats.
  * ----------------------------------------------------------------------------------------- */
+int ccvpe_conv_wgrad_tile(int n, int ncols);   /* (tile rows << 16) | tile columns the launch will use (reporting) */
 int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad, int ctot,
                                     int n);
 int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1, const float* dy,
@@ -359,22 +363,26 @@ int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const 
  *     train_VIGOR.py:120-128 from 3 scalars per sample instead of 24 MB of host tensors:
  *       center_xy [B][2] = (cx, cy) with x_j = -W/2 + cx + j*W/(W-1), y_i = -H/2 + cy + i*H/(H-1)
  *                          (VIGOR: cx = col_offset, cy = -row_offset; KITTI: cx = x_offset, cy = y_offset)
- *       angle_deg [B] in [0, 360);  n_bins 20 (VIGOR) / 16 (KITTI);  sigma 4
+ *       angle_deg [B] (wrapped into [0, 360) by the kernel);  n_bins 20 (VIGOR) / 16 (KITTI);  sigma 4
  *     writes gt [B,1,H,W], gt_norm [B,H*W] (= gt / sum gt), gt_ori [B,2,H,W] (cos, sin) and the six max-pooled
  *     orientation-binned label maps lab_l [B,n_bins,H/k,W/k], k = 64,32,16,8,4,2 (gt_with_ori is never materialised).
  *     scratch: batch * ccvpe_train_targets_nblk(h, w) floats.
  *   ccvpe_adam_step_f32: torch.optim.Adam (no weight decay / amsgrad; train_VIGOR.py:104) for ALL parameter tensors in
  *     one launch.  table [n_tensors][5] int64 device array of (param, grad, exp_avg, exp_avg_sq, numel) — a NULL grad
- *     skips the tensor; chunk_tensor / chunk_off [n_chunks] map each workgroup to (tensor, chunk of
- *     ccvpe_adam_chunk_elems() elements).  step = 1-based step count.
+ *     skips the tensor; hyper [n_tensors][ccvpe_adam_hyper_floats()] fp32 device array, per tensor
+ *     (lr / (1 - beta1^t), beta1, beta2, 1 - beta1, 1 - beta2, eps, sqrt(1 - beta2^t), 0) with t that tensor's own
+ *     1-based step count (bias corrections and 1 - beta formed in double on the host, as torch does);
+ *     chunk_tensor / chunk_off [n_chunks] map each workgroup to (tensor, chunk of ccvpe_adam_chunk_elems() elements);
+ *     grad_scale multiplies every gradient on load (1 / world after a SUM all-reduce; 1 otherwise).
  * ----------------------------------------------------------------------------------------- */
 int ccvpe_train_targets_nblk(int h, int w);
 int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
                             float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
                             float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream);
 int ccvpe_adam_chunk_elems(void);
-int ccvpe_adam_step_f32(const void* table, const int* chunk_tensor, const int* chunk_off, int n_chunks, double lr,
-                        double beta1, double beta2, double eps, int step, void* stream);
+int ccvpe_adam_hyper_floats(void);
+int ccvpe_adam_step_f32(const void* table, const float* hyper, const int* chunk_tensor, const int* chunk_off, int n_chunks,
+                        float grad_scale, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * Input pipeline after JPEG decoding (csrc/preprocess.hip): transforms.Resize on a PIL image

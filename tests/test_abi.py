@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libccvpe_hip.so does not export %s" % n
     assert sorted(_lib.PROTOTYPES) == names, "ctypes table and header disagree"
-    assert lib.ccvpe_abi_version() == 1
+    assert lib.ccvpe_abi_version() == 2
 
 
 def test_ctypes_prototypes_match_header_signatures():
@@ -49,6 +49,8 @@ def test_ctypes_prototypes_match_header_signatures():
                 assert a is ctypes.c_float, (name, q, a)
             elif q.startswith("double"):
                 assert a is ctypes.c_double, (name, q, a)
+            elif q.startswith("long"):
+                assert a is ctypes.c_long, (name, q, a)
             else:
                 assert a is ctypes.c_int, (name, q, a)
 

@@ -62,4 +62,49 @@ def test_adam_matches_torch_adam():
     assert torch.allclose(sd["state"][3]["exp_avg_sq"].cpu(), rs[3]["exp_avg_sq"], rtol=1e-5, atol=1e-12)
     twin = optim.Adam(our_p, lr=1e-4)
     twin.load_state_dict(sd)
-    assert twin.steps == ours.steps and torch.equal(twin.exp_avg[0], ours.exp_avg[0])
+    assert float(twin.state[our_p[0]]["step"]) == 5.0 and torch.equal(twin.state[our_p[0]]["exp_avg"], ours.state[our_p[0]]["exp_avg"])
+    with pytest.raises(ValueError):                      # torch's own validation: wrong number of parameters
+        optim.Adam(our_p[:2], lr=1e-4).load_state_dict(sd)
+
+
+def test_adam_late_parameter_scheduler_and_grad_scale():
+    """torch.optim.Adam semantics the first version lacked: a parameter that starts receiving gradients later
+    keeps its own step count / bias correction, torch LR schedulers drive the optimizer, per-group hyper-parameters;
+    plus grad_scale (SUM all-reduce -> mean folded into the update)."""
+    from ccvpe_amd import optim
+    shapes = [(33, 7), (4096,), (5, 3, 3, 3)]
+    ref_p = [torch.nn.Parameter(synth.normal(s, 2100 + i, 0.1)) for i, s in enumerate(shapes)]
+    our_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ref = torch.optim.Adam([dict(params=ref_p[:2]), dict(params=ref_p[2:], lr=3e-3, betas=(0.8, 0.99))], lr=1e-3)
+    ours = optim.Adam([dict(params=our_p[:2]), dict(params=our_p[2:], lr=3e-3, betas=(0.8, 0.99))], lr=1e-3)
+    rs = torch.optim.lr_scheduler.StepLR(ref, step_size=2, gamma=0.5)
+    os_ = torch.optim.lr_scheduler.StepLR(ours, step_size=2, gamma=0.5)          # TypeError before: not an Optimizer
+    ours.grad_scale = 0.25
+    for step in range(6):
+        for i, (a, b) in enumerate(zip(ref_p, our_p)):
+            if i == 1 and step < 3:            # starts receiving gradients at step 3
+                a.grad, b.grad = None, None
+                continue
+            g = synth.normal(tuple(a.shape), 3100 + 10 * step + i, 1e-2)
+            a.grad = g.clone() * 0.25
+            b.grad = g.cuda()
+        ref.step(); ours.step()
+        rs.step(); os_.step()
+    torch.cuda.synchronize()
+    assert float(ours.state[our_p[1]]["step"]) == 3.0 and float(ours.state[our_p[0]]["step"]) == 6.0
+    for i, (a, b) in enumerate(zip(ref_p, our_p)):
+        d = (a.detach() - b.detach().cpu()).abs().max().item()
+        moved = (a.detach() - synth.normal(shapes[i], 2100 + i, 0.1)).abs().max().item()
+        assert d <= 2e-3 * moved + 1e-9, (i, d, moved)
+
+
+def test_targets_angle_wrap():
+    """a negative / >= 360 angle must land in the same bins as its wrapped value (datasets.py:483-487 wraps
+    before binning), never produce all-zero labels."""
+    from ccvpe_amd import targets
+    center = torch.tensor([[3.0, -7.0]] * 4, device="cuda")
+    ang = torch.tensor([-30.0, 330.0, 365.5, 5.5], device="cuda")
+    labs = targets.train_targets(center, ang, 16)[3]
+    for l in labs:
+        assert torch.equal(l[0], l[1]) and torch.equal(l[2], l[3])
+        assert float(l[0].sum()) > 0
