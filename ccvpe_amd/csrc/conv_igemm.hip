@@ -34,6 +34,7 @@
 // (1 x v_mfma_f32_16x16x32_bf16, fp32 accumulate).  bf16 stores round-to-nearest-even
 // (v_cvt_pk_bf16_f32); scale/shift/gate and all accumulation stay fp32.
 #include "common.h"
+#include <cstdlib>
 
 namespace ccvpe {
 
@@ -370,6 +371,258 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       store4<T>(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pointwise (1x1, stride 1, one source) GEMM: the EfficientNet expand / project / head convs and the fused ground
+// descriptor conv (efficientnet_pytorch/model.py:62,86,209; models.py:57-97) and their 1x1 input gradients.
+//
+// These layers have SHORT K (16 ... 1152 channels) against millions of pixels: with 64-byte K stages the generic kernel
+// above is a chain of dependent (global load -> LDS -> barrier) round trips per tile (4-72 of them) with ~15 KB in flight
+// per workgroup, and its epilogue stores 8-16 bytes per lane at a pixel stride — the profile showed 0.5-1.2 TB/s
+// algorithmic on layers whose roof is HBM.  Here:
+//   * a K stage is KP x 64 bytes per row (KP = 4: 64 fp32 / 128 bf16 channels): one stage covers the whole K of most
+//     expand convs in bf16; 4x fewer barriers and 4x the bytes in flight; 16 consecutive lanes read 256 contiguous bytes
+//     of one pixel row (full cache lines instead of 64-byte fragments);
+//   * register-staged, ONE LDS buffer (the loads of stage s+1 are in flight during the MFMAs of stage s; 2 workgroups per
+//     CU cover the store/barrier bubbles) — register staging keeps the SE-gate multiply and the zero fill of the K / M tails;
+//   * the epilogue goes through LDS: scale/shift/activation in registers, fp32 tile rows in LDS, then every thread stores
+//     16 bytes with consecutive lanes along the channel axis — whole output rows (and whole residual rows) per wave.
+// Same MFMA k-order as igemm_kernel (stage pieces in order, the q/kk permutation inside a 64-byte piece): fp32 results are
+// bit-identical to the generic kernel's.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MT, int NT, int WN>
+struct PwGeom {
+  static constexpr int WM = 4 / WN;
+  static constexpr int BM = 16 * MT * WM;
+  static constexpr int BN = 16 * NT * WN;
+  static constexpr int LDS_BUDGET = 80 * 1024;                                   // 2 workgroups per CU
+  // 64-byte pieces per staged row: 4 when the stage fits the LDS budget — except the 20-accumulator fp32 tile, whose
+  // staging registers (18 x 16 bytes per thread at KP = 4) would spill past the 256-VGPR cap of 2 waves per SIMD
+  static constexpr int KP = ((BM + BN) * (64 * 4 + 16) <= LDS_BUDGET && !(sizeof(T) == 4 && MT * NT >= 20)) ? 4 : 2;
+  static constexpr int LDF = 16 * KP + 4;                                        // floats per staged row
+  static constexpr int OLD = BN + 4;                                             // floats per epilogue-tile row
+  static constexpr int IC = (BM * OLD * 4 <= LDS_BUDGET) ? MT : MT / 2;          // MFMA row tiles per epilogue pass
+  static constexpr int STAGE_BYTES = (BM + BN) * LDF * 4;
+  static constexpr int OUT_BYTES = WM * IC * 16 * OLD * 4;
+  static constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+};
+
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
+  using G = PwGeom<T, MT, NT, WN>;
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int WM = G::WM, BM = G::BM, BN = G::BN, KP = G::KP, LDF = G::LDF, OLD = G::OLD, IC = G::IC;
+  constexpr int PPR = 4 * KP;                 // 16-byte pieces per staged row
+  constexpr int KS = PPR * E;                 // K elements per stage
+  constexpr int A_IT = BM * PPR / 256;
+  constexpr int B_IT = (BN * PPR + 255) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) float pw_sm[];
+  float* As = pw_sm;                          // [BM][LDF]
+  float* Bs = pw_sm + BM * LDF;               // [BN][LDF]
+  float* Os = pw_sm;                          // epilogue tile [WM*IC*16][OLD] (aliases the dead stage buffers)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
+  const int tm = tile / p.tiles_n;
+  const int tn = tile % p.tiles_n;
+  const int m0 = tm * BM;
+  const int n0 = tn * BN;
+  const T* src0 = reinterpret_cast<const T*>(p.src0);
+  const T* wp = reinterpret_cast<const T*>(p.w);
+  const int hw = p.Ho * p.Wo;
+  const int nstages = (p.c0 + KS - 1) / KS;
+
+  const int prow = tid / PPR;                 // staged row of iteration 0; iteration `it` adds it * (256 / PPR)
+  const int pc = tid % PPR;                   // 16-byte piece inside the staged row
+  f32x4 a_reg[A_IT], b_reg[B_IT];
+
+  auto load_stage = [&](int s) {
+    const int kcol = s * KS + pc * E;         // first K element of this thread's piece
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int m = m0 + prow + it * (256 / PPR);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (m < p.M && kcol < p.c0) {
+        v = *reinterpret_cast<const f32x4*>(src0 + (size_t)m * p.ld0 + kcol);
+        if (p.gate != nullptr) v = apply_gate<T>(v, p.gate + (size_t)(m / hw) * p.c0 + kcol);
+      }
+      a_reg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = prow + it * (256 / PPR);
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (nrow < BN && n0 + nrow < p.Npad && kcol < p.Kpad)
+        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + kcol);
+      b_reg[it] = v;
+    }
+  };
+  auto store_stage = [&]() {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      *reinterpret_cast<f32x4*>(&As[(prow + it * (256 / PPR)) * LDF + pc * 4]) = a_reg[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) {
+      const int nrow = prow + it * (256 / PPR);
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[nrow * LDF + pc * 4]) = b_reg[it];
+    }
+  };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 4;
+
+  load_stage(0);
+  store_stage();
+  __syncthreads();
+  for (int s = 0; s < nstages; ++s) {
+    const bool more = s + 1 < nstages;
+    if (more) load_stage(s + 1);
+#pragma unroll
+    for (int kp = 0; kp < KP; ++kp) {
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * LDF + kp * 16 + fk]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * LDF + kp * 16 + fk]);
+      if (sizeof(T) == 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
+      }
+    }
+    __syncthreads();                          // every wave is done reading this stage
+    if (more) {
+      store_stage();
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: registers -> (scale, shift, act) -> LDS rows -> 16-byte stores along the channel axis ----------
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
+  const bool f32out = sizeof(T) == 4 || p.out_f32;
+  const T* res = reinterpret_cast<const T*>(p.residual);
+#pragma unroll
+  for (int ic = 0; ic < MT / IC; ++ic) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int nl = (wn * NT + j) * 16 + en;             // tile-local channel of acc[.][j][0]
+      float sc[4], sh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + nl + q;
+        const bool ok = n < p.N;
+        sc[q] = (ok && p.scale) ? p.scale[n] : 1.0f;
+        sh[q] = (ok && p.shift) ? p.shift[n] : 0.0f;
+      }
+#pragma unroll
+      for (int ii = 0; ii < IC; ++ii) {
+        f32x4 v = acc[ic * IC + ii][j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t = v[q] * sc[q] + sh[q];
+          if (p.act == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
+          else if (p.act == CCVPE_ACT_SWISH) t = swishf(t);
+          v[q] = t;
+        }
+        *reinterpret_cast<f32x4*>(&Os[((wm * IC + ii) * 16 + epix) * OLD + nl]) = v;
+      }
+    }
+    __syncthreads();
+    // each thread: one run of EO consecutive channels of one pixel per iteration (EO * out element size = 16 bytes)
+    const int EO = f32out ? 4 : 8;
+    const int ppo = BN / EO;                              // BN is a multiple of 16
+    const int total = WM * IC * 16 * ppo;
+    for (int idx = tid; idx < total; idx += 256) {
+      const int r = idx / ppo;
+      const int c = (idx - r * ppo) * EO;
+      const int m = m0 + ((r / (IC * 16)) * MT + ic * IC + (r / 16) % IC) * 16 + (r & 15);
+      const int n = n0 + c;
+      if (m >= p.M || n >= p.N) continue;
+      const float* o = &Os[r * OLD + c];
+      f32x4 v0 = *reinterpret_cast<const f32x4*>(o);
+      f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
+      if (!f32out) v1 = *reinterpret_cast<const f32x4*>(o + 4);
+      const size_t obase = (size_t)m * p.ldd + n;
+      const size_t rbase = (size_t)m * p.ldres + n;
+      if (n + EO <= p.N) {
+        if (res) {
+          if (sizeof(T) == 4) {
+            v0 += *reinterpret_cast<const f32x4*>(res + rbase);
+          } else {          // bf16 residual: 8 channels = 16 bytes (4 when the output is fp32)
+            const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(res + rbase);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v0[q] += (float)r0[q];
+            if (!f32out) {
+              const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(res + rbase + 4);
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v1[q] += (float)r1[q];
+            }
+          }
+        }
+        if (f32out) {
+          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + obase) = v0;
+        } else {
+          bf16x8 ov;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { ov[q] = (bf16_t)v0[q]; ov[q + 4] = (bf16_t)v1[q]; }
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.dst) + obase) = ov;
+        }
+      } else {              // ragged N tail: element by element
+        for (int q = 0; q < EO && n + q < p.N; ++q) {
+          float t = q < 4 ? v0[q] : v1[q - 4];
+          if (res) t += (float)res[rbase + q];
+          if (f32out) reinterpret_cast<float*>(p.dst)[obase + q] = t;
+          else reinterpret_cast<bf16_t*>(p.dst)[obase + q] = (bf16_t)t;
+        }
+      }
+    }
+    if (ic + 1 < MT / IC) __syncthreads();
+  }
+}
+
+template <typename T, int MT, int NT, int WN>
+static int launch_pw(const IgemmParams& p0, hipStream_t stream) {
+  using G = PwGeom<T, MT, NT, WN>;
+  IgemmParams p = p0;
+  const int tiles_m = (p.M + G::BM - 1) / G::BM;
+  p.tiles_n = (p.Npad + G::BN - 1) / G::BN;
+  p.tiles_total = tiles_m * p.tiles_n;
+  p.ksplit = 1;
+  p.sps = p.stages;
+  p.partial = nullptr;
+  static bool attr_set = false;               // one flag per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)pw_gemm_kernel<T, MT, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       G::LDS_BYTES);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "pw_gemm: set smem attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((pw_gemm_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
+  return check_launch("pw_gemm_kernel");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1215,6 +1468,9 @@ static int pick_cfg(int npad16) {
 
 using namespace ccvpe;
 
+// CCVPE_PW_GEMM=0 routes the pointwise convs through the generic kernel again (A/B measurements)
+static const bool g_use_pw = !(getenv("CCVPE_PW_GEMM") && getenv("CCVPE_PW_GEMM")[0] == '0');
+
 template <typename T>
 static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, float* scratch = nullptr,
                           long* want_floats = nullptr) {
@@ -1262,10 +1518,18 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   // split-K mode (planning or with scratch): everything, 3x3 included, goes through the generic gather kernel
   const bool sk = scratch != nullptr || want_floats != nullptr;
   if (scratch && !aligned16(scratch)) return fail(CCVPE_EINVAL, "conv_igemm: scratch must be 16-byte aligned");
+  // pointwise convs (1x1, stride 1, one source, plain NHWC store) take the deep-stage kernel; the residual / bf16 rows
+  // it touches with 16-byte accesses must be 16-byte aligned along the channel axis
+  const int esz = (int)sizeof(T);
+  const bool out32 = esz == 4 || out_f32;
+  const bool is_pw = g_use_pw && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 &&
+                     d->out_mode == CCVPE_OUT_NHWC && (d->ldd * (out32 ? 4 : 2)) % 16 == 0 &&
+                     (!d->residual || (d->ldres * esz) % 16 == 0);
 #define CCVPE_CASE(MT_, NT_, WN_)                                                  \
   if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                                 \
     if (sk) return launch<T, MT_, NT_, WN_>(p, st, scratch, want_floats);          \
     if (is3x3) return launch3x3<T, MT_, NT_, WN_>(p, d->batch, st);                \
+    if (is_pw) return launch_pw<T, MT_, NT_, WN_>(p, st);                          \
     return launch<T, MT_, NT_, WN_>(p, st);                                        \
   }
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)

@@ -342,17 +342,20 @@ class _CVMBase(nn.Module):
         self._pack_cache = None
         self._pack_key = None
         self.precision = "fp32"
-        self.fp32_tail_levels = 2
+        self.fp32_tail_levels = 1
 
-    def set_precision(self, precision, fp32_tail_levels=2):
+    def set_precision(self, precision, fp32_tail_levels=1):
         """'fp32' (default: exact fp32 everywhere) or 'bf16' (BASELINE C2/C4: bf16 NHWC activations and
         packed weights, fp32 accumulation/BN/SE/softmax; scores, logits, heat-map and orientation are
         returned in fp32 either way).
-        fp32_tail_levels (bf16 only, default 2): the last levels of the localisation decoder — level 2, level 1 and the
-        heat-map head by default — run through the fp32 kernels on widened activations (the arg-max of
-        the heat-map, models.py:319-320, is a logits-ORDERING question; bf16 storage of the 256^2 / 512^2 tensors that
-        directly form the logits reorders near-ties).  0 = bf16 storage everywhere (fastest; arg-max may move to a
-        near-tie pixel)."""
+        fp32_tail_levels (bf16 only, default 1): the last levels of the localisation decoder — level 1 and the heat-map
+        head by default — run through the fp32 kernels on widened activations (the arg-max of the
+        heat-map, models.py:319-320, is a logits-ORDERING question; bf16 storage of the 512^2 tensors that directly form the
+        logits reorders near-ties).  Measured over 64 seeded pairs against the fp32 path (tools/bf16_argmax_rate.py, CVM_VIGOR
+        N_rot = 20; fp32 top-1/top-2 margins down to 1.5e-3 of the logit range): tail 0 -> 63/64 arg-max pixels equal (logit
+        error 5.3e-3 of range), tail 1 -> 64/64 (4.5e-3), tail 2 -> 64/64 (3.5e-3), tail 3 -> 64/64 (3.4e-3): the floor
+        comes from the bf16 encoders / upper decoder levels, so more than one fp32 level buys little for ~2.5 ms per level
+        at B = 64.  0 = bf16 storage everywhere (fastest; the arg-max may move to a near-tie pixel)."""
         if precision not in ("fp32", "bf16"):
             raise ValueError("precision must be 'fp32' or 'bf16'")
         if not 0 <= int(fp32_tail_levels) <= 5:

@@ -214,14 +214,47 @@ def test_forward_bf16_vs_oracle(case, synth_sd):
     lg, rl = out[0].cpu(), ref[0]
     rng = (rl.max() - rl.min()).item()
     err = (lg - rl).abs().max().item()
-    assert err < 5e-2 * rng, "logits err %.3e vs range %.3e" % (err, rng)
-    idx = rl.argmax(1)
-    for b in range(2):   # the oracle's arg-max pixel is (within tolerance) the bf16 maximum
-        assert lg[b].max().item() - lg[b, idx[b]].item() < 5e-2 * rng
+    assert err < 1e-2 * rng, "logits err %.3e vs range %.3e (measured: ~4e-3 with the default fp32 tail)" % (err, rng)
+    # north_star: heat-map arg-max identical to the reference — with the fp32 tail (set_precision default) the bf16 path
+    # picks the oracle's pixel on these cases (rate over 64 seeded pairs: test_bf16_argmax_match_rate)
+    assert torch.equal(lg.argmax(1), rl.argmax(1)), "bf16 arg-max pixel differs from the fp32 oracle's"
     for a, bb in zip(out[3:], ref[3:]):
         assert (a.cpu() - bb).abs().max().item() < 2e-2
     assert abs(out[1].sum().item() - 2.0) < 1e-3
+    # the orientation at the arg-max pixel (what the evaluation reads, train_VIGOR.py:310-324) within bf16 resolution
+    for b in range(2):
+        i = int(rl[b].argmax())
+        o_got, o_ref = out[2][b].reshape(2, -1)[:, i].cpu(), ref[2][b].reshape(2, -1)[:, i]
+        assert (o_got - o_ref).abs().max().item() < 3e-2
     # fp32 precision is restored by switching back (packed weights are re-derived)
     net.set_precision("fp32")
     out32 = net(grd.cuda(), sat.cuda())
     assert ((out32[0].cpu() - rl).abs().max() / rl.abs().max()).item() < 1e-3
+
+
+def test_bf16_argmax_match_rate(synth_sd):
+    """Arg-max pixel of the bf16 storage path (default fp32 tail) against the fp32 HIP path — itself arg-max exact against
+    the reference's goldens (tests/test_forward_gpu.py) — over 64 seeded pairs of CVM_VIGOR (N_rot = 20).  Measured 64/64
+    with the tail, 63/64 without; the bar leaves room for ONE near-tie (fp32 margins go down to 1.5e-3 of the logit range
+    while the bf16 logit error is ~4e-3 of it)."""
+    from ccvpe_amd import models
+    net = models.CVM_VIGOR("cuda", True)
+    net.load_state_dict(synth_sd("vigor", 0), strict=True)
+    net = net.to("cuda:0").eval()
+    same_tail = same_pure = total = 0
+    worst = 0.0
+    for c0 in range(0, 64, 16):
+        grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0)
+        grd, sat = grd.cuda(), sat.cuda()
+        ref = net.set_precision("fp32")(grd, sat)[0]
+        got = net.set_precision("bf16")(grd, sat)[0]
+        pure = net.set_precision("bf16", fp32_tail_levels=0)(grd, sat)[0]
+        rng = ref.max(1)[0] - ref.min(1)[0]
+        worst = max(worst, float(((got - ref).abs().max(1)[0] / rng).max()))
+        same_tail += int((got.argmax(1) == ref.argmax(1)).sum())
+        same_pure += int((pure.argmax(1) == ref.argmax(1)).sum())
+        total += 16
+    print("bf16 arg-max match rate: %d/%d with the fp32 tail, %d/%d pure bf16; worst logit error %.2e of the range"
+          % (same_tail, total, same_pure, total, worst))
+    assert same_tail >= total - 1 and same_pure >= total - 3
+    assert worst < 1e-2

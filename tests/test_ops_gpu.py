@@ -65,6 +65,26 @@ def test_igemm_1x1_all_tile_configs(ops, cin, cout):
     close(nchw(got), want, 1e-4, "1x1 %d->%d" % (cin, cout))
 
 
+@pytest.mark.parametrize("cin,cout,ldd", [(112, 126, 128), (1280, 126, 128), (200, 36, 40), (16, 24, 24)])
+def test_pointwise_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd):
+    """pw_gemm_kernel: several M tiles + M tail, K not a multiple of the 256-byte stage, N not a multiple of 16 written
+    into wider rows (the fused ground-descriptor conv: N = 126, ldd = 128), residual rows read with 16-byte loads."""
+    b, h, w = 3, 19, 23                                  # M = 1311
+    x = synth.normal((b, cin, h, w), 410 + cin)
+    wt = synth.normal((cout, cin, 1, 1), 420 + cout, (1.0 / cin) ** 0.5)
+    sh = synth.normal((cout,), 430, 0.1)
+    res = synth.normal((b, cout, h, w), 431)
+    resp = torch.zeros((b, h, w, ldd))
+    resp[..., :cout] = nhwc(res)
+    want = torch.relu(F.conv2d(x, wt) + sh.view(1, -1, 1, 1)) + res
+    dst = torch.full((b, h, w, ldd), -7.0, device="cuda")
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, batch=b, in_h=h, in_w=w, shift=dev(sh),
+                         act=ops.ACT_RELU, residual=dev(resp), dst=dst, ldd=ldd)
+    close(nchw(got[..., :cout]), want, 1e-4, "pw ragged %d->%d" % (cin, cout))
+    if ldd > cout:
+        assert float((got[..., cout:] + 7.0).abs().max()) == 0.0, "columns beyond N were written"
+
+
 def test_igemm_gate_and_residual(ops):
     b, h, w, cin, cout = 3, 7, 10, 96, 24
     x = synth.normal((b, cin, h, w), 1)

@@ -15,12 +15,14 @@ from collections import defaultdict
 
 def family(name):
     """rocprof kernel name -> the name bench.py's launch recorder uses."""
-    m = re.search(r"(igemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)[,>]", name)
+    m = re.search(r"(igemm_kernel|pw_gemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)[,>]", name)
     if m:
         k, t, a, b, c = m.groups()
         if t == "float":
             if k == "igemm_kernel":
                 return "igemm_f32_kernel<%s,%s,%s>" % (a, b, c)
+            if k == "pw_gemm_kernel":
+                return "pw_gemm_f32_kernel<%s,%s,%s>" % (a, b, c)
             if k == "conv3x3_kernel":
                 return "conv3x3_f32_kernel<%s,%s,%s>" % (a, b, c)
             return "%s<f32,%s,%s,%s>" % (k, a, b, c)
