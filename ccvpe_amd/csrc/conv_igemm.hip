@@ -35,6 +35,7 @@
 // (v_cvt_pk_bf16_f32); scale/shift/gate and all accumulation stay fp32.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace ccvpe {
 
@@ -105,6 +106,7 @@ struct IgemmParams {
   // partial[y][M][Npad]; splitk_finish_kernel adds the slices in order and applies the epilogue.
   int ksplit, sps;
   float* partial;
+  int ablate;        // diagnostics only (CCVPE_PW_ABLATE): 1 = no global stores, 2 = no global loads, 4 = no MFMAs
 };
 
 constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad)
@@ -119,14 +121,17 @@ __device__ __forceinline__ int xcd_tile(int bid, int total) {
 }
 
 // Epilogue for one accumulator: 4 consecutive channels n..n+3 of one pixel.
-template <typename T>
+// ACT is a TEMPLATE parameter: the callers switch on p.act ONCE around their whole epilogue (CCVPE_ACT_DISPATCH).  With a
+// runtime `if (p.act == ...)` here the compiler emitted a scalar compare + branch per VALUE (113-163 per kernel): ~8 000
+// cycles per tile — nothing next to a K = 12 096 3x3 tile, a third of a bf16 tile's life.
+template <typename T, int ACT>
 __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, size_t obase, size_t rbase,
                                        const float* sc, const float* sh) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     float t = v[r] * sc[r] + sh[r];
-    if (p.act == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
-    else if (p.act == CCVPE_ACT_SWISH) t = swishf(t);
+    if (ACT == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
+    else if (ACT == CCVPE_ACT_SWISH) t = swishf(t);
     v[r] = t;
   }
   const T* res = reinterpret_cast<const T*>(p.residual);
@@ -160,6 +165,14 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
       }
   }
 }
+
+// run `body(std::integral_constant<int, ACT>)` for the (workgroup-uniform) activation code `act`
+#define CCVPE_ACT_DISPATCH(act, body)                                            \
+  do {                                                                           \
+    if ((act) == CCVPE_ACT_SWISH) body(std::integral_constant<int, CCVPE_ACT_SWISH>{});      \
+    else if ((act) == CCVPE_ACT_RELU) body(std::integral_constant<int, CCVPE_ACT_RELU>{});   \
+    else body(std::integral_constant<int, CCVPE_ACT_NONE>{});                    \
+  } while (0)
 
 template <typename T, int MT, int NT, int WN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
@@ -343,6 +356,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       sc[j][q] = (ok && p.scale) ? p.scale[n] : 1.0f;
       sh[j][q] = (ok && p.shift) ? p.shift[n] : 0.0f;
     }
+  auto epilogue = [&](auto act_tag) {
+  constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + (wm * MT + i) * 16 + epix;
@@ -368,9 +383,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int co = n - quad * p.cout;
         obase = pbase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
       }
-      store4<T>(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
+      store4<T, ACT>(p, acc[i][j], n, obase, (size_t)m * p.ldres, sc[j], sh[j]);
     }
   }
+  };
+  CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -397,18 +414,20 @@ struct PwGeom {
   static constexpr int BM = 16 * MT * WM;
   static constexpr int BN = 16 * NT * WN;
   static constexpr int LDS_BUDGET = 80 * 1024;                                   // 2 workgroups per CU
-  // 64-byte pieces per staged row: 4 when the stage fits the LDS budget — except the 20-accumulator fp32 tile, whose
-  // staging registers (18 x 16 bytes per thread at KP = 4) would spill past the 256-VGPR cap of 2 waves per SIMD
-  static constexpr int KP = ((BM + BN) * (64 * 4 + 16) <= LDS_BUDGET && !(sizeof(T) == 4 && MT * NT >= 20)) ? 4 : 2;
+  // 64-byte pieces per staged row.  2 (= 128 bytes of K per row: full cache lines, half the barriers of the generic
+  // kernel): the staging registers of the NEXT tile's first stage stay live across the epilogue (persistent loop), and
+  // with 4 pieces they push the 14-20 accumulator tiles over the 256-VGPR cap of 2 waves per SIMD (spills).
+  static constexpr int KP = 2;
   static constexpr int LDF = 16 * KP + 4;                                        // floats per staged row
   static constexpr int OLD = BN + 4;                                             // floats per epilogue-tile row
   static constexpr int IC = (BM * OLD * 4 <= LDS_BUDGET) ? MT : MT / 2;          // MFMA row tiles per epilogue pass
   static constexpr int STAGE_BYTES = (BM + BN) * LDF * 4;
   static constexpr int OUT_BYTES = WM * IC * 16 * OLD * 4;
-  static constexpr int LDS_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+  static constexpr int TILE_BYTES = STAGE_BYTES > OUT_BYTES ? STAGE_BYTES : OUT_BYTES;
+  static constexpr int LDS_BYTES = TILE_BYTES + 2 * BN * 4;                      // + the tile's scale / shift vectors
 };
 
-template <typename T, int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN, int ACT>
 __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
   using G = PwGeom<T, MT, NT, WN>;
   constexpr int E = ElemTraits<T>::E;
@@ -417,51 +436,75 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
   constexpr int KS = PPR * E;                 // K elements per stage
   constexpr int A_IT = BM * PPR / 256;
   constexpr int B_IT = (BN * PPR + 255) / 256;
+  // next-tile prefetch across the epilogue keeps the staging registers live there: the 20-accumulator tile would spill
+  constexpr bool PREFETCH = MT * NT < 20;
 
   extern __shared__ __attribute__((aligned(16))) float pw_sm[];
   float* As = pw_sm;                          // [BM][LDF]
   float* Bs = pw_sm + BM * LDF;               // [BN][LDF]
   float* Os = pw_sm;                          // epilogue tile [WM*IC*16][OLD] (aliases the dead stage buffers)
+  float* Ss = pw_sm + G::TILE_BYTES / 4;      // [2][BN] scale, shift of the tile's channels (fetched with the first K
+                                              // stage: the epilogue must not start with a chain of dependent global loads)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave / WN;
   const int wn = wave % WN;
-  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
-  const int tm = tile / p.tiles_n;
-  const int tn = tile % p.tiles_n;
-  const int m0 = tm * BM;
-  const int n0 = tn * BN;
   const T* src0 = reinterpret_cast<const T*>(p.src0);
   const T* wp = reinterpret_cast<const T*>(p.w);
   const int hw = p.Ho * p.Wo;
   const int nstages = (p.c0 + KS - 1) / KS;
+  const bool f32out = sizeof(T) == 4 || p.out_f32;
+  const T* res = reinterpret_cast<const T*>(p.residual);
 
   const int prow = tid / PPR;                 // staged row of iteration 0; iteration `it` adds it * (256 / PPR)
   const int pc = tid % PPR;                   // 16-byte piece inside the staged row
+  const int frow = lane & 15;
+  const int fk = (lane >> 4) * 4;
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  float sc_reg = 1.0f, sh_reg = 0.0f;
 
-  auto load_stage = [&](int s) {
+  auto load_ss = [&](int n0) {                // scale / shift of channel n0 + tid (threads < BN)
+    const int n = n0 + tid;
+    const bool ok = tid < BN && n < p.N;
+    sc_reg = (ok && p.scale) ? p.scale[n] : 1.0f;
+    sh_reg = (ok && p.shift) ? p.shift[n] : 0.0f;
+  };
+  // BRANCH-FREE staging loads: out-of-range rows / K pieces read a clamped (valid) address and are zeroed by a select, so
+  // the 8-9 loads of a stage issue back to back (a guarded load per iteration compiled to an exec-mask branch around
+  // every load).  The SE gate is a workgroup-uniform switch around the whole loop.
+  auto load_stage_t = [&](int m0, int n0, int s, auto gate_tag) {
+    constexpr bool GATE = decltype(gate_tag)::value;
     const int kcol = s * KS + pc * E;         // first K element of this thread's piece
+    const bool kok = kcol < p.c0;
+    const int kc = kok ? kcol : 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int m = m0 + prow + it * (256 / PPR);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (m < p.M && kcol < p.c0) {
-        v = *reinterpret_cast<const f32x4*>(src0 + (size_t)m * p.ld0 + kcol);
-        if (p.gate != nullptr) v = apply_gate<T>(v, p.gate + (size_t)(m / hw) * p.c0 + kcol);
-      }
-      a_reg[it] = v;
+      const bool ok = kok && m < p.M;
+      const int mc = m < p.M ? m : p.M - 1;
+      f32x4 v = *reinterpret_cast<const f32x4*>(src0 + (size_t)mc * p.ld0 + kc);
+      if (GATE) v = apply_gate<T>(v, p.gate + (size_t)(mc / hw) * p.c0 + kc);
+      a_reg[it] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+    const bool wkok = kcol < p.Kpad;
+    const int wkc = wkok ? kcol : 0;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = prow + it * (256 / PPR);
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nrow < BN && n0 + nrow < p.Npad && kcol < p.Kpad)
-        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + kcol);
-      b_reg[it] = v;
+      const int nr = n0 + nrow;
+      const bool ok = wkok && nrow < BN && nr < p.Npad;
+      const int nc = nr < p.Npad ? nr : p.Npad - 1;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + (size_t)nc * p.Kpad + wkc);
+      b_reg[it] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
+  };
+  auto load_stage = [&](int m0, int n0, int s) {
+    if (p.gate != nullptr) load_stage_t(m0, n0, s, std::true_type{});
+    else load_stage_t(m0, n0, s, std::false_type{});
   };
   auto store_stage = [&]() {
 #pragma unroll
@@ -474,138 +517,169 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
     }
   };
 
-  f32x4 acc[MT][NT];
+  // PERSISTENT workgroups: virtual block v = blockIdx.x + k * gridDim.x (gridDim.x is a multiple of 8, so every virtual
+  // block of a workgroup maps to the same XCD and xcd_tile() keeps giving each XCD a contiguous run of tiles, n fastest).
+  // The first K stage of the NEXT tile is loaded into the staging registers before the epilogue of the current one, so
+  // the HBM latency of a tile's prologue hides behind the previous tile's epilogue.
+  int v = blockIdx.x;
+  if (v >= p.tiles_total) return;
+  int tile = xcd_tile(v, p.tiles_total);
+  int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
+  load_stage(m0, n0, 0);
+  load_ss(n0);
+  while (true) {
+    f32x4 acc[MT][NT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15;
-  const int fk = (lane >> 4) * 4;
-
-  load_stage(0);
-  store_stage();
-  __syncthreads();
-  for (int s = 0; s < nstages; ++s) {
-    const bool more = s + 1 < nstages;
-    if (more) load_stage(s + 1);
+      for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    store_stage();
+    if (tid < BN) {
+      Ss[tid] = sc_reg;
+      Ss[BN + tid] = sh_reg;
+    }
+    __syncthreads();
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < p.tiles_total;
+    int m0n = 0, n0n = 0;
+    if (has_next) {
+      const int tn_ = xcd_tile(vn, p.tiles_total);
+      m0n = (tn_ / p.tiles_n) * BM;
+      n0n = (tn_ % p.tiles_n) * BN;
+    }
+    for (int s = 0; s < nstages; ++s) {
+      const bool more = s + 1 < nstages;
+      if (more) load_stage(m0, n0, s + 1);
+      else if (PREFETCH && has_next) {                   // next tile's first stage: lands during the epilogue below
+        load_stage(m0n, n0n, 0);
+        load_ss(n0n);
+      }
 #pragma unroll
-    for (int kp = 0; kp < KP; ++kp) {
-      f32x4 af[MT], bf[NT];
+      for (int kp = 0; kp < KP; ++kp) {
+        if (s * KS + kp * 4 * E >= p.c0 || (p.ablate & 4)) break;   // K tail: whole 64-byte pieces beyond K are zero (uniform branch)
+        f32x4 af[MT], bf[NT];
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * LDF + kp * 16 + fk]);
+        for (int i = 0; i < MT; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * LDF + kp * 16 + fk]);
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * LDF + kp * 16 + fk]);
-      if (sizeof(T) == 4) {
+        for (int j = 0; j < NT; ++j)
+          bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * LDF + kp * 16 + fk]);
+        if (sizeof(T) == 4) {
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+          for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
+        } else {
 #pragma unroll
           for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][kk], af[i][kk], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
-      }
-    }
-    __syncthreads();                          // every wave is done reading this stage
-    if (more) {
-      store_stage();
-      __syncthreads();
-    }
-  }
-
-  // ---- epilogue: registers -> (scale, shift, act) -> LDS rows -> 16-byte stores along the channel axis ----------
-  const int epix = lane & 15;
-  const int en = (lane >> 4) * 4;
-  const bool f32out = sizeof(T) == 4 || p.out_f32;
-  const T* res = reinterpret_cast<const T*>(p.residual);
-#pragma unroll
-  for (int ic = 0; ic < MT / IC; ++ic) {
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int nl = (wn * NT + j) * 16 + en;             // tile-local channel of acc[.][j][0]
-      float sc[4], sh[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + nl + q;
-        const bool ok = n < p.N;
-        sc[q] = (ok && p.scale) ? p.scale[n] : 1.0f;
-        sh[q] = (ok && p.shift) ? p.shift[n] : 0.0f;
-      }
-#pragma unroll
-      for (int ii = 0; ii < IC; ++ii) {
-        f32x4 v = acc[ic * IC + ii][j];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t = v[q] * sc[q] + sh[q];
-          if (p.act == CCVPE_ACT_RELU) t = fmaxf(t, 0.0f);
-          else if (p.act == CCVPE_ACT_SWISH) t = swishf(t);
-          v[q] = t;
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
         }
-        *reinterpret_cast<f32x4*>(&Os[((wm * IC + ii) * 16 + epix) * OLD + nl]) = v;
+      }
+      __syncthreads();                        // every wave is done reading this stage
+      if (more) {
+        store_stage();
+        __syncthreads();
       }
     }
-    __syncthreads();
-    // each thread: one run of EO consecutive channels of one pixel per iteration (EO * out element size = 16 bytes)
-    const int EO = f32out ? 4 : 8;
-    const int ppo = BN / EO;                              // BN is a multiple of 16
-    const int total = WM * IC * 16 * ppo;
-    for (int idx = tid; idx < total; idx += 256) {
-      const int r = idx / ppo;
-      const int c = (idx - r * ppo) * EO;
-      const int m = m0 + ((r / (IC * 16)) * MT + ic * IC + (r / 16) % IC) * 16 + (r & 15);
-      const int n = n0 + c;
-      if (m >= p.M || n >= p.N) continue;
-      const float* o = &Os[r * OLD + c];
-      f32x4 v0 = *reinterpret_cast<const f32x4*>(o);
-      f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
-      if (!f32out) v1 = *reinterpret_cast<const f32x4*>(o + 4);
-      const size_t obase = (size_t)m * p.ldd + n;
-      const size_t rbase = (size_t)m * p.ldres + n;
-      if (n + EO <= p.N) {
-        if (res) {
-          if (sizeof(T) == 4) {
-            v0 += *reinterpret_cast<const f32x4*>(res + rbase);
-          } else {          // bf16 residual: 8 channels = 16 bytes (4 when the output is fp32)
-            const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(res + rbase);
+
+    // ---- epilogue: registers -> (scale, shift, act) -> LDS rows -> 16-byte stores along the channel axis ----------
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v0[q] += (float)r0[q];
-            if (!f32out) {
-              const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(res + rbase + 4);
+    for (int ic = 0; ic < MT / IC; ++ic) {
+      // (the activation is a template parameter: a per-element `if (p.act == ...)` compiled to a scalar compare + branch
+      // per value — 8 000 cycles per tile for 56 values per lane)
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v1[q] += (float)r1[q];
+      for (int j = 0; j < NT; ++j) {
+        const int nl = (wn * NT + j) * 16 + en;           // tile-local channel of acc[.][j][0]
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&Ss[nl]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&Ss[BN + nl]);
+#pragma unroll
+        for (int ii = 0; ii < IC; ++ii) {
+          f32x4 vv = acc[ic * IC + ii][j] * sc + sh;
+          if (ACT == CCVPE_ACT_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[q] = swishf(vv[q]);
+          }
+          *reinterpret_cast<f32x4*>(&Os[((wm * IC + ii) * 16 + epix) * OLD + nl]) = vv;
+        }
+      }
+      __syncthreads();
+      // store phase without integer divisions: a thread owns one 16-byte column piece and walks down the rows.
+      // Piece columns are padded to a power of two (PCP); row r of the tile <-> pixel via shifts (IC * 16 is a power of 2).
+      auto store_rows = [&](auto eo_tag) {
+        constexpr int EO = decltype(eo_tag)::value;      // output elements per 16 bytes: 4 (fp32) or 8 (bf16)
+        constexpr int PPO = BN / EO;
+        constexpr int PCP = PPO <= 2 ? 2 : PPO <= 4 ? 4 : PPO <= 8 ? 8 : PPO <= 16 ? 16 : PPO <= 32 ? 32 : 64;
+        constexpr int RSTEP = 256 / PCP;
+        const int pcol = tid % PCP;
+        const int c = pcol * EO;
+        const int n = n0 + c;
+        if (pcol < PPO && n < p.N && !(p.ablate & 1)) {
+          const bool full = n + EO <= p.N;
+#pragma unroll 2
+          for (int r = tid / PCP; r < WM * IC * 16; r += RSTEP) {
+            const int m = m0 + ((r / (IC * 16)) * MT + ic * IC) * 16 + (r % (IC * 16));
+            if (m >= p.M) continue;
+            const float* o = &Os[r * OLD + c];
+            f32x4 v0 = *reinterpret_cast<const f32x4*>(o);
+            f32x4 v1 = {0.f, 0.f, 0.f, 0.f};
+            if (EO == 8) v1 = *reinterpret_cast<const f32x4*>(o + 4);
+            const size_t obase = (size_t)m * p.ldd + n;
+            const size_t rbase = (size_t)m * p.ldres + n;
+            if (full) {
+              if (res) {
+                if (sizeof(T) == 4) {
+                  v0 += *reinterpret_cast<const f32x4*>(res + rbase);
+                } else {          // bf16 residual: 8 channels = 16 bytes (4 when the output is fp32)
+                  const bf16x4 r0 = *reinterpret_cast<const bf16x4*>(res + rbase);
+#pragma unroll
+                  for (int q = 0; q < 4; ++q) v0[q] += (float)r0[q];
+                  if (EO == 8) {
+                    const bf16x4 r1 = *reinterpret_cast<const bf16x4*>(res + rbase + 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v1[q] += (float)r1[q];
+                  }
+                }
+              }
+              if (EO == 4) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + obase) = v0;
+              } else {
+                bf16x8 ov;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { ov[q] = (bf16_t)v0[q]; ov[q + 4] = (bf16_t)v1[q]; }
+                *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.dst) + obase) = ov;
+              }
+            } else {              // ragged N tail: element by element
+              for (int q = 0; q < EO && n + q < p.N; ++q) {
+                float t = q < 4 ? v0[q] : v1[q - 4];
+                if (res) t += (float)res[rbase + q];
+                if (EO == 4) reinterpret_cast<float*>(p.dst)[obase + q] = t;
+                else reinterpret_cast<bf16_t*>(p.dst)[obase + q] = (bf16_t)t;
+              }
             }
           }
         }
-        if (f32out) {
-          *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + obase) = v0;
-        } else {
-          bf16x8 ov;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { ov[q] = (bf16_t)v0[q]; ov[q + 4] = (bf16_t)v1[q]; }
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.dst) + obase) = ov;
-        }
-      } else {              // ragged N tail: element by element
-        for (int q = 0; q < EO && n + q < p.N; ++q) {
-          float t = q < 4 ? v0[q] : v1[q - 4];
-          if (res) t += (float)res[rbase + q];
-          if (f32out) reinterpret_cast<float*>(p.dst)[obase + q] = t;
-          else reinterpret_cast<bf16_t*>(p.dst)[obase + q] = (bf16_t)t;
-        }
-      }
+      };
+      if (f32out) store_rows(std::integral_constant<int, 4>{});
+      else store_rows(std::integral_constant<int, 8>{});
+      __syncthreads();                        // the tile rows are dead: next epilogue pass / next tile's stage may overwrite
     }
-    if (ic + 1 < MT / IC) __syncthreads();
+    if (!has_next) break;
+    v = vn;
+    m0 = m0n;
+    n0 = n0n;
+    if (!PREFETCH) {
+      load_stage(m0, n0, 0);
+      load_ss(n0);
+    }
   }
 }
 
-template <typename T, int MT, int NT, int WN>
-static int launch_pw(const IgemmParams& p0, hipStream_t stream) {
+template <typename T, int MT, int NT, int WN, int ACT>
+static int launch_pw_act(const IgemmParams& p0, hipStream_t stream) {
   using G = PwGeom<T, MT, NT, WN>;
   IgemmParams p = p0;
   const int tiles_m = (p.M + G::BM - 1) / G::BM;
@@ -614,15 +688,26 @@ static int launch_pw(const IgemmParams& p0, hipStream_t stream) {
   p.ksplit = 1;
   p.sps = p.stages;
   p.partial = nullptr;
+  static const int ablate = getenv("CCVPE_PW_ABLATE") ? atoi(getenv("CCVPE_PW_ABLATE")) : 0;
+  p.ablate = ablate;
   static bool attr_set = false;               // one flag per instantiation
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)pw_gemm_kernel<T, MT, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    hipError_t e = hipFuncSetAttribute((const void*)pw_gemm_kernel<T, MT, NT, WN, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        G::LDS_BYTES);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "pw_gemm: set smem attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL((pw_gemm_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
+  // persistent grid: 2 workgroups per CU (LDS / VGPR budget of the kernel), a multiple of 8 so that the virtual-block ->
+  // XCD map is stable over a workgroup's iterations
+  int grid = p.tiles_total < 512 ? (p.tiles_total + 7) / 8 * 8 : 512;
+  hipLaunchKernelGGL((pw_gemm_kernel<T, MT, NT, WN, ACT>), dim3(grid), dim3(256), G::LDS_BYTES, stream, p);
   return check_launch("pw_gemm_kernel");
+}
+
+template <typename T, int MT, int NT, int WN>
+static int launch_pw(const IgemmParams& p, hipStream_t stream) {
+  if (p.act == CCVPE_ACT_SWISH) return launch_pw_act<T, MT, NT, WN, CCVPE_ACT_SWISH>(p, stream);
+  return launch_pw_act<T, MT, NT, WN, CCVPE_ACT_NONE>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -819,6 +904,8 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   const int epix = lane & 15;
   const int en = (lane >> 4) * 4;
   const int ox = x0 + epix;
+  auto epilogue = [&](auto act_tag) {
+  constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int n = n0 + (wn * NT + j) * 16 + en;
@@ -835,9 +922,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
       const int oy = y0 + wm * MT + i;
       if (oy >= p.H || ox >= p.W) continue;
       const size_t m = (size_t)(b * p.H + oy) * p.W + ox;
-      store4<T>(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc, sh);
+      store4<T, ACT>(p, acc[i][j], n, m * p.ldd + n, m * p.ldres, sc, sh);
     }
   }
+  };
+  CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
 // split-K second pass: thread = (pixel m, 4 channels); adds the K slices in index order (deterministic) and applies
@@ -873,7 +962,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const IgemmParams p)
     const int co = n - quad * p.cout;
     obase = pbase + ((size_t)(quad >> 1) * (2 * p.Wo) + (quad & 1)) * p.ldd + co;
   }
-  store4<T>(p, v, n, obase, (size_t)m * p.ldres, sc, sh);
+  auto fin = [&](auto act_tag) { store4<T, decltype(act_tag)::value>(p, v, n, obase, (size_t)m * p.ldres, sc, sh); };
+  CCVPE_ACT_DISPATCH(p.act, fin);
 }
 
 // K slices for a GEMM with `tiles` workgroups and `stages` K stages (1 = no split): only when the launch cannot fill
@@ -1136,6 +1226,8 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
   IgemmParams ep;   // reuse store4 (needs N, act, residual, dst, out_f32)
   ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  auto epilogue = [&](auto act_tag) {
+  constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int m = m0 + (wm * MT + i) * 16 + epix;
@@ -1156,9 +1248,11 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
       float sh[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh[q] = (n + q < p.N) ? shp[n + q] : 0.f;
-      store4<T>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
+      store4<T, ACT>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
     }
   }
+  };
+  CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1400,6 +1494,8 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
   const int x1 = x0 + epix;
+  auto epilogue = [&](auto act_tag) {
+  constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int y1 = y0 + wm * MT + i;
@@ -1416,9 +1512,11 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
       float sh[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) sh[q] = (n + q < p.N) ? shp[n + q] : 0.f;
-      store4<T>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
+      store4<T, ACT>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
     }
   }
+  };
+  CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
 template <typename T, int MT, int NT, int WN>
@@ -1522,14 +1620,20 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   // it touches with 16-byte accesses must be 16-byte aligned along the channel axis
   const int esz = (int)sizeof(T);
   const bool out32 = esz == 4 || out_f32;
-  const bool is_pw = g_use_pw && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 &&
+  const bool is_pw = g_use_pw && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->act != CCVPE_ACT_RELU &&
+                     d->n > 48 &&      // narrow outputs (N <= 48: 16-48 column tiles) stay with the generic kernel
+                    
                      d->out_mode == CCVPE_OUT_NHWC && (d->ldd * (out32 ? 4 : 2)) % 16 == 0 &&
                      (!d->residual || (d->ldres * esz) % 16 == 0);
+  // the 256 x 80 tile needs more than 256 VGPRs in the persistent pointwise kernel (staging registers live across the
+  // epilogue): N = 65..80 pointwise layers take the 128 x 96 tile there
+  if (is_pw && !sk && c.mt == 4 && c.nt == 5 && c.wn == 1) return launch_pw<T, 4, 3, 2>(p, st);
 #define CCVPE_CASE(MT_, NT_, WN_)                                                  \
   if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) {                                 \
     if (sk) return launch<T, MT_, NT_, WN_>(p, st, scratch, want_floats);          \
     if (is3x3) return launch3x3<T, MT_, NT_, WN_>(p, d->batch, st);                \
-    if (is_pw) return launch_pw<T, MT_, NT_, WN_>(p, st);                          \
+    if constexpr (16 * NT_ * WN_ > 48 && !(MT_ == 4 && NT_ == 5 && WN_ == 1))     \
+      if (is_pw) return launch_pw<T, MT_, NT_, WN_>(p, st);                        \
     return launch<T, MT_, NT_, WN_>(p, st);                                        \
   }
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)

@@ -182,37 +182,54 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 
 // ---------------------------------------------------------------------------------------------
 // Depthwise conv for SMALL planes (H*W <= 1024: MBConv blocks 6-15, 32x32 ... 10x20): one workgroup
-// per (sample, 8-channel chunk) loads the whole input plane into LDS once (fp32), computes every
-// output pixel from LDS and writes ONE squeeze-partial row.  The strip kernel above is latency-bound
-// there (~100 us per launch for a few MB: k dependent global-load rounds per thread, 2k+ tiny
-// workgroups); this one has a single coalesced load phase.
+// per (sample, channel chunk) loads the whole input plane into LDS once, computes every output pixel from
+// LDS and writes ONE squeeze-partial row.  The strip kernel above is latency-bound there (~100 us per
+// launch for a few MB: k dependent global-load rounds per thread, 2k+ tiny workgroups); this one has a
+// single coalesced load phase.
+//   * chunk = 32 bytes of channels per pixel (8 fp32 / 16 bf16): two 16-byte lanes per pixel;
+//   * workgroup order is XCD-aware: consecutive workgroup ids round-robin over the 8 XCDs, so the chunks that
+//     share a pixel's cache lines are given to ONE XCD (a contiguous run of logical blocks per XCD) — with
+//     chunk = blockIdx % nch every 128-byte line was fetched into (and partially written from) 8 different L2s;
+//   * a thread computes 4 adjacent output columns of one row for 4 channels: the (3S+K) input vectors of a kernel
+//     row are read from LDS once for the 4 outputs (3x fewer LDS reads than one output per thread);
+//   * the plane is kept in LDS in the storage type (bf16 stays bf16: 32 KB for 1024 pixels either way).
 // ---------------------------------------------------------------------------------------------
-constexpr int DWP_CH = 8;
+template <typename T> struct DwpGeom { static constexpr int CH = 32 / (int)sizeof(T); };   // channels per chunk
 
 template <typename T, int K, int S, bool RAW>
 __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ scale,
                                                            const float* __restrict__ shift, T* __restrict__ y,
                                                            float* __restrict__ se_partial, int H, int W, int C, int Ho,
-                                                           int Wo, int circular) {
+                                                           int Wo, int circular, int total_blocks) {
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int CH = DwpGeom<T>::CH;          // 8 (fp32) or 16 (bf16) channels = 32 bytes per pixel
+  constexpr int CG = CH / 4;                  // 4-channel groups per chunk
+  constexpr int NCOL = 3 * S + K;             // input columns feeding 4 adjacent outputs
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* plane = sm;                          // [H*W][8]
-  float* wl = plane + (size_t)H * W * DWP_CH; // [K*K][8]
-  float* red = wl + K * K * DWP_CH;           // [256][4]
+  T* plane = reinterpret_cast<T*>(sm);                                   // [H*W][CH] storage type
+  float* wl = sm + (size_t)H * W * 8;                                    // [K*K][CH] (32 bytes per pixel = 8 floats)
+  float* red = wl + K * K * CH;                                          // [256][4]
   const int tid = threadIdx.x;
-  const int nch = C / DWP_CH;
-  const int chunk = blockIdx.x % nch;
-  const int b = blockIdx.x / nch;
-  const int c0 = chunk * DWP_CH;
-  const T* xb = x + (size_t)b * H * W * C + c0;
-  for (int i = tid; i < H * W * 2; i += 256) {
-    const int px = i >> 1, q = i & 1;
-    *reinterpret_cast<f32x4*>(plane + px * DWP_CH + q * 4) = ld4<T>(xb + (size_t)px * C + q * 4);
+  const int nch = C / CH;
+  int lb;
+  {
+    const int q = total_blocks / 8, r = total_blocks % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
-  for (int i = tid; i < K * K * DWP_CH; i += 256) wl[i] = w[(size_t)(i / DWP_CH) * C + c0 + (i % DWP_CH)];
+  const int chunk = lb % nch;
+  const int b = lb / nch;
+  const int c0 = chunk * CH;
+  const T* xb = x + (size_t)b * H * W * C + c0;
+  for (int i = tid; i < H * W * 2; i += 256) {                           // 2 x 16 bytes per pixel
+    const int px = i >> 1, q = i & 1;
+    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(plane) + (size_t)px * 32 + q * 16) =
+        *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb + (size_t)px * C) + q * 16);
+  }
+  for (int i = tid; i < K * K * CH; i += 256) wl[i] = w[(size_t)(i / CH) * C + c0 + (i % CH)];
   __syncthreads();
-  const int cg = tid & 1;
+  const int cg = tid % CG;
   f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
   if (!RAW) {
     sc = *reinterpret_cast<const f32x4*>(scale + c0 + cg * 4);
@@ -220,46 +237,68 @@ __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__
   }
   T* yb = y + (size_t)b * Ho * Wo * C + c0 + cg * 4;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-  for (int o = tid >> 1; o < Ho * Wo; o += 128) {
-    const int oy = o / Wo, ox = o - oy * Wo;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int xg = (Wo + 3) >> 2;                                          // 4-column groups per output row
+  for (int it = tid / CG; it < Ho * xg; it += 256 / CG) {
+    const int oy = it / xg, ox0 = (it - oy * xg) * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S - PB + ky;
       if ((unsigned)iy >= (unsigned)H) continue;
+      f32x4 col[NCOL];
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        int ix = ox * S - PB + kx;
+      for (int j = 0; j < NCOL; ++j) {
+        int ix = ox0 * S - PB + j;
         if (circular) {
           if (ix < 0) ix += W;
           else if (ix >= W) ix -= W;
         }
-        if ((unsigned)ix < (unsigned)W) {
-          const f32x4 v = *reinterpret_cast<const f32x4*>(plane + (iy * W + ix) * DWP_CH + cg * 4);
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * DWP_CH + cg * 4);
-          acc += v * wv;
-        }
+        col[j] = ((unsigned)ix < (unsigned)W) ? ld4<T>(plane + (size_t)(iy * W + ix) * CH + cg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * CH + cg * 4);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] += col[t * S + kx] * wv;
       }
     }
-    f32x4 v = acc * sc + sh;
-    if (!RAW) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+    for (int t = 0; t < 4; ++t) {
+      if (ox0 + t >= Wo) continue;
+      f32x4 v = acc[t] * sc + sh;
+      if (!RAW) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
+      }
+      st4<T>(yb + (size_t)(oy * Wo + ox0 + t) * C, v);
+      sum += v;
     }
-    st4<T>(yb + (size_t)o * C, v);
-    sum += v;
   }
   if (RAW) return;
   *reinterpret_cast<f32x4*>(red + tid * 4) = sum;
   __syncthreads();
-  if (tid < 2) {                               // fixed-order reduction over the 128 pixel lanes
+  // fixed-order reduction over the 256 / CG item lanes of each channel group: 16 partial sums, then one
+  constexpr int LN = 256 / CG;                // threads per channel group (tid = lane * CG + cg)
+  const bool lvl1 = tid < 16 * CG;            // (barriers stay outside the branches: 16 * CG can split a wave)
+  f32x4 t1 = {0.f, 0.f, 0.f, 0.f};
+  if (lvl1) {
+    const int g = tid % CG, part = tid / CG;  // part 0..15 sums lanes part, part+16, ...
+    for (int i = part; i < LN; i += 16) t1 += *reinterpret_cast<const f32x4*>(red + (i * CG + g) * 4);
+  }
+  __syncthreads();
+  if (lvl1) *reinterpret_cast<f32x4*>(red + tid * 4) = t1;
+  __syncthreads();
+  if (tid < CG) {
     f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    for (int i = 0; i < 128; ++i) t += *reinterpret_cast<const f32x4*>(red + (i * 2 + tid) * 4);
+    for (int i = 0; i < 16; ++i) t += *reinterpret_cast<const f32x4*>(red + (i * CG + tid) * 4);
     *reinterpret_cast<f32x4*>(se_partial + (size_t)b * C + c0 + tid * 4) = t;
   }
 }
 
-static bool dw_use_plane(int H, int W, int C) { return H * W <= 1024 && C % DWP_CH == 0; }
+// one rule for both storage types (the SE-partial row count ccvpe_dwconv_nblk reports must not depend on the dtype)
+static bool dw_use_plane(int H, int W, int C) { return H * W <= 1024 && C % 16 == 0; }
 
 static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* ychunks, int* nblk, int* Ho, int* Wo,
                         int k, int* RB) {
@@ -410,11 +449,13 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k, &RB);
   if (circular && (k / 2 + 1 > W)) return fail(CCVPE_EINVAL, "dwconv: W too small for circular wrap");
   if (dw_use_plane(H, W, C)) {
-    const size_t psm = ((size_t)H * W * DWP_CH + (size_t)k * k * DWP_CH + 1024) * sizeof(float);
-    dim3 pgrid((unsigned)((C / DWP_CH) * B));
+    constexpr int CH = DwpGeom<T>::CH;
+    const size_t psm = ((size_t)H * W * 8 + (size_t)k * k * CH + 1024) * sizeof(float);
+    const int pblocks = (C / CH) * B;
+    dim3 pgrid((unsigned)pblocks);
     hipStream_t pst = (hipStream_t)stream;
 #define DWP_LAUNCH(K_, S_) \
-  hipLaunchKernelGGL((dwconv_plane_kernel<T, K_, S_, RAW>), pgrid, dim3(256), psm, pst, x, w, scale, shift, y, se_partial, H, W, C, Ho, Wo, circular)
+  hipLaunchKernelGGL((dwconv_plane_kernel<T, K_, S_, RAW>), pgrid, dim3(256), psm, pst, x, w, scale, shift, y, se_partial, H, W, C, Ho, Wo, circular, pblocks)
     if (k == 3 && stride == 1) DWP_LAUNCH(3, 1);
     else if (k == 3 && stride == 2) DWP_LAUNCH(3, 2);
     else if (k == 5 && stride == 1) DWP_LAUNCH(5, 1);

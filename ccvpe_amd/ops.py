@@ -160,8 +160,10 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
                         + (m * n if residual is not None else 0))
         is3x3 = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and out_mode == OUT_NHWC and gate is None)
         name = igemm_tile(n, is3x3)
-        if want <= 0 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and src1 is None and out_mode == OUT_NHWC:
+        if (want <= 0 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and src1 is None and out_mode == OUT_NHWC
+                and act != ACT_RELU and n > 48):
             name = name.replace("igemm_f32_kernel<", "pw_gemm_f32_kernel<")      # mirrors is_pw in conv_igemm_any()
+            name = name.replace("pw_gemm_f32_kernel<4,5,1>", "pw_gemm_f32_kernel<4,3,2>")
         if dt != torch.float32:
             name = name.replace("_f32_kernel<", "_kernel<bf16,")
         rec.end(name, "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
