@@ -39,7 +39,7 @@ constexpr int WG_BP = 32;   // pixels per stage
 // tile with several taps instead of zero columns.
 template <int TN, int TC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
-  constexpr bool SQ = TN >= 64;                       // 2 x 2 waves of (TN/2) x (TC/2); else 4 waves of TN x (TC/4)
+  constexpr bool SQ = TN == 64 || TN == 128;          // 2 x 2 waves of (TN/2) x (TC/2); else 4 waves of TN x (TC/4)
   constexpr int NI = (SQ ? TN / 2 : TN) / 16;         // 16-row MFMA tiles per wave along n
   constexpr int NJ = (SQ ? TC / 2 : TC / 4) / 16;     // 16-col MFMA tiles per wave along columns
   constexpr int YP = (TN + 31) / 32;                  // float4 pieces per thread per stage (dY): columns (tid&7)*4 + 32*q
@@ -52,7 +52,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wn = SQ ? wave >> 1 : 0;
   const int wc = SQ ? wave & 1 : wave;
-  int bid = blockIdx.x;
+  // XCD-aware order: workgroup ids round-robin over the 8 XCDs (private L2s).  All tiles of ONE pixel split re-read the same
+  // dY / X pixel rows (each (row tile, column tile) pair streams both panels), so give each XCD a contiguous run of logical
+  // blocks (tile fastest, then split): with the identity map the 8 column tiles of a split sat on 8 different L2s and
+  // every panel was fetched from HBM / the Infinity Cache 8 times.
+  int bid;
+  {
+    const int total = gridDim.x, q = total / 8, r = total % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
   const int tc = bid % p.tiles_c; bid /= p.tiles_c;
   const int tn = bid % p.tiles_n;
   const int split = bid / p.tiles_n;
@@ -78,42 +87,56 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   }
   f32x4 yr[YP], xr[XP];
 
-  auto load_stage = [&](int m0) {
-    const int m = m0 + prow;
+  // Pixel cursor of this thread's staged row: decoded ONCE (two integer divisions) and then advanced by WG_BP pixels per
+  // stage with compare-and-carry (the per-stage decode was ~80 VALU instructions next to 1 024 cycles of MFMA work).
+  // All loads are BRANCH-FREE: out-of-range pixels / columns read a clamped valid address and are zeroed by a select, so
+  // the 4-8 loads of a stage issue back to back instead of one exec-mask branch each.
+  int cm = m_begin + prow, cb, coy, cox;
+  {
+    const int hw = p.Ho * p.Wo;
+    const int mm = cm < p.M ? cm : 0;
+    cb = mm / hw;
+    const int rem = mm - cb * hw;
+    coy = rem / p.Wo;
+    cox = rem - coy * p.Wo;
+  }
+  const int lastpix = p.M - 1;
+  auto load_stage = [&](int /*m0*/) {
+    const int m = cm;
     const bool ok = m < m_end;
-    int b = 0, oy = 0, ox = 0;
-    if (ok) {
-      const int hw = p.Ho * p.Wo;
-      b = m / hw;
-      const int rem = m - b * hw;
-      oy = rem / p.Wo;
-      ox = rem - oy * p.Wo;
-    }
+    const int mc = m < p.M ? m : lastpix;
 #pragma unroll
     for (int q = 0; q < YP; ++q) {
       const int nl = pc + 32 * q;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (nl < TN) {
         const int n = n0 + nl;
-        if (ok && n < p.N) {
-          if (n + 3 < p.N) v = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.ldy + n);
-          else
-            for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
+        if (n + 3 < p.N) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(p.dy + (size_t)mc * p.ldy + n);
+          v = ok ? t : v;
+        } else if (ok && n < p.N) {
+          for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
         }
       }
       yr[q] = v;
     }
 #pragma unroll
     for (int q = 0; q < XP; ++q) {
-      const int iy = oy * p.stride - p.pad + pky[q], ix = ox * p.stride - p.pad + pkx[q];
-      f32x4 u = {0.f, 0.f, 0.f, 0.f};
-      if (ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-        const size_t pix = (size_t)(b * p.H + iy) * p.W + ix;
-        const int c = pch[q];
-        u = (c < p.c0) ? *reinterpret_cast<const f32x4*>(p.src0 + pix * p.ld0 + c)
-                       : *reinterpret_cast<const f32x4*>(p.src1 + pix * p.ld1 + (c - p.c0));
-      }
-      xr[q] = u;
+      const int iy = coy * p.stride - p.pad + pky[q], ix = cox * p.stride - p.pad + pkx[q];
+      const bool in = ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+      const int cy = in ? iy : 0, cx = in ? ix : 0, bb = in ? cb : 0;
+      const size_t pix = (size_t)(bb * p.H + cy) * p.W + cx;
+      const int c = pok[q] ? pch[q] : 0;
+      const f32x4 t = (c < p.c0) ? *reinterpret_cast<const f32x4*>(p.src0 + pix * p.ld0 + c)
+                                 : *reinterpret_cast<const f32x4*>(p.src1 + pix * p.ld1 + (c - p.c0));
+      xr[q] = in ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // advance the cursor by one stage
+    cm += WG_BP;
+    cox += WG_BP;
+    while (cox >= p.Wo) {
+      cox -= p.Wo;
+      if (++coy == p.Ho) { coy = 0; ++cb; }
     }
   };
   auto store_stage = [&](int buf) {
@@ -124,11 +147,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     for (int q = 0; q < XP; ++q) *reinterpret_cast<f32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = xr[q];
   };
 
+  // Square tiles (TN >= 64) run on v_mfma_f32_32x32x2_f32: a wave owns (TN/2) x (TC/2) as 32 x 32 blocks.  Operand lanes
+  // are (channel = lane & 31, pixel = lane >> 5): the 32 lanes of a half-wave read 32 CONSECUTIVE floats of one staged pixel
+  // row — conflict-free for any row pitch (with 16x16x4 the four pixel groups of a ds_read_b32 collided on the 68-float
+  // pitch: SQ_LDS_BANK_CONFLICT was 40 % of the LDS-active cycles) — and half as many matrix instructions are issued.
+  constexpr bool M32 = SQ;
+  constexpr int NI32 = M32 ? TN / 2 / 32 : 1, NJ32 = M32 ? TC / 2 / 32 : 1;
+  typedef float f32x16 __attribute__((ext_vector_type(16)));
   f32x4 acc[NI][NJ];
+  f32x16 acc32[NI32][NJ32];
+  if constexpr (M32) {
 #pragma unroll
-  for (int i = 0; i < NI; ++i)
+    for (int i = 0; i < NI32; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < NJ32; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   const int fi = lane & 15, fq = lane >> 4;       // fragment: channel-in-tile, pixel-in-group
   const int nstage = (m_end - m_begin + WG_BP - 1) / WG_BP;
@@ -141,25 +181,77 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int buf = s & 1;
     const bool more = s + 1 < nstage;
     if (more) load_stage(m_begin + (s + 1) * WG_BP);
+    if constexpr (M32) {
+      // pixel pairs: group g = pixels 2g, 2g+1 of the stage; fragments of group g+1 are read before the MFMAs of group g
+      const int l31 = lane & 31, lh = lane >> 5;
+      float a[2][NI32], bb[2][NJ32];
+      auto read_pair = [&](int g, float* ad, float* bd) {
+        const float* yrow = &Ys[(buf * WG_BP + g * 2 + lh) * YLD + wn * NI32 * 32 + l31];
+        const float* xrow = &Xs[(buf * WG_BP + g * 2 + lh) * XLD + wc * NJ32 * 32 + l31];
 #pragma unroll
-    for (int g = 0; g < WG_BP / 4; ++g) {
-      float a[NI], bb[NJ];
+        for (int i = 0; i < NI32; ++i) ad[i] = yrow[i * 32];
+#pragma unroll
+        for (int j = 0; j < NJ32; ++j) bd[j] = xrow[j * 32];
+      };
+      read_pair(0, a[0], bb[0]);
+#pragma unroll
+      for (int g = 0; g < WG_BP / 2; ++g) {
+        const int cur = g & 1;
+        if (g + 1 < WG_BP / 2) read_pair(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NI32; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ32; ++j)
+            acc32[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i], bb[cur][j], acc32[i][j], 0, 0, 0);
+      }
+    } else {
+    // fragments of pixel group g+1 are read from LDS BEFORE the MFMAs of group g are issued (two register sets): the
+    // compiler's own schedule read a group, waited lgkmcnt(0), issued its NI*NJ MFMAs and only then read the next group —
+    // with 4 MFMAs per group the LDS latency (~100 cycles) was exposed behind every 128 cycles of matrix work.
+    float a[2][NI], bb[2][NJ];
+    auto read_group = [&](int g, float* ad, float* bd) {
       const float* yrow = &Ys[(buf * WG_BP + g * 4 + fq) * YLD + wn * NI * 16 + fi];
       const float* xrow = &Xs[(buf * WG_BP + g * 4 + fq) * XLD + wc * NJ * 16 + fi];
 #pragma unroll
-      for (int i = 0; i < NI; ++i) a[i] = yrow[i * 16];
+      for (int i = 0; i < NI; ++i) ad[i] = yrow[i * 16];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) bb[j] = xrow[j * 16];
+      for (int j = 0; j < NJ; ++j) bd[j] = xrow[j * 16];
+    };
+    read_group(0, a[0], bb[0]);
+#pragma unroll
+    for (int g = 0; g < WG_BP / 4; ++g) {
+      const int cur = g & 1;
+      if (g + 1 < WG_BP / 4) read_group(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);      // keep the reads of group g+1 ABOVE the MFMAs of group g (see above)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bb[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
+    }
     }
     if (more) store_stage(buf ^ 1);
     __syncthreads();
   }
-  // D: row (n) = (lane>>4)*4 + reg, col = lane&15.  dw layout [n][tap][c] == [n][col]
+  // D (16x16): row (n) = (lane>>4)*4 + reg, col = lane&15; D (32x32): row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31.
+  // dw layout [n][tap][c] == [n][col]
   float* out = p.part + (size_t)split * p.N * ncols;
+  if constexpr (M32) {
+#pragma unroll
+    for (int i = 0; i < NI32; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ32; ++j) {
+        const int col = cc0 + (wc * NJ32 + j) * 32 + (lane & 31);
+        if (col >= ncols) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + (wn * NI32 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (n < p.N) out[(size_t)n * ncols + col] = acc32[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < NI; ++i)
 #pragma unroll
@@ -233,15 +325,27 @@ static int wgrad_splits(int M, int tiles, int taps) {
   return S < 1 ? 1 : S;
 }
 
-static int wgrad_tn(int n) { return n <= 16 ? 16 : (n <= 32 ? 32 : 64); }
-// the 128 x 128 tile pays when both dimensions fill it and enough tiles remain to split the pixels over
-static bool wgrad_big(int n, int ncols) {
-  const int padded = (n + 127) / 128 * 128;
-  return n >= 128 && ncols >= 512 && (padded - n) * 4 <= n;        // at most 25 % of the MFMA rows are padding
+// Row tile: minimise (padded MFMA rows) / (measured relative efficiency of the tile).  N = 40 -> 48 rows, N = 80 / 160 /
+// 320 -> 80 rows (the 64-row tile spent 37.5 % of its matrix work on zero rows there); the 128 x 128 tile (needs >= 512
+// columns to fill) wins whenever its padding stays small (N = 640, 672, 1152, 1280 ...).
+static int wgrad_pick(int n, int ncols) {
+  static const int cand[] = {16, 32, 48, 64, 80, 128};
+  static const double eff[] = {0.45, 0.70, 0.75, 0.80, 0.90, 1.00};      // from tools/wgrad_probe.py, relative to 128 x 128
+  int best = 64;
+  double best_cost = 1e30;
+  for (int i = 0; i < 6; ++i) {
+    const int t = cand[i];
+    if (t == 128 && (n < 128 || ncols < 512)) continue;
+    const double cost = (double)((n + t - 1) / t * t) / eff[i];
+    if (cost < best_cost) { best_cost = cost; best = t; }
+  }
+  return best;
 }
+static int wgrad_tn(int n, int ncols) { const int t = wgrad_pick(n, ncols); return t == 128 ? 64 : t; }
+static bool wgrad_big(int n, int ncols) { return wgrad_pick(n, ncols) == 128; }
 static int wgrad_tile_count(int n, int ncols) {
   if (wgrad_big(n, ncols)) return ((n + 127) / 128) * ((ncols + 127) / 128);
-  const int tn = wgrad_tn(n);
+  const int tn = wgrad_tn(n, ncols);
   return ((n + tn - 1) / tn) * ((ncols + WG_T - 1) / WG_T);
 }
 
@@ -250,7 +354,7 @@ static int wgrad_tile_count(int n, int ncols) {
 extern "C" int ccvpe_conv_wgrad_tile(int n, int ncols) {
   if (n <= 0 || ncols <= 0) return CCVPE_EINVAL;
   if (wgrad_big(n, ncols)) return (128 << 16) | 128;
-  return (wgrad_tn(n) << 16) | WG_T;
+  return (wgrad_tn(n, ncols) << 16) | WG_T;
 }
 
 extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad,
@@ -283,7 +387,7 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   p.M = (int)M;
   const int ctot = c0 + c1;
   const bool big = wgrad_big(n, p.taps * ctot);
-  const int tn = big ? 128 : wgrad_tn(n);
+  const int tn = big ? 128 : wgrad_tn(n, p.taps * ctot);
   const int tcw = big ? 128 : WG_T;
   p.tiles_n = (n + tn - 1) / tn;
   p.tiles_c = (p.taps * ctot + tcw - 1) / tcw;
@@ -302,6 +406,8 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   } else if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else if (tn == 48) hipLaunchKernelGGL((conv_wgrad_kernel<48, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  else if (tn == 80) hipLaunchKernelGGL((conv_wgrad_kernel<80, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   const long n_elem = (long)n * p.taps * ctot;
   launch_sum_parts(scratch, p.S, n_elem, (int)n_elem, dw, st);

@@ -31,7 +31,9 @@ def close(got, want, tol, what):
 @pytest.mark.parametrize("c0,c1,n,k,stride,pad,h,w", [(40, 16, 40, 3, 1, 1, 12, 14), (96, 0, 24, 1, 1, 0, 9, 13),
                                                        (16, 0, 96, 1, 1, 0, 17, 11), (64, 0, 48, 2, 2, 0, 8, 8),
                                                        (320, 112, 320, 3, 1, 1, 6, 6), (16, 0, 16, 3, 1, 1, 33, 20),
-                                                       (1024, 320, 640, 3, 1, 1, 4, 4), (1280, 0, 126, 1, 1, 0, 10, 20)])
+                                                       (1024, 320, 640, 3, 1, 1, 4, 4), (1280, 0, 126, 1, 1, 0, 10, 20),
+                                                       (104, 0, 80, 3, 1, 1, 9, 11), (200, 0, 160, 3, 1, 1, 7, 9),
+                                                       (432, 0, 320, 3, 1, 1, 5, 6), (56, 0, 40, 3, 1, 1, 13, 9)])
 def test_conv_wgrad_and_dgrad_vs_autograd(bw, c0, c1, n, k, stride, pad, h, w):
     b = 3
     x = synth.normal((b, c0 + c1, h, w), 800 + c0).requires_grad_(True)
