@@ -21,7 +21,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .synth import B0_BLOCKS, MODEL_SPECS, state_dict_spec, synthetic_state_dict
+from .synth import B0_BLOCKS, MODEL_SPECS, state_dict_spec
 
 BN_EPS = 1e-3                      # efficientnet_pytorch/utils.py:666
 SKIP_BLOCKS = (15, 10, 4, 2, 0)    # models.py:167-171 (decoder levels 6..2)
@@ -323,22 +323,23 @@ def _double_conv(lv, up, skip, batch, hw):
     return y
 
 
-_INIT_CACHE = {}
-
-
 class _CVMBase(nn.Module):
     kind = "vigor"
 
-    def __init__(self, device, circular_padding, ori_noise=None):
+    def __init__(self, device, circular_padding, ori_noise=None, efficientnet_weights=None):
         super().__init__()
         self.device = device                     # stored, never used (models.py:52)
         self.circular_padding = circular_padding
         self.ori_noise = ori_noise
-        # No network: instead of ImageNet-pretrained EfficientNet weights (utils.py:747) the
-        # parameters start from the deterministic synthetic init; load_state_dict() a checkpoint.
-        if self.kind not in _INIT_CACHE:
-            _INIT_CACHE[self.kind] = synthetic_state_dict(self.kind, 0)
-        _populate(self, self.kind, _INIT_CACHE[self.kind])
+        # Parameters start from the reference's construction-time distributions (torch default Conv2d / ConvTranspose2d /
+        # Linear / BatchNorm initialisation: ccvpe_amd/init.py, models.py:55-148).  The reference then loads ImageNet
+        # EfficientNet-B0 weights from the network (utils.py:747): here that is a LOCAL checkpoint, given as
+        # `efficientnet_weights=` (path or state_dict, lukemelas key names) or through CCVPE_EFFICIENTNET_B0.
+        from . import init as _init
+        _populate(self, self.kind, _init.reference_init_state_dict(self.kind))
+        weights = efficientnet_weights if efficientnet_weights is not None else __import__("os").environ.get("CCVPE_EFFICIENTNET_B0")
+        if weights:
+            _init.load_efficientnet_b0(self, weights)
         self._pack_cache = None
         self._pack_key = None
         self.precision = "fp32"
@@ -565,16 +566,16 @@ class CVM_VIGOR(_CVMBase):
     """models.py:49-343 — training-time VIGOR model, 20 rotation hypotheses at every level."""
     kind = "vigor"
 
-    def __init__(self, device, circular_padding):
-        super().__init__(device, circular_padding, None)
+    def __init__(self, device, circular_padding, efficientnet_weights=None):
+        super().__init__(device, circular_padding, None, efficientnet_weights)
 
 
 class CVM_VIGOR_ori_prior(_CVMBase):
     """models.py:346-652 — test-time VIGOR model with an orientation prior of +-ori_noise deg."""
     kind = "vigor"
 
-    def __init__(self, device, ori_noise, circular_padding=True):
-        super().__init__(device, circular_padding, ori_noise)
+    def __init__(self, device, ori_noise, circular_padding=True, efficientnet_weights=None):
+        super().__init__(device, circular_padding, ori_noise, efficientnet_weights)
 
 
 class CVM_OxfordRobotCar(_CVMBase):
@@ -582,13 +583,13 @@ class CVM_OxfordRobotCar(_CVMBase):
     224 ... 7), zero padding, and a matching window CENTRED in the rolled aerial volume (models.py:1094)."""
     kind = "oxford"
 
-    def __init__(self, device):
-        super().__init__(device, False)
+    def __init__(self, device, efficientnet_weights=None):
+        super().__init__(device, False, None, efficientnet_weights)
 
 
 class CVM_KITTI(_CVMBase):
     """models.py:655-950 — KITTI model: 16 hypotheses, 2048-d aerial descriptor, no circular pad."""
     kind = "kitti"
 
-    def __init__(self, device):
-        super().__init__(device, False, None)
+    def __init__(self, device, efficientnet_weights=None):
+        super().__init__(device, False, None, efficientnet_weights)
