@@ -372,6 +372,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   for (int j0 = wave * 4; j0 < Cs; j0 += 16) {
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     const int j1 = min(j0 + 1, Cs - 1), j2 = min(j0 + 2, Cs - 1), j3 = min(j0 + 3, Cs - 1);
+#pragma unroll 6                             // 24 independent weight loads in flight per pass (C = 1152: 3 round trips, not 18)
     for (int c = lane; c < C; c += 64) {
       const float m = mean[c];
       s0 = fmaf(w1[(size_t)j0 * C + c], m, s0);
@@ -392,8 +393,10 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
   const int c = blockIdx.x * SE_SLICE + (tid & (SE_SLICE - 1));
   const int hsel = tid >> 7;                 // 0 or 1
   float s = 0.f;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 8
     for (int j = hsel; j < Cs; j += 2) s = fmaf(w2[(size_t)j * C + c], z[j], s);
+  }
   red[tid] = s;
   __syncthreads();
   if (hsel == 0 && c < C) gate[(size_t)b * C + c] = sigmoidf(red[tid] + red[tid + SE_SLICE] + b2[c]);

@@ -17,6 +17,7 @@
 //     dwordx4 store, running per-channel sum for the squeeze.
 // Vertical overlap between bands costs (K-S)/(RB*S) extra expand rows.
 #include "common.h"
+#include <type_traits>
 
 namespace ccvpe {
 
@@ -49,8 +50,12 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   constexpr int SK = 4 * E;
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;   // pad before (224-schedule SAME)
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* ring = sm;                                  // [K][W][16]
-  float* wdw = ring + max(K * p.W * 16, 1024);       // [K*K][16] (ring region >= 1024 floats: red aliases it)
+  // ring rows are PADDED by the horizontal halo (PB pixels before, K-1-PB after): the pads hold zeros (zero padding) or
+  // the wrapped pixels (circular padding), so the depthwise taps read ring[ox*S + kx] with NO bounds test — a per-tap
+  // `if (ix < W)` made every tap its own basic block (exec-mask branch, LDS read, s_waitcnt, FMA): ~240 cycles per tap.
+  const int RW = p.W + K - 1;                        // ring row width in pixels
+  float* ring = sm;                                  // [K][RW][16]
+  float* wdw = ring + max(K * RW * 16, 1024);        // [K*K][16] (ring region >= 1024 floats: red aliases it)
   float* red = ring;                                 // [256][4], aliases the ring after the last row
 
   const int tid = threadIdx.x;
@@ -92,32 +97,41 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
   const TE* xb = reinterpret_cast<const TE*>(p.x) + (size_t)b * p.H * p.W * p.Cin;
   const int last_needed = (oy1 - 1) * S - PB + K - 1;
 
-  // Register-resident x fragments of ONE input row for this wave's tiles (<= MBF_MAXT tiles x
-  // <= 3 k-chunks).  The loads of row r+1 are issued right after the MFMAs of row r consumed the
-  // registers, so they are in flight during row r's swish/LDS epilogue and the depthwise phase
-  // (a first version loaded per tile and exposed ~130 HBM latencies per workgroup).
-  f32x4 xv[T][NKK];
-  auto prefetch_row = [&](int iy) {
+  // Register-resident x fragments of D = S input rows for this wave's tiles (<= MBF_MAXT tiles x <= 3 k-chunks each): row r
+  // lives in set (r - r_begin) % D and the loads of row r + D are issued right after the MFMAs of row r consumed that set.
+  // An output row consumes S new input rows: with one set (the first version) the SECOND row of a stride-2 pair was loaded
+  // a few hundred cycles before its use (one exposed L2/HBM round trip per output row: expand was 3 000 cycles per input
+  // row against ~900 of work); with S sets every row's loads are issued one whole depthwise phase ahead.
+  // Loads are branch-free (clamped address, result AND-ed with a lane mask): the compiler turns a guarded load into an
+  // exec-mask branch per load.
+  constexpr int D = S;
+  constexpr int KY_UNROLL = K == 3 ? 3 : 1;
+  f32x4 xv[D][T][NKK];
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  auto prefetch_row = [&](int iy, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
     const bool rowok = (unsigned)iy < (unsigned)p.H && iy <= last_needed;
     const TE* xr = xb + (size_t)(rowok ? iy : 0) * p.W * p.Cin;
 #pragma unroll
     for (int ti = 0; ti < T; ++ti) {
       const int px = (wave + 4 * ti) * 16 + (lane & 15);
+      const int pxc = px < p.W ? px : p.W - 1;
 #pragma unroll
       for (int kk = 0; kk < NKK; ++kk) {
         const int ch = kk * SK + (lane >> 4) * E;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (rowok && kk < nkk && px < p.W && ch < p.Cin) v = *reinterpret_cast<const f32x4*>(xr + (size_t)px * p.Cin + ch);
-        xv[ti][kk] = v;
+        const int m = (rowok && px < p.W && ch < p.Cin) ? -1 : 0;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + (size_t)pxc * p.Cin + (ch < p.Cin ? ch : 0));
+        xv[SET][ti][kk] = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & (i32x4){m, m, m, m});
       }
     }
   };
 
-  auto produce_row = [&](int iy) {
-    float* dst = ring + (size_t)((iy - r_begin) % K) * p.W * 16;
+  auto produce_row_t = [&](int iy, auto set_tag) {
+    constexpr int SET = decltype(set_tag)::value;
+    float* dst = ring + (size_t)((iy - r_begin) % K) * RW * 16 + PB * 16;      // pixel 0 of the row (after the left pad)
     if ((unsigned)iy >= (unsigned)p.H) {
-      for (int i = tid; i < p.W * 4; i += 256) *reinterpret_cast<f32x4*>(dst + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if ((unsigned)(iy + 1) < (unsigned)p.H) prefetch_row(iy + 1);     // top padding row -> first real row
+      for (int i = tid; i < RW * 4; i += 256) *reinterpret_cast<f32x4*>(dst - PB * 16 + i * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      prefetch_row(iy + D, set_tag);                     // keep the pipeline going across padding rows
       return;
     }
     f32x4 acc[T];
@@ -131,15 +145,15 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
             if (sizeof(TE) == 4) {
 #pragma unroll
               for (int r = 0; r < 4; ++r)
-                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xv[ti][kk][r], acc[ti], 0, 0, 0);
+                acc[ti] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xv[SET][ti][kk][r], acc[ti], 0, 0, 0);
             } else {
               acc[ti] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]),
-                                                                __builtin_bit_cast(cc_bf16x8, xv[ti][kk]), acc[ti], 0, 0, 0);
+                                                                __builtin_bit_cast(cc_bf16x8, xv[SET][ti][kk]), acc[ti], 0, 0, 0);
             }
           }
       }
     }
-    prefetch_row(iy + 1);
+    prefetch_row(iy + D, set_tag);
     // D: row = channel 4*(lane>>4)+reg, col = pixel lane&15
 #pragma unroll
     for (int ti = 0; ti < T; ++ti) {
@@ -149,10 +163,26 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = swishf(acc[ti][r] * sc0[r] + sh0[r]);
         *reinterpret_cast<f32x4*>(dst + (size_t)px * 16 + q4) = o;
+        if (p.circular) {                               // wrapped copies into the pads (utils.py:350: F.pad(..., 'circular') on W)
+          if (px < K - 1 - PB) *reinterpret_cast<f32x4*>(dst + (size_t)(px + p.W) * 16 + q4) = o;
+          if (px >= p.W - PB) *reinterpret_cast<f32x4*>(dst + (size_t)(px - p.W) * 16 + q4) = o;
+        }
       }
     }
   };
-  prefetch_row(r_begin);   // no-op (zeros) when r_begin is a padding row; produce_row chains from there
+  auto produce_row = [&](int iy) {
+    if (D == 1 || ((iy - r_begin) & 1) == 0) produce_row_t(iy, std::integral_constant<int, 0>{});
+    else produce_row_t(iy, std::integral_constant<int, D - 1>{});
+  };
+  // the pads of all K ring rows start as zeros (only circular padding ever overwrites them)
+  for (int i = tid; i < (p.circular ? 0 : K * (K - 1) * 4); i += 256) {
+    const int row = i / ((K - 1) * 4), rem = i - row * (K - 1) * 4;
+    const int pp = rem >> 2, q = rem & 3;                           // pad pixel 0..K-2: first PB on the left, rest on the right
+    const int col = pp < PB ? pp : p.W + pp;
+    *reinterpret_cast<f32x4*>(ring + ((size_t)row * RW + col) * 16 + q * 4) = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  prefetch_row(r_begin, std::integral_constant<int, 0>{});   // fill the pipeline (padding rows load nothing)
+  if (D > 1) prefetch_row(r_begin + 1, std::integral_constant<int, D - 1>{});
 
   // depthwise coordinates
   const int cg = tid & 3;
@@ -171,22 +201,17 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbFrontParams p
     __syncthreads();
     for (int ox = pxl; ox < p.Wo; ox += 64) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+      // k = 5: one kernel row (5 taps = 10 LDS reads in flight) at a time — fully unrolled, the branch-free loop lets the
+      // scheduler hoist all 50 reads and the kernel needs 200-256 VGPRs (1-2 waves per SIMD)
+#pragma unroll KY_UNROLL
       for (int ky = 0; ky < K; ++ky) {
         const int iy = oy * S - PB + ky;
-        const float* rrow = ring + (size_t)((iy - r_begin) % K) * p.W * 16 + cg * 4;
+        const float* rrow = ring + (size_t)((iy - r_begin) % K) * RW * 16 + (size_t)(ox * S) * 16 + cg * 4;
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          int ix = ox * S - PB + kx;
-          if (p.circular) {
-            if (ix < 0) ix += p.W;
-            else if (ix >= p.W) ix -= p.W;
-          }
-          if ((unsigned)ix < (unsigned)p.W) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(rrow + (size_t)ix * 16);
-            const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (ky * K + kx) * 16 + cg * 4);
-            acc += v * wv;
-          }
+          const f32x4 v = *reinterpret_cast<const f32x4*>(rrow + kx * 16);
+          const f32x4 wv = *reinterpret_cast<const f32x4*>(wdw + (ky * K + kx) * 16 + cg * 4);
+          acc += v * wv;
         }
       }
       f32x4 o = acc * sc1 + sh1;
@@ -212,7 +237,7 @@ constexpr int MBF_RB = 16;
 
 static bool mbf_supported(int W, int cin, int mid, int k, int sk = 16) {
   return cin % 8 == 0 && cin <= sk * MBF_MAX_KK && mid % 16 == 0 && W >= 1 &&
-         W <= 64 * MBF_MAXT && (size_t)((k * W * 16 > 1024 ? k * W * 16 : 1024) + k * k * 16) * 4 <= 64 * 1024;
+         W <= 64 * MBF_MAXT && (size_t)((k * (W + k - 1) * 16 > 1024 ? k * (W + k - 1) * 16 : 1024) + k * k * 16) * 4 <= 64 * 1024;
 }
 
 }  // namespace ccvpe
@@ -250,7 +275,7 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
   const long total = (long)p.nbands * p.nchunks * B;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "mbconv_front: grid too large");
   p.total_blocks = (int)total;
-  const size_t smem = (size_t)((k * W * 16 > 1024 ? k * W * 16 : 1024) + k * k * 16) * sizeof(float);
+  const size_t smem = (size_t)((k * (W + k - 1) * 16 > 1024 ? k * (W + k - 1) * 16 : 1024) + k * k * 16) * sizeof(float);
   hipStream_t st = (hipStream_t)stream;
   const int tneed = ((W + 15) / 16 + 3) / 4;          // 16-pixel tiles per wave per row
   const int tsel = tneed <= 1 ? 1 : (tneed <= 2 ? 2 : (tneed <= 3 ? 3 : 5));
