@@ -90,6 +90,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
                                                      int ychunks, int total_blocks) {
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;  // pad before (224-schedule SAME)
   constexpr int NCOL = (DW_TW - 1) * S + K;
+  constexpr int KYU_STRIP = K == 3 ? 3 : 1;    // k = 5: one kernel row (8-11 loads) in flight at a time, else 256 VGPRs
   extern __shared__ __attribute__((aligned(16))) float red[];  // [P][cgx] float4
 
   const int tid = threadIdx.x;
@@ -122,23 +123,27 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
 #pragma unroll
     for (int t = 0; t < DW_TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const T* xb = x + (size_t)b * H * W * C + c;
-#pragma unroll
+    // BRANCH-FREE window loads: rows / columns outside the image read a clamped (valid) address and are zeroed by AND-ing
+    // the bits with a lane mask; the circular wrap is two selects.  (`ok ? load : 0` and `if (row outside) continue`
+    // compiled to one exec-mask branch per load / per kernel row: each of the K * NCOL loads of a strip waited for the
+    // previous one — the strip kernel ran at a fifth of the HBM rate on the 256^2 x 32 tensor of block 0.)
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll KYU_STRIP
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S - PB + ky;
-      if ((unsigned)iy >= (unsigned)H) continue;
+      const bool rowok = (unsigned)iy < (unsigned)H;
+      const size_t rbase = (size_t)(rowok ? iy : 0) * W;
       f32x4 col[NCOL];
 #pragma unroll
       for (int j = 0; j < NCOL; ++j) {
         int ix = ox0 * S - PB + j;
-        bool ok = true;
-        if (circular) {
-          if (ix < 0) ix += W;
-          else if (ix >= W) ix -= W;
-          ok = (unsigned)ix < (unsigned)W;
-        } else {
-          ok = (unsigned)ix < (unsigned)W;
-        }
-        col[j] = ok ? ld4<T>(xb + ((size_t)iy * W + ix) * C) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int wrapped = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
+        ix = circular ? wrapped : ix;
+        const bool ok = rowok && (unsigned)ix < (unsigned)W;
+        const int ixc = (unsigned)ix < (unsigned)W ? ix : 0;
+        const int m = ok ? -1 : 0;
+        const f32x4 v = ld4<T>(xb + (rbase + ixc) * C);
+        col[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & (i32x4){m, m, m, m});
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
@@ -206,6 +211,7 @@ __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__
   constexpr int CH = DwpGeom<T>::CH;          // 8 (fp32) or 16 (bf16) channels = 32 bytes per pixel
   constexpr int CG = CH / 4;                  // 4-channel groups per chunk
   constexpr int NCOL = 3 * S + K;             // input columns feeding 4 adjacent outputs
+  constexpr int KYU = K == 3 ? 3 : 1;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   T* plane = reinterpret_cast<T*>(sm);                                   // [H*W][CH] storage type
   float* wl = sm + (size_t)H * W * 8;                                    // [K*K][CH] (32 bytes per pixel = 8 floats)
@@ -243,19 +249,25 @@ __global__ __launch_bounds__(256) void dwconv_plane_kernel(const T* __restrict__
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
+    // branch-free window reads (clamped LDS address + lane mask; see dwconv_kernel): one kernel row at a time for k = 5 so
+    // that the hoisted reads do not blow up the register count
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+#pragma unroll KYU
     for (int ky = 0; ky < K; ++ky) {
       const int iy = oy * S - PB + ky;
-      if ((unsigned)iy >= (unsigned)H) continue;
+      const bool rowok = (unsigned)iy < (unsigned)H;
+      const int rbase = (rowok ? iy : 0) * W;
       f32x4 col[NCOL];
 #pragma unroll
       for (int j = 0; j < NCOL; ++j) {
         int ix = ox0 * S - PB + j;
-        if (circular) {
-          if (ix < 0) ix += W;
-          else if (ix >= W) ix -= W;
-        }
-        col[j] = ((unsigned)ix < (unsigned)W) ? ld4<T>(plane + (size_t)(iy * W + ix) * CH + cg * 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const int wrapped = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
+        ix = circular ? wrapped : ix;
+        const bool ok = rowok && (unsigned)ix < (unsigned)W;
+        const int ixc = (unsigned)ix < (unsigned)W ? ix : 0;
+        const int m = ok ? -1 : 0;
+        const f32x4 v = ld4<T>(plane + (size_t)(rbase + ixc) * CH + cg * 4);
+        col[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & (i32x4){m, m, m, m});
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {

@@ -1,0 +1,13 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out
+cd $R
+timeout 900 python3 -m pytest tests/test_ops_gpu.py tests/test_bf16_gpu.py tests/test_forward_gpu.py tests/test_train_forward_gpu.py tests/test_backward_gpu.py -m gpu -q -x 2>&1 | tail -2
+python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $OUT/f32_c.json 2> $OUT/f32_c.err
+python3 bench.py --precision bf16 --steps 10 --warmup 3 --no-cpu-baseline --no-extra > $OUT/bf16_c.json 2> $OUT/bf16_c.err
+python3 bench.py --train --model vigor20 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/train_c.json 2> $OUT/train_c.err
+python3 -c "
+import json
+for f in ('f32','bf16','train'):
+    d=json.load(open('$OUT/%s_c.json'%f)); print(f,d['value'],d['ms_per_step'])
+"

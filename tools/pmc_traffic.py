@@ -4,7 +4,7 @@ profiles/pmc_traffic.json: kernel family -> HBM bytes per launch.
 Corrections per /opt/skills/guides/MI355X_MICROARCH.md §HBM: counters are in KiB; on gfx950
 FETCH_SIZE reports exactly 1/2 of the bytes of a wide (16 B/lane) coalesced read, which is how
 every kernel here loads, so the read side is doubled.  WRITE_SIZE is taken as is (uncalibrated).
-Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+Usage: python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [commit] [workload]
 """
 import csv
 import json
@@ -48,7 +48,11 @@ def collect(path, counter):
 def main():
     fetch, n1 = collect(sys.argv[1], "FETCH_SIZE")
     write, n2 = collect(sys.argv[2], "WRITE_SIZE")
-    out = {}
+    out = {"#meta": {"commit": sys.argv[4] if len(sys.argv) > 4 else "unknown",
+                     "workload": sys.argv[5] if len(sys.argv) > 5 else "",
+                     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB); FETCH_SIZE x 2 "
+                               "(gfx950 reports half of a 16 B/lane coalesced read, MI355X_MICROARCH.md HBM section), "
+                               "WRITE_SIZE as is (uncalibrated); mean bytes per launch of each kernel family"}}
     for k in sorted(set(fetch) | set(write)):
         rd = 2.0 * fetch.get(k, 0.0) * 1024.0
         wr = write.get(k, 0.0) * 1024.0
