@@ -137,18 +137,19 @@ def cpu_baseline_train(sd, kind="vigor", batch=2, reps=2):
 # ------------------------------------------------------------------------------------------------------
 # roofline from the HIP-event launch records
 # ------------------------------------------------------------------------------------------------------
-def _traffic(name):
-    """PMC HBM bytes per launch of kernel `name` from the committed counter pass, with its provenance."""
+def _traffic(name, workload):
+    """PMC HBM bytes per launch of kernel `name` from the committed counter pass of `workload` ("f32" forward, "bf16"
+    forward or "train"), with its provenance."""
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.isfile(tpath):
         return None, None
     try:
-        d = json.load(open(tpath))
+        d = json.load(open(tpath)).get(workload, {})
     except Exception:
         return None, None
     meta = d.get("#meta", {})
-    src = "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per MI355X_MICROARCH.md; " \
-          "static file taken at commit %s, not re-measured in this run)" % meta.get("commit", "unknown")
+    src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per MI355X_MICROARCH.md; " \
+          "static file taken at commit %s, not re-measured in this run)" % (workload, meta.get("commit", "unknown"))
     return d.get(name), src
 
 
@@ -160,8 +161,9 @@ def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12
     gbs = d["bytes"] / (d["ms"] * 1e-3) / 1e9
-    traffic, tsrc = _traffic(name)
-    if precision == "bf16":
+    traffic, tsrc = _traffic(name, "train" if train else ("f32" if precision == "fp32" else "bf16"))
+    kernel_is_f32 = "f32" in name or name.startswith("conv_wgrad")           # the bf16 path's fp32 tail runs fp32 kernels
+    if precision == "bf16" and not kernel_is_f32:
         # bf16 storage: the whole forward is HBM-governed (18 k pairs/s HBM vs 44 k MFMA); the dominant
         # kernel is priced against BOTH roofs, `bound` names the one its arithmetic intensity puts it under
         ai = d["flops"] / max(d["bytes"], 1.0)
@@ -177,6 +179,8 @@ def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
     else:
         head = {"bound": "mfma", "kernel": name, "achieved": round(tfl, 2), "peak": FP32_MATRIX_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(tfl / FP32_MATRIX_PEAK_TFLOPS, 4)}
+        if precision == "bf16":
+            head["note"] = "fp32 kernel of the bf16 path's fp32 tail (set_precision fp32_tail_levels): priced against the fp32 matrix peak"
     head["traffic"] = traffic
     head["traffic_source"] = tsrc if traffic is not None else None
     roof = dict(head)

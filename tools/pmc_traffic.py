@@ -14,7 +14,12 @@ from collections import defaultdict
 
 
 def family(name):
-    """rocprof kernel name -> the name bench.py's launch recorder uses."""
+    """rocprof kernel name -> the name bench.py's launch recorder uses.  bf16 instantiations arrive MANGLED (the profiler's
+    demangler does not know the __bf16 type code DF16b): _ZN5ccvpe14conv3x3_kernelIDF16bLi4ELi5ELi2ELi4ELb1EEEv..."""
+    m = re.search(r"(igemm_kernel|pw_gemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)IDF16bLi(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:
+        k, a, b, c = m.groups()
+        return "%s<bf16,%s,%s,%s>" % (k, a, b, c)
     m = re.search(r"(igemm_kernel|pw_gemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)<(float|__bf16|bf16), *(\d+), *(\d+), *(\d+)[,>]", name)
     if m:
         k, t, a, b, c = m.groups()
@@ -27,6 +32,12 @@ def family(name):
                 return "conv3x3_f32_kernel<%s,%s,%s>" % (a, b, c)
             return "%s<f32,%s,%s,%s>" % (k, a, b, c)
         return "%s<bf16,%s,%s,%s>" % (k, a, b, c)
+    m = re.search(r"conv_wgrad_kernel<(\d+), *(\d+)>", name)
+    if m:
+        return "conv_wgrad_kernel<%s,%s>" % m.groups()
+    m = re.search(r"_ZN5ccvpe\d+(\w+?_kernel)I", name)
+    if m:
+        return m.group(1)
     m = re.search(r"ccvpe::(\w+?)(<[^>]*>)?\(", name) or re.search(r"ccvpe::(\w+)", name)
     return m.group(1) if m else None
 
