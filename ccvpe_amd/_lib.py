@@ -12,7 +12,8 @@ import subprocess
 import torch  # noqa: F401  (must be imported before the HIP library is mapped)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libccvpe_hip.so")
+# CCVPE_LIB: load another build of the same C ABI (A/B runs of compiler flags); the default is the in-tree library
+LIB_PATH = os.environ.get("CCVPE_LIB") or os.path.join(_HERE, "libccvpe_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 c_float_p = ctypes.c_void_p   # device pointers travel as integers
@@ -95,7 +96,7 @@ PROTOTYPES = {
     "ccvpe_gate_mul_f32": (c_int, [c_void_p] * 3 + [c_int] * 3 + [c_void_p]),
     "ccvpe_softmax_bwd_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_l2norm2_bwd_f32": (c_int, [c_void_p] * 3 + [c_int, c_int, c_void_p]),
-    "ccvpe_head_conv3x3_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 4 + [c_void_p]),
+    "ccvpe_head_conv3x3_bwd_f32": (c_int, [c_void_p] * 7 + [c_int] * 5 + [c_void_p]),
     "ccvpe_ground_descriptor_bwd_f32": (c_int, [c_void_p, c_int, c_void_p, ctypes.POINTER(c_int)] + [c_void_p] * 4 +
                                         [c_int] * 3 + [c_void_p]),
     "ccvpe_add_cols_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -75,12 +75,17 @@ def conv1x1_dgrad(dy, w):
     return ops.conv_igemm(dy, n, _pack_conv(w.permute(1, 0, 2, 3)), c, batch=b, in_h=h, in_w=wd)
 
 
-def conv3x3_dgrad(dy, w):
-    """w [N,C,3,3] (stride 1, pad 1) -> dx [B,H,W,C] (split it along C for a two-source forward)."""
+def conv3x3_dgrad(dy, w, relu_out=None):
+    """w [N,C,3,3] (stride 1, pad 1) -> dx [B,H,W,C] (split it along C for a two-source forward).
+    relu_out [B,H,W,C]: the convolution's input was this ReLU output; return the gradient in FRONT of the ReLU
+    (dx where relu_out > 0, else 0) from the same launch instead of a relu_bwd pass over dx."""
     b, h, wd, n = dy.shape
     c = w.shape[1]
     wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
-    return ops.conv_igemm(dy, n, _pack_conv(wt), c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1)
+    if relu_out is None:
+        return ops.conv_igemm(dy, n, _pack_conv(wt), c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1)
+    return ops.conv_igemm(dy, n, _pack_conv(wt), c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1, residual=relu_out,
+                          act=ops.ACT_RELU_MASK)
 
 
 def deconv_dgrad(dy_hi, w):
@@ -113,8 +118,8 @@ def bn_act_bwd(x, dv, mean, var, gamma, beta, eps, act, gate=None, dmean=None, d
         ops._chk(t, nm)
     b, rps, c = _bc(x)
     dx = torch.empty_like(x)
-    dgamma = torch.empty((c,), device=x.device, dtype=torch.float32)
-    dbeta = torch.empty((c,), device=x.device, dtype=torch.float32)
+    both = torch.empty((2, c), device=x.device, dtype=torch.float32)       # dbeta, dgamma adjacent: one merge launch
+    dbeta, dgamma = both[0], both[1]
     scratch = torch.empty((2 * c * b * lib.ccvpe_bn_bwd_nblk(rps),), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_bn_act_bwd_f32(ops._ptr(x), ops._ptr(dv), ops._ptr(mean), ops._ptr(var), ops._ptr(gamma), ops._ptr(beta),
                                    ops._ptr(gate), ops._ptr(dmean), ops._ptr(dc_scale), float(eps), act, ops._ptr(dx),
@@ -223,8 +228,9 @@ def l2norm2_bwd(raw, dout):
     return out
 
 
-def head_conv3x3_bwd(x, w, dout):
-    """x [B,H,W,16], w [cout,3,3,16] packed, dout [B,cout,H,W] -> (dx, dw [cout,3,3,16], dbias [cout])."""
+def head_conv3x3_bwd(x, w, dout, relu_mask_x=False):
+    """x [B,H,W,16], w [cout,3,3,16] packed, dout [B,cout,H,W] -> (dx, dw [cout,3,3,16], dbias [cout]).
+    relu_mask_x: x is a ReLU output and dx is wanted in front of that ReLU (dx zeroed where x <= 0)."""
     lib = _lib.load()
     for t, nm in ((x, "x"), (w, "w"), (dout, "dout")):
         ops._chk(t, nm)
@@ -235,7 +241,8 @@ def head_conv3x3_bwd(x, w, dout):
     db = torch.empty((cout,), device=x.device, dtype=torch.float32)
     scratch = torch.empty((HEAD_BWD_SCRATCH,), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_head_conv3x3_bwd_f32(ops._ptr(x), ops._ptr(w), ops._ptr(dout), ops._ptr(dx), ops._ptr(dw), ops._ptr(db),
-                                         ops._ptr(scratch), b, h, wd, cout, ops._stream()), "ccvpe_head_conv3x3_bwd_f32")
+                                         ops._ptr(scratch), b, h, wd, cout, int(bool(relu_mask_x)), ops._stream()),
+          "ccvpe_head_conv3x3_bwd_f32")
     return dx, dw, db
 
 

@@ -138,12 +138,19 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
   const bool f32out = sizeof(T) == 4 || p.out_f32;
   if (n + 3 < p.N) {
     if (res) {
+      f32x4 rf;
       if (sizeof(T) == 4) {
-        v += *reinterpret_cast<const f32x4*>(res + rbase + n);
+        rf = *reinterpret_cast<const f32x4*>(res + rbase + n);
       } else {
         const bf16x4 rv = *reinterpret_cast<const bf16x4*>(res + rbase + n);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] += (float)rv[r];
+        for (int r = 0; r < 4; ++r) rf[r] = (float)rv[r];
+      }
+      if (ACT == CCVPE_ACT_RELU_MASK) {   // residual = a ReLU's output: pass the gradient where it was positive
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = rf[r] > 0.f ? v[r] : 0.f;
+      } else {
+        v += rf;
       }
     }
     if (f32out) {
@@ -159,7 +166,10 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
     for (int r = 0; r < 4; ++r)
       if (n + r < p.N) {
         float t = v[r];
-        if (res) t += (float)res[rbase + n + r];
+        if (res) {
+          const float rf = (float)res[rbase + n + r];
+          t = ACT == CCVPE_ACT_RELU_MASK ? (rf > 0.f ? t : 0.f) : t + rf;
+        }
         if (f32out) reinterpret_cast<float*>(p.dst)[obase + r] = t;
         else reinterpret_cast<bf16_t*>(p.dst)[obase + r] = (bf16_t)t;
       }
@@ -171,6 +181,7 @@ __device__ __forceinline__ void store4(const IgemmParams& p, f32x4 v, int n, siz
   do {                                                                           \
     if ((act) == CCVPE_ACT_SWISH) body(std::integral_constant<int, CCVPE_ACT_SWISH>{});      \
     else if ((act) == CCVPE_ACT_RELU) body(std::integral_constant<int, CCVPE_ACT_RELU>{});   \
+    else if ((act) == CCVPE_ACT_RELU_MASK) body(std::integral_constant<int, CCVPE_ACT_RELU_MASK>{}); \
     else body(std::integral_constant<int, CCVPE_ACT_NONE>{});                    \
   } while (0)
 
@@ -1585,6 +1596,8 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     return fail(CCVPE_EINVAL, "conv_igemm: pointers must be 16-byte aligned");
   if (d->gate && (d->kh != 1 || d->c1 != 0)) return fail(CCVPE_EINVAL, "conv_igemm: gate only for 1x1 single-source");
   if (d->stride < 1 || d->kh < 1 || d->kw < 1) return fail(CCVPE_EINVAL, "conv_igemm: bad kernel/stride");
+  if (d->act == CCVPE_ACT_RELU_MASK && (!d->residual || d->out_mode != CCVPE_OUT_NHWC))
+    return fail(CCVPE_EINVAL, "conv_igemm: CCVPE_ACT_RELU_MASK needs the ReLU output in `residual` and an NHWC store");
   IgemmParams p;
   p.src0 = d->src0; p.src1 = d->src1; p.gate = d->gate; p.w = d->w;
   p.scale = d->scale; p.shift = d->shift; p.residual = d->residual; p.dst = d->dst;
@@ -1621,8 +1634,8 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   const int esz = (int)sizeof(T);
   const bool out32 = esz == 4 || out_f32;
   const bool is_pw = g_use_pw && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->c1 == 0 && d->act != CCVPE_ACT_RELU &&
+                     d->act != CCVPE_ACT_RELU_MASK &&
                      d->n > 48 &&      // narrow outputs (N <= 48: 16-48 column tiles) stay with the generic kernel
-                    
                      d->out_mode == CCVPE_OUT_NHWC && (d->ldd * (out32 ? 4 : 2)) % 16 == 0 &&
                      (!d->residual || (d->ldres * esz) % 16 == 0);
   // the 256 x 80 tile needs more than 256 VGPRs in the persistent pointwise kernel (staging registers live across the

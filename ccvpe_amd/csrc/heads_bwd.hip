@@ -62,37 +62,60 @@ __global__ __launch_bounds__(256) void l2norm2_bwd_kernel(const float* __restric
 }
 
 // dx[b,y,x,c] = sum_{o,ky,kx} dr[b,o,y+1-ky,x+1-kx] * w[o][ky][kx][c]
-template <int COUT>
+// Taps outside the image read a clamped address and are multiplied by 0 (no per-tap branch, so the nine loads of
+// a plane issue back to back).  RELU: the convolution's input is a ReLU output, and the gradient is wanted in
+// front of that ReLU: dx = x > 0 ? dx : 0 (what relu_bwd would do in a second pass over the tensor).
+template <int COUT, bool RELU>
 __global__ __launch_bounds__(256) void head_dgrad_kernel(const float* __restrict__ dr, const float* __restrict__ w,
-                                                         float* __restrict__ dx, int B, int H, int W) {
+                                                         const float* __restrict__ xin, float* __restrict__ dx, int B, int H,
+                                                         int W) {
   __shared__ __attribute__((aligned(16))) float ws[COUT * 9 * 16];
   for (int i = threadIdx.x; i < COUT * 9 * 16; i += 256) ws[i] = w[i];
   __syncthreads();
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * H * W) return;
   const int x = (int)(idx % W), y = (int)((idx / W) % H), b = (int)(idx / ((long)W * H));
+  f32x4 keep[4];
+  if constexpr (RELU) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) keep[q] = *reinterpret_cast<const f32x4*>(xin + (size_t)idx * 16 + q * 4);
+  }
   f32x4 acc[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float g[COUT][9];
 #pragma unroll
   for (int o = 0; o < COUT; ++o) {
     const float* plane = dr + ((size_t)b * COUT + o) * H * W;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
       const int yy = y + 1 - ky;
-      if ((unsigned)yy >= (unsigned)H) continue;
+      const bool yok = (unsigned)yy < (unsigned)H;
+      const int yc = yok ? yy : y;
 #pragma unroll
       for (int kx = 0; kx < 3; ++kx) {
         const int xx = x + 1 - kx;
-        if ((unsigned)xx >= (unsigned)W) continue;
-        const float g = plane[(size_t)yy * W + xx];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += g * *reinterpret_cast<const f32x4*>(&ws[((o * 3 + ky) * 3 + kx) * 16 + q * 4]);
+        const bool ok = yok && (unsigned)xx < (unsigned)W;
+        const float v = plane[(size_t)yc * W + (ok ? xx : x)];
+        g[o][ky * 3 + kx] = ok ? v : 0.f;
       }
     }
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(dx + (size_t)idx * 16 + q * 4) = acc[q];
+  for (int o = 0; o < COUT; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) acc[q] += g[o][t] * *reinterpret_cast<const f32x4*>(&ws[(o * 9 + t) * 16 + q * 4]);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    f32x4 v = acc[q];
+    if constexpr (RELU) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = keep[q][e] > 0.f ? v[e] : 0.f;
+    }
+    *reinterpret_cast<f32x4*>(dx + (size_t)idx * 16 + q * 4) = v;
+  }
 }
 
 // dw[o][ky][kx][c] = sum_px dr[b,o,px] * x[px + (ky-1,kx-1)][c] ; db[o] = sum_px dr[b,o,px]
@@ -287,20 +310,27 @@ extern "C" int ccvpe_l2norm2_bwd_f32(const float* raw, const float* dout, float*
 }
 
 extern "C" int ccvpe_head_conv3x3_bwd_f32(const float* x, const float* w, const float* dout, float* dx, float* dw, float* dbias,
-                                          float* scratch, int batch, int h, int wd, int cout, void* stream) {
+                                          float* scratch, int batch, int h, int wd, int cout, int relu_mask_x, void* stream) {
   if (batch <= 0 || h <= 0 || wd <= 0 || (cout != 1 && cout != 2)) return fail(CCVPE_EINVAL, "head_conv_bwd: bad shape");
   if (!aligned16(x) || !aligned16(dx)) return fail(CCVPE_EINVAL, "head_conv_bwd: 16-byte alignment");
   hipStream_t st = (hipStream_t)stream;
   const long npx = (long)batch * h * wd;
   const int ntiles = ((wd + HW_TW - 1) / HW_TW) * ((h + HW_TH - 1) / HW_TH) * batch;
   const int nblk = ntiles < CCVPE_HEAD_WGRAD_BLOCKS ? ntiles : CCVPE_HEAD_WGRAD_BLOCKS;
-  if (cout == 1) {
-    hipLaunchKernelGGL((head_dgrad_kernel<1>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, dout, w, dx, batch, h, wd);
-    hipLaunchKernelGGL((head_wgrad_kernel<1>), dim3(nblk), dim3(256), 0, st, x, dout, scratch, batch, h, wd, ntiles);
-  } else {
-    hipLaunchKernelGGL((head_dgrad_kernel<2>), dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, st, dout, w, dx, batch, h, wd);
-    hipLaunchKernelGGL((head_wgrad_kernel<2>), dim3(nblk), dim3(256), 0, st, x, dout, scratch, batch, h, wd, ntiles);
-  }
+  const dim3 dgrid((unsigned)((npx + 255) / 256));
+#define CCVPE_HEAD_DGRAD(CO)                                                                                          \
+  do {                                                                                                                \
+    if (relu_mask_x)                                                                                                  \
+      hipLaunchKernelGGL((head_dgrad_kernel<CO, true>), dgrid, dim3(256), 0, st, dout, w, x, dx, batch, h, wd);        \
+    else                                                                                                              \
+      hipLaunchKernelGGL((head_dgrad_kernel<CO, false>), dgrid, dim3(256), 0, st, dout, w, x, dx, batch, h, wd);       \
+    hipLaunchKernelGGL((head_wgrad_kernel<CO>), dim3(nblk), dim3(256), 0, st, x, dout, scratch, batch, h, wd, ntiles); \
+  } while (0)
+  if (cout == 1)
+    CCVPE_HEAD_DGRAD(1);
+  else
+    CCVPE_HEAD_DGRAD(2);
+#undef CCVPE_HEAD_DGRAD
   // partials [nblk][cout][145] -> tmp [cout][145] (second half of scratch), then split into dw / dbias
   float* tmp = scratch + (size_t)CCVPE_HEAD_WGRAD_BLOCKS * 2 * 145;
   launch_sum_parts(scratch, nblk, cout * 145, cout * 145, tmp, st);

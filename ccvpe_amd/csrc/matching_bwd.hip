@@ -90,15 +90,15 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+#pragma unroll 1   // the body is NPAD independent LDS reads + FMAs: unrolling the channel walk as well only spills
     for (int cc = 0; cc < ck; ++cc) {
       const float xv = xs[cc * XLD + tid];
       const float x2 = xv * xv;
       tot += x2;
       xd = fmaf(xv, dd[cc * XLD + tid], xd);
-      if (partial) {
+      if (partial) {          // (shifts i >= n_shifts have offset 0 and are never used: no per-shift guard in the loop)
 #pragma unroll
-        for (int i = 0; i < NPAD; ++i)
-          if (i < n_shifts) nrm[i] = fmaf(x2, ww[c0 + cc + mo.off[i]], nrm[i]);
+        for (int i = 0; i < NPAD; ++i) nrm[i] = fmaf(x2, ww[c0 + cc + mo.off[i]], nrm[i]);
       }
     }
     __syncthreads();
@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
       }
     }
   }
+  float bqsum = 0.f;                       // full windows (L == C): sum_i b_i x[c] ww[.] = x[c] * sum_i b_i
 #pragma unroll
-  for (int i = 0; i < NPAD; ++i)
+  for (int i = 0; i < NPAD; ++i) {
+    bqsum += bq[i];
     if (i < n_shifts) as[i * TPB + tid] = a[i];
+  }
   const float xn = sqrtf(tot);
   const float k1 = 1.0f / fmaxf(xn, 1e-12f);
   const float k2 = xn > 1e-12f ? xd * k1 * k1 * k1 : 0.f;
@@ -167,19 +170,37 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
       }
     }
     __syncthreads();
+    // BRANCH-FREE shift loop: a[i] = b[i] = 0 and offset 0 for the padding shifts i >= n_shifts, gg[] is already zero outside
+    // the window, so sum_i a_i gg[c + off_i] needs no test at all and its NPAD LDS broadcast reads are issued together;
+    // the b-term is one FMA with sum_i b_i for full windows and uses the 0/1 window table for partial ones.  (With
+    // `if (i < n_shifts)` / `if (kk < L)` inside, every shift was its own basic block: one exposed LDS round trip per
+    // (channel, shift) — 270 k cycles per 256-pixel workgroup at level 6.)
+#pragma unroll 1   // (left to itself the compiler unrolls this 16x: 256 VGPRs + 2.9 KB of scratch per lane, 5x slower)
     for (int cc = 0; cc < ck; ++cc) {
       const float xv = xs[cc * XLD + tid];
       float acc = pvalid ? dd[cc * XLD + tid] * k1 - xv * k2 : 0.f;
+      const float* ggc = gg + c0 + cc;
+      float s0 = 0.f, s1 = 0.f;
+      if (!partial) {
 #pragma unroll
-      for (int i = 0; i < NPAD; ++i) {
-        if (i < n_shifts) {
-          const int k = c0 + cc + mo.off[i];
-          const int kk = k >= C ? k - C : k;
-          if (kk < L) {
-            acc = fmaf(a[i], gg[k], acc);
-            acc = fmaf(-bq[i], xv, acc);
+        for (int i = 0; i < NPAD; i += 2) {
+          s0 = fmaf(a[i], ggc[mo.off[i]], s0);
+          if (i + 1 < NPAD) s1 = fmaf(a[i + 1], ggc[mo.off[i + 1]], s1);
+        }
+        acc = fmaf(-bqsum, xv, acc + (s0 + s1));
+      } else {
+        const float* wwc = ww + c0 + cc;
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NPAD; i += 2) {
+          s0 = fmaf(a[i], ggc[mo.off[i]], s0);
+          t0 = fmaf(bq[i], wwc[mo.off[i]], t0);
+          if (i + 1 < NPAD) {
+            s1 = fmaf(a[i + 1], ggc[mo.off[i + 1]], s1);
+            t1 = fmaf(bq[i + 1], wwc[mo.off[i + 1]], t1);
           }
         }
+        acc = fmaf(-(t0 + t1), xv, acc + (s0 + s1));
       }
       dd[cc * XLD + tid] = acc;
     }
@@ -319,6 +340,10 @@ extern "C" int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g
   int rc;
   if (n_shifts <= 8)
     rc = launch_match_bwd<8>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
+  else if (n_shifts <= 16)
+    rc = launch_match_bwd<16>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
+  else if (n_shifts <= 20)
+    rc = launch_match_bwd<20>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
   else if (n_shifts <= 24)
     rc = launch_match_bwd<24>(x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dscores, ddst, ldo, dx, lddx, scratch, B, hw, C, st);
   else

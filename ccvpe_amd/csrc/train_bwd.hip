@@ -236,8 +236,12 @@ extern "C" int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(p.nblk, batch);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), (size_t)P * cgx * 2 * 16, st, p, scratch);
-  launch_sum_parts(scratch, p.nblk * batch, 2L * channels, channels, dbeta, st);
-  launch_sum_parts(scratch + channels, p.nblk * batch, 2L * channels, channels, dgamma, st);
+  if (dgamma == dbeta + channels) {   // adjacent outputs (what the host side allocates): the partial rows are [dbeta | dgamma] too
+    launch_sum_parts(scratch, p.nblk * batch, 2L * channels, 2 * channels, dbeta, st);
+  } else {
+    launch_sum_parts(scratch, p.nblk * batch, 2L * channels, channels, dbeta, st);
+    launch_sum_parts(scratch + channels, p.nblk * batch, 2L * channels, channels, dgamma, st);
+  }
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, p, dbeta, dgamma,
                      1.0f / ((float)batch * (float)rows_per_sample), dx);
   return check_launch("bn_act_bwd");

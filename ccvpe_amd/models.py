@@ -150,6 +150,8 @@ FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEV
 # K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
 # instead.  B = 64 keeps every level folded (level 6 has 4096 low-res pixels).
 FOLD_MIN_PIXELS = 4096
+# train mode: replay the per-step weight re-pack as one hipGraph (see _CVMBase._packed); CCVPE_PACK_GRAPH=0 keeps it eager
+PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
@@ -387,18 +389,45 @@ class _CVMBase(nn.Module):
         # from them) additionally depends on how many train-mode forwards have run; the train pack does not use them
         epoch = 0 if self.training else getattr(self, "_stats_epoch", 0)
         key = (self.precision, self.fp32_tail_levels, self.training, epoch) + self._weights_key()
-        if self._pack_cache is None or key != self._pack_key:
-            sd = {k: v.detach() for k, v in self.state_dict().items()}
-            dev = next(self.parameters()).device
-            if dev.type != "cuda":
-                raise RuntimeError("ccvpe_amd: move the model to the MI355X first (.to('cuda'))")
-            n_tail = MODEL_SPECS[self.kind]["n_rot"]
-            dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        if self._pack_cache is not None and key == self._pack_key:
+            return self._pack_cache
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("ccvpe_amd: move the model to the MI355X first (.to('cuda'))")
+        sd = {k: v.detach() for k, v in self.state_dict().items()}
+        n_tail = MODEL_SPECS[self.kind]["n_rot"]
+        dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
+
+        def pack():
             with torch.no_grad():
                 # train mode runs the decoders unfused (ccvpe_amd/train.py): skip the fp64 fold of deconv into conv
-                self._pack_cache = _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training,
-                                               f32_tail=self.fp32_tail_levels)
-            self._pack_key = key
+                return _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training, f32_tail=self.fp32_tail_levels)
+
+        if self.training and PACK_GRAPH:
+            # Every optimizer step changes every weight, so a training step re-packs all of them: ~280 tiny torch launches
+            # (permute / pad / copy), 8.8 ms of wall time of which 1.9 ms is kernel time.  The launches read the live
+            # parameters in place and never change shape, so from the second pack on (the first one runs eagerly and
+            # warms the allocator) they are one hipGraph launch, re-captured only if a parameter's storage moves.
+            where = (self.precision, self.fp32_tail_levels) + tuple(
+                t.data_ptr() for t in list(self.parameters()) + list(self.buffers()))
+            g = getattr(self, "_pack_graph", None)
+            if g is not None and g[0] == where:
+                g[1].replay()
+                self._pack_cache = g[2]
+            elif getattr(self, "_pack_where", None) == where:
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    pk = pack()
+                graph.replay()
+                self._pack_graph = (where, graph, pk)
+                self._pack_cache = pk
+            else:
+                self._pack_graph = None
+                self._pack_where = where
+                self._pack_cache = pack()
+        else:
+            self._pack_cache = pack()
+        self._pack_key = key
         return self._pack_cache
 
     def _side_stream(self):

@@ -11,7 +11,7 @@ import torch
 from . import _lib
 from ._lib import ConvDesc, check
 
-ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SWISH, ACT_RELU_MASK = 0, 1, 2, 3
 SPLIT_K_CALLS = 0        # number of conv_igemm calls that took the split-K path (tests / diagnostics)
 SPLIT_K = __import__("os").environ.get("CCVPE_SPLIT_K", "1") == "1"      # split-K for small-batch GEMMs (0 disables)
 OUT_NHWC, OUT_DECONV2X = 0, 1
@@ -161,7 +161,7 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         is3x3 = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and out_mode == OUT_NHWC and gate is None)
         name = igemm_tile(n, is3x3)
         if (want <= 0 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and src1 is None and out_mode == OUT_NHWC
-                and act != ACT_RELU and n > 48):
+                and act not in (ACT_RELU, ACT_RELU_MASK) and n > 48):
             name = name.replace("igemm_f32_kernel<", "pw_gemm_f32_kernel<")      # mirrors is_pw in conv_igemm_any()
             name = name.replace("pw_gemm_f32_kernel<4,5,1>", "pw_gemm_f32_kernel<4,3,2>")
         if dt != torch.float32:

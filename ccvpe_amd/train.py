@@ -261,14 +261,13 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
     y, up, skip, cat, k = t["y"], t["up"], t["skip"], t["cat"], t["k"]
     w_b = _p(live, conv + ".2.weight")
     if last:
-        dy, dwb, dbb = bw.head_conv3x3_bwd(y, lv.w_b, dout)
+        dy, dwb, dbb = bw.head_conv3x3_bwd(y, lv.w_b, dout, relu_mask_x=True)      # dy: in front of conv.1's ReLU
         grads[conv + ".2.weight"] = dwb.permute(0, 3, 1, 2)
         grads[conv + ".2.bias"] = dbb
     else:
         grads[conv + ".2.weight"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1)
         grads[conv + ".2.bias"] = bw.bias_grad(dout)
-        dy = bw.conv3x3_dgrad(dout, w_b)
-    dy = bw.relu_bwd(y, dy)
+        dy = bw.conv3x3_dgrad(dout, w_b, relu_out=y)                               # ReLU backward fused in the store
     grads[conv + ".0.weight"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip)
     grads[conv + ".0.bias"] = bw.bias_grad(dy)
     dcat2 = bw.conv3x3_dgrad(dy, _p(live, conv + ".0.weight"))                 # [B,2hw,2hw,c0+c1]

@@ -34,6 +34,8 @@ extern "C" {
 #define CCVPE_ACT_NONE 0
 #define CCVPE_ACT_RELU 1
 #define CCVPE_ACT_SWISH 2
+#define CCVPE_ACT_RELU_MASK 3  /* out = residual > 0 ? value : 0 — the backward of a ReLU fused into the conv that produces its
+                                 output gradient (residual = the ReLU's forward output; it is a mask here, not added) */
 
 #define CCVPE_OUT_NHWC 0      /* dst[(pixel)*ldd + n]                                            */
 #define CCVPE_OUT_DECONV2X 1  /* n = (dy*2+dx)*cout + co -> dst[(b,2y+dy,2x+dx)*ldd + co]        */
@@ -334,7 +336,7 @@ int ccvpe_softmax_bwd_f32(const float* heatmap, const float* dheatmap, const flo
                           int rows, int n, void* stream);
 int ccvpe_l2norm2_bwd_f32(const float* raw, const float* dout, float* draw, int batch, int hw, void* stream);
 int ccvpe_head_conv3x3_bwd_f32(const float* x, const float* w, const float* dout, float* dx, float* dw, float* dbias,
-                               float* scratch, int batch, int h, int wd, int cout, void* stream);
+                               float* scratch, int batch, int h, int wd, int cout, int relu_mask_x, void* stream);
 int ccvpe_ground_descriptor_bwd_f32(const float* y1, int ld, const float* wh, const int* cd, const float* dout,
                                     float* dy1, float* dwh, float* dbh, int batch, int h, int w, void* stream);
 int ccvpe_add_cols_f32(const float* src, int ld_src, int col_off, float* dst, int ld_dst, int channels, int rows,

@@ -61,6 +61,10 @@ def test_conv_wgrad_and_dgrad_vs_autograd(bw, c0, c1, n, k, stride, pad, h, w):
     else:
         dx = bw.conv2x2s2_dgrad(dyd, wd)
     close(dx.permute(0, 3, 1, 2), x.grad, 2e-4, "dgrad")
+    if k == 3:                                  # gradient in front of a ReLU that produced x: same launch, masked store
+        keep = torch.relu(synth.normal((b, h, w, c0 + c1), 804)).cuda()
+        dxm = bw.conv3x3_dgrad(dyd, wd, relu_out=keep)
+        assert torch.equal(dxm, dx * (keep > 0)), "fused ReLU mask differs from relu_bwd of the plain dgrad"
 
 
 @pytest.mark.parametrize("cin,cout,h", [(48, 16, 9), (648, 320, 3), (168, 40, 5)])
@@ -202,6 +206,8 @@ def test_head_conv_bwd_vs_autograd(bw, cout):
     if cout == 2:
         dr = bw.l2norm2_bwd(r.detach().cuda(), dr)
     dx, dw, db = bw.head_conv3x3_bwd(xd, wp, dr)
+    dxm, dwm, dbm = bw.head_conv3x3_bwd(xd, wp, dr, relu_mask_x=True)
+    assert torch.equal(dxm, dx * (xd > 0)) and torch.equal(dwm, dw) and torch.equal(dbm, db)
     close(dx, nhwc(x.grad), 2e-4, "head dx")
     close(dw, wt.grad.permute(0, 2, 3, 1), 2e-4, "head dw")
     close(db, bias.grad, 2e-4, "head dbias")
