@@ -82,6 +82,45 @@ __device__ __forceinline__ f32x4 apply_gate<bf16_t>(f32x4 raw, const float* g) {
   return __builtin_bit_cast(f32x4, v);
 }
 
+// ---------------------------------------------------------------------------------------------
+// STAGING RULE for every kernel in this file: a stage's global loads are issued into RAW registers and nothing touches
+// those registers until the stage's matrix instructions have been issued; validity masks, the SE gate and any other
+// per-element work are applied when the registers are written to LDS (store_*).  Three ways the prefetch used to be
+// waited for BEFORE the MFMAs it was meant to overlap (rocprof: 28-79 % MFMA-busy), all visible as `s_waitcnt vmcnt`
+// between the loads and the first v_mfma of the loop body (tools/isa_loop.py):
+//   * `v = ok ? load : 0` / `v = load * gate` at the load: the select / multiply needs the data;
+//   * `f32x4 v = 0; if (ok) v = load;`: the zero-initialisation rewrites a register an earlier load may still own, so the
+//     compiler waits vmcnt(0) — for the loads just issued as well;
+//   * struct fields used only under a lane-dependent condition (`from0 ? p.ld0 : p.ld1`) were fetched from the kernarg
+//     segment with a VECTOR load per use, a dependent load in front of every activation load.
+// Out-of-range lanes read a clamped, valid address instead.
+// ---------------------------------------------------------------------------------------------
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 keep_if(f32x4 v, bool keep) {       // v or all-zero bits, without a branch
+  return __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & (keep ? -1 : 0));
+}
+// SE gate values of one 16-byte activation piece (4 fp32 / 8 bf16 channels), fetched with the stage's loads into two plain
+// registers and applied at the LDS store
+template <typename T>
+__device__ __forceinline__ void gate_load(const float* g, f32x4& g0, f32x4& g1) {
+  g0 = *reinterpret_cast<const f32x4*>(g);
+  if (sizeof(T) == 2) g1 = *reinterpret_cast<const f32x4*>(g + 4);
+}
+template <typename T>
+__device__ __forceinline__ f32x4 gate_apply(f32x4 raw, f32x4 g0, f32x4 g1) {
+  if (sizeof(T) == 4) return raw * g0;
+  bf16x8 v = __builtin_bit_cast(bf16x8, raw);
+  bf16x8 o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    o[i] = (bf16_t)((float)v[i] * g0[i]);
+    o[i + 4] = (bf16_t)((float)v[i + 4] * g1[i]);
+  }
+  return __builtin_bit_cast(f32x4, o);
+}
+// a kernel-argument field pinned in a scalar register (see the third bullet above)
+__device__ __forceinline__ int sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
 struct IgemmParams {
   const void* src0;
   const void* src1;
@@ -249,33 +288,36 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  unsigned a_keep = 0;                      // bit `it`: piece `it` of the stage in a_reg is inside the image and the K range
+  f32x4 g_r0 = {0.f, 0.f, 0.f, 0.f}, g_r1 = g_r0;   // SE gate of the FIRST staged row's sample (rows of a tile nearly always share it)
+  int g_ch = 0;                             // channel of the staged piece, for the rare rows of another sample
+  const bool gated = p.gate != nullptr;     // (1x1, single-source convs only)
+  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
 
   auto load_stage = [&](int s) {
     const bool kvalid = kc < p.total_chunks;
-    const bool from0 = r < p.cpt0;
+    const bool from0 = !kvalid || r < p.cpt0;
     const T* base = from0 ? src0 : src1;
-    const int ld = from0 ? p.ld0 : p.ld1;
-    const int ch = (from0 ? r : r - p.cpt0) * 8 + half;
+    const int ld = from0 ? ld0s : ld1s;
+    const int ch = kvalid ? (from0 ? r : r - p.cpt0) * 8 + half : 0;
+    a_keep = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int iy = a_y[it] + ky;
       const int ix = a_x[it] + kx;
       const bool ok = a_ok[it] && kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const size_t off = ((size_t)(a_b[it] * p.H + iy) * p.W + ix) * ld + ch;
-        v = *reinterpret_cast<const f32x4*>(base + off);
-        if (p.gate != nullptr && from0) v = apply_gate<T>(v, p.gate + (size_t)a_b[it] * p.c0 + ch);
-      }
-      a_reg[it] = v;
+      const int cb = ok ? a_b[it] : 0, cy = ok ? iy : 0, cx = ok ? ix : 0;
+      a_reg[it] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cb * p.H + cy) * p.W + cx) * ld + ch);
+      a_keep |= ok ? (1u << it) : 0u;
+    }
+    if (gated) {
+      g_ch = ch;
+      gate_load<T>(p.gate + (size_t)a_b[0] * p.c0 + ch, g_r0, g_r1);
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + 64 * it;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nrow < BN && n0 + nrow < p.Npad)
-        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + s * SK + ssub * E);
-      b_reg[it] = v;
+      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);     // rows past the tile / Npad: any valid row (never stored)
+      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + s * SK + ssub * E);
     }
     kc += CPS;
     r += CPS;
@@ -287,8 +329,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   auto store_stage = [&](int buf) {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = a_reg[it];
+    for (int it = 0; it < A_IT; ++it) {
+      f32x4 v = a_reg[it];
+      if (gated) {
+        if (a_b[it] == a_b[0]) v = gate_apply<T>(v, g_r0, g_r1);
+        else v = apply_gate<T>(v, p.gate + (size_t)a_b[it] * p.c0 + g_ch);
+      }
+      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = keep_if(v, (a_keep >> it) & 1u);
+    }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
@@ -484,43 +532,53 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
     sc_reg = (ok && p.scale) ? p.scale[n] : 1.0f;
     sh_reg = (ok && p.shift) ? p.shift[n] : 0.0f;
   };
-  // BRANCH-FREE staging loads: out-of-range rows / K pieces read a clamped (valid) address and are zeroed by a select, so
-  // the 8-9 loads of a stage issue back to back (a guarded load per iteration compiled to an exec-mask branch around
-  // every load).  The SE gate is a workgroup-uniform switch around the whole loop.
-  auto load_stage_t = [&](int m0, int n0, int s, auto gate_tag) {
-    constexpr bool GATE = decltype(gate_tag)::value;
+  // Staging (see STAGING RULE at the top of the file): raw loads from clamped addresses; row / K validity is kept as bits
+  // and applied, with the SE gate, when the pieces are written to LDS.  W needs no mask: its rows beyond N and columns
+  // beyond K are zero padding, rows beyond Npad are never stored, and a K piece beyond Kpad meets a zeroed A piece.
+  unsigned row_ok = 0;                        // bit `it`: staged row `it` of the tile in a_reg is < M
+  bool k_ok = false;                          // the staged K piece is < c0
+  int st_m0 = 0, g_kc = 0, g_mend = 0;        // tile row base of a_reg; gate: piece channel, end row of the first row's sample
+  f32x4 g_r0 = {0.f, 0.f, 0.f, 0.f}, g_r1 = g_r0;
+  const bool gated = p.gate != nullptr;
+  const int ld0s = sgpr(p.ld0);
+  auto load_stage = [&](int m0, int n0, int s) {
     const int kcol = s * KS + pc * E;         // first K element of this thread's piece
-    const bool kok = kcol < p.c0;
-    const int kc = kok ? kcol : 0;
+    k_ok = kcol < p.c0;
+    const int kc = k_ok ? kcol : 0;
+    row_ok = 0;
+    st_m0 = m0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int m = m0 + prow + it * (256 / PPR);
-      const bool ok = kok && m < p.M;
-      const int mc = m < p.M ? m : p.M - 1;
-      f32x4 v = *reinterpret_cast<const f32x4*>(src0 + (size_t)mc * p.ld0 + kc);
-      if (GATE) v = apply_gate<T>(v, p.gate + (size_t)(mc / hw) * p.c0 + kc);
-      a_reg[it] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const bool rok = m < p.M;
+      const int mc = rok ? m : p.M - 1;
+      a_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (size_t)mc * ld0s + kc);
+      row_ok |= rok ? (1u << it) : 0u;
     }
-    const bool wkok = kcol < p.Kpad;
-    const int wkc = wkok ? kcol : 0;
+    if (gated) {
+      const int bf = min(m0 + prow, p.M - 1) / hw;
+      gate_load<T>(p.gate + (size_t)bf * p.c0 + kc, g_r0, g_r1);
+      g_kc = kc;
+      g_mend = (bf + 1) * hw;
+    }
+    const int wkc = kcol < p.Kpad ? kcol : 0;
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = prow + it * (256 / PPR);
-      const int nr = n0 + nrow;
-      const bool ok = wkok && nrow < BN && nr < p.Npad;
-      const int nc = nr < p.Npad ? nr : p.Npad - 1;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(wp + (size_t)nc * p.Kpad + wkc);
-      b_reg[it] = ok ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int nr = min(n0 + prow + it * (256 / PPR), p.Npad - 1);
+      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + wkc);
     }
-  };
-  auto load_stage = [&](int m0, int n0, int s) {
-    if (p.gate != nullptr) load_stage_t(m0, n0, s, std::true_type{});
-    else load_stage_t(m0, n0, s, std::false_type{});
   };
   auto store_stage = [&]() {
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      *reinterpret_cast<f32x4*>(&As[(prow + it * (256 / PPR)) * LDF + pc * 4]) = a_reg[it];
+    for (int it = 0; it < A_IT; ++it) {
+      f32x4 v = a_reg[it];
+      if (gated) {
+        const int m = st_m0 + prow + it * (256 / PPR);
+        if (m < g_mend) v = gate_apply<T>(v, g_r0, g_r1);                       // same sample as the thread's first row: the usual case
+        else v = apply_gate<T>(v, p.gate + (size_t)(min(m, p.M - 1) / hw) * p.c0 + g_kc);
+      }
+      *reinterpret_cast<f32x4*>(&As[(prow + it * (256 / PPR)) * LDF + pc * 4]) = keep_if(v, k_ok && ((row_ok >> it) & 1u));
+    }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = prow + it * (256 / PPR);
@@ -800,25 +858,27 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
   const int srow = tid >> 2, ssub = tid & 3;
 
   f32x4 h_reg[H_IT], b_reg[B_IT];
+  int h_chunk = 0;                         // chunk held in h_reg (workgroup-uniform: lives in a scalar register)
+  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
 
-  auto load_halo = [&](int chunk) {
+  auto load_halo = [&](int chunk) {        // raw loads from clamped addresses; masked in store_halo (STAGING RULE)
+    h_chunk = chunk;
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int ch = chunk * SK + h_sub[it] * E;
-      if (h_pix[it] >= 0 && ch < ctot) {
-        const bool from0 = ch < p.c0;
-        const T* base = from0 ? src0 : src1;
-        const size_t off = (size_t)h_pix[it] * (from0 ? p.ld0 : p.ld1) + (from0 ? ch : ch - p.c0);
-        v = *reinterpret_cast<const f32x4*>(base + off);
-      }
-      h_reg[it] = v;
+      const bool ok = h_pix[it] >= 0 && ch < ctot;
+      const bool from0 = !ok || ch < p.c0;
+      const T* base = from0 ? src0 : src1;
+      const size_t off = ok ? (size_t)h_pix[it] * (from0 ? ld0s : ld1s) + (from0 ? ch : ch - p.c0) : 0;
+      h_reg[it] = *reinterpret_cast<const f32x4*>(base + off);
     }
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int it = 0; it < H_IT; ++it)
-      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Hs[0][0] + h_off[it]) = h_reg[it];
+      if (h_off[it] >= 0)
+        *reinterpret_cast<f32x4*>(&Hs[0][0] + h_off[it]) =
+            keep_if(h_reg[it], h_pix[it] >= 0 && h_chunk * SK + h_sub[it] * E < ctot);
   };
   auto load_w = [&](int chunk, int tap, int dbuf) {
     if constexpr (DMA) {
@@ -832,13 +892,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
       }
     } else {
       const int ch = chunk * SK + ssub * E;
+      const int kcol = ch < ctot ? tap * ctot + ch : 0;        // beyond the channel range the halo piece is zero anyway
 #pragma unroll
       for (int it = 0; it < B_IT; ++it) {
-        const int nrow = srow + RPP * it;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (nrow < BN && n0 + nrow < p.Npad && ch < ctot)
-          v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + tap * ctot + ch);
-        b_reg[it] = v;
+        const int nr = min(n0 + srow + RPP * it, p.Npad - 1);
+        b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + kcol);
       }
     }
   };
@@ -873,8 +931,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
     int nchunk = chunk, ntap = tap + 1;
     if (ntap == 9) { ntap = 0; ++nchunk; }
     const bool next_halo = (tap == 0) && (chunk + 1 < nchunks);
-    if (more) load_w(nchunk, ntap, (s + 1) & 1);
-    if (next_halo) load_halo(chunk + 1);
 
     const int ky = tap / 3, kx = tap - ky * 3;
     const float* hb = &Hs[0][0];
@@ -885,6 +941,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
 #pragma unroll
     for (int j = 0; j < NT; ++j)
       bf[j] = *reinterpret_cast<const f32x4*>(&Bs[s & 1][(wn * NT + j) * 16 + frow][DMA ? (((lane >> 4) ^ w_swz(frow)) * 4) : fk]);
+    // The next stage's loads are issued AFTER this stage's fragment reads: the W panel arrives by LDS-DMA, and the compiler
+    // waits vmcnt(0) before any LDS read that follows a DMA it cannot prove disjoint — issued first, every stage stalled
+    // on its own prefetch before its first MFMA.  Here the wait lands at the stage's closing barrier instead.
+    if (more) load_w(nchunk, ntap, (s + 1) & 1);
+    if (next_halo) load_halo(chunk + 1);
     if (sizeof(T) == 4) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -900,6 +961,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) void conv3x3_kernel(const
         for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
     }
 
+    // keep the closing barrier (and the vmcnt(0) the DMA needs in front of it) BELOW the matrix work: the scheduler moves
+    // s_barrier freely among MFMAs and had put it after the first one
+    __builtin_amdgcn_sched_barrier(0);
     if (more) store_w((s + 1) & 1);
     __syncthreads();
     if (tap == 8 && more) {   // chunk boundary: every wave is done reading the halo -> overwrite it
@@ -1134,55 +1198,49 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
   const int k0end = 4 * p.cpt0;      // chunks belonging to the low-res source
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  unsigned a_keep = 0;                      // bit `it`: piece `it` in a_reg is inside its image and the K range
+  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
 
   // (an incrementally advanced cursor instead of the two divisions measured 5 % SLOWER: 96.8 vs 101.6 TF)
+  // One unconditional load per piece (STAGING RULE): the source, its geometry and the tap offset are selected per thread
+  // first; lanes outside the image read pixel 0 and are zeroed when the piece is written to LDS.
   auto load_stage = [&](int s) {
     const int kc = CPS * s + chunk_in_stage;
     const bool kvalid = kc < p.total_chunks;
-    const bool from0 = kc < k0end;
+    const bool from0 = !kvalid || kc < k0end;
     int dy, dx, ch;
-    if (from0) {
-      const int tap = kc / p.cpt0;
-      ch = (kc - tap * p.cpt0) * 8 + half;
-      dy = (tap >> 1) - 1 + py;
-      dx = (tap & 1) - 1 + px;
-    } else {
+    {
+      const int tap0 = kc / p.cpt0;
       const int k2 = kc - k0end;
-      const int tap = p.cpt1 > 0 ? k2 / p.cpt1 : 0;
-      ch = (k2 - tap * p.cpt1) * 8 + half;
-      const int ky = tap / 3;
-      dy = py + ky - 1;
-      dx = px + (tap - 3 * ky) - 1;
+      const int tap1 = p.cpt1 > 0 ? k2 / p.cpt1 : 0;
+      const int ky = tap1 / 3;
+      ch = kvalid ? (from0 ? (kc - tap0 * p.cpt0) : (k2 - tap1 * p.cpt1)) * 8 + half : 0;
+      dy = from0 ? (tap0 >> 1) - 1 + py : py + ky - 1;
+      dx = from0 ? (tap0 & 1) - 1 + px : px + (tap1 - 3 * ky) - 1;
     }
+    const T* base = from0 ? src0 : src1;
+    const int ld = from0 ? ld0s : ld1s;
+    const int mul = from0 ? 1 : 2;
+    const int hh = from0 ? p.H1 : H2, ww = from0 ? p.W1 : W2;
+    a_keep = 0;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (a_ok[it] && kvalid) {
-        if (from0) {
-          const int iy = a_y[it] + dy, ix = a_x[it] + dx;
-          if ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1)
-            v = *reinterpret_cast<const f32x4*>(src0 + ((size_t)(a_b[it] * p.H1 + iy) * p.W1 + ix) * p.ld0 + ch);
-        } else {
-          const int iy = 2 * a_y[it] + dy, ix = 2 * a_x[it] + dx;
-          if ((unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2)
-            v = *reinterpret_cast<const f32x4*>(src1 + ((size_t)(a_b[it] * H2 + iy) * W2 + ix) * p.ld1 + ch);
-        }
-      }
-      a_reg[it] = v;
+      const int iy = mul * a_y[it] + dy, ix = mul * a_x[it] + dx;
+      const bool ok = a_ok[it] && kvalid && (unsigned)iy < (unsigned)hh && (unsigned)ix < (unsigned)ww;
+      const int cb = ok ? a_b[it] : 0, cy = ok ? iy : 0, cx = ok ? ix : 0;
+      a_reg[it] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cb * hh + cy) * ww + cx) * ld + ch);
+      a_keep |= ok ? (1u << it) : 0u;
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + 64 * it;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nrow < BN && n0 + nrow < p.Npad)
-        v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + s * SK + ssub * E);
-      b_reg[it] = v;
+      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);
+      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + s * SK + ssub * E);
     }
   };
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
-      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = a_reg[it];
+      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
@@ -1335,27 +1393,29 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     }
   }
   f32x4 h_reg[H_IT], b_reg[B_IT], a_reg[A_IT];
-  auto load_halo = [&](int chunk) {
+  unsigned h_keep = 0, a_keep = 0;          // validity bits of the pieces in h_reg / a_reg, applied at the LDS store
+  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
+  auto load_halo = [&](int chunk) {         // raw loads from clamped addresses (STAGING RULE)
+    h_keep = 0;
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
       const int ch = chunk * SK + h_sub[it] * E;
-      if (h_pix[it] >= 0 && ch < p.c0) v = *reinterpret_cast<const f32x4*>(src0 + (size_t)h_pix[it] * p.ld0 + ch);
-      h_reg[it] = v;
+      const bool ok = h_pix[it] >= 0 && ch < p.c0;
+      h_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (ok ? (size_t)h_pix[it] * ld0s + ch : 0));
+      h_keep |= ok ? (1u << it) : 0u;
     }
   };
   auto store_halo = [&]() {
 #pragma unroll
     for (int it = 0; it < H_IT; ++it)
-      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Us[0][0] + h_off[it]) = h_reg[it];
+      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Us[0][0] + h_off[it]) = keep_if(h_reg[it], (h_keep >> it) & 1u);
   };
   auto load_w = [&](int kcol, bool ok) {        // kcol: first K column of this 64-byte piece row
+    const int kc = ok ? kcol : 0;               // (a piece beyond the channel range meets a zeroed activation piece)
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nrow = srow + 64 * it;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok && nrow < BN && n0 + nrow < p.Npad) v = *reinterpret_cast<const f32x4*>(wp + (size_t)(n0 + nrow) * p.Kpad + kcol);
-      b_reg[it] = v;
+      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);
+      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + kc);
     }
   };
   auto store_w = [&](int buf) {
@@ -1411,11 +1471,11 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
       int nchunk = chunk, ntap = tap + 1;
       if (ntap == 4) { ntap = 0; ++nchunk; }
       const bool next_halo = (tap == 0) && (chunk + 1 < nchunks0);
+      if (next_halo) load_halo(chunk + 1);       // before the W loads: re-using h_reg costs a vmcnt(0), harmless while nothing is in flight
       if (more) {
         const int ch = nchunk * SK + ssub * E;
         load_w(ntap * p.c0 + ch, ch < p.c0);
       }
-      if (next_halo) load_halo(chunk + 1);
       const int du = tap >> 1, dv = tap & 1;
       f32x4 af[MT];
 #pragma unroll
@@ -1453,22 +1513,24 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     }
     auto load_a = [&](int s) {
       const int kc = CPS * s + chunk_in_stage;
+      const bool kvalid = kc < chunksB;
       const int tapb = kc / p.cpt1;
-      const int ch = (kc - tapb * p.cpt1) * 8 + half;
+      const int ch = kvalid ? (kc - tapb * p.cpt1) * 8 + half : 0;
       const int ky = tapb / 3, kx = tapb - 3 * ky;
+      a_keep = 0;
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         const int iy = a_yy[it] + ky, ix = a_xx[it] + kx;
-        if (kc < chunksB && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2)
-          v = *reinterpret_cast<const f32x4*>(src1 + ((size_t)(b * H2 + iy) * W2 + ix) * p.ld1 + ch);
-        a_reg[it] = v;
+        const bool ok = kvalid && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+        const int cy = ok ? iy : 0, cx = ok ? ix : 0;
+        a_reg[it] = *reinterpret_cast<const f32x4*>(src1 + ((size_t)(b * H2 + cy) * W2 + cx) * ld1s + ch);
+        a_keep |= ok ? (1u << it) : 0u;
       }
     };
     auto store_a = [&](int buf) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it)
-        *reinterpret_cast<f32x4*>(&Us[buf * BM + srow + 64 * it][ssub * 4]) = a_reg[it];
+        *reinterpret_cast<f32x4*>(&Us[buf * BM + srow + 64 * it][ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
     };
     // the halo is dead (phase A ended on a barrier); W buffer `wbuf` was the last one read
     load_a(0);

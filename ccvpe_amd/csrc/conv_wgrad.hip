@@ -74,18 +74,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // staging: thread -> pixel row tid >> 3 (0..31), float4 pieces at tile column (tid & 7) * 4 + 32 * q
   const int prow = tid >> 3;
   const int pc = (tid & 7) * 4;
-  int pky[XP], pkx[XP], pch[XP];                     // per X piece: tap offsets and input channel (stage-invariant)
+  int pky[XP], pkx[XP], pld[XP];                     // per X piece: tap offsets, pixel stride of its source (stage-invariant)
+  const float* pbase[XP];                            // ... and the source row base at its input channel (src0 or src1)
   bool pok[XP];
 #pragma unroll
   for (int q = 0; q < XP; ++q) {
     const int col = cc0 + pc + 32 * q;
     pok[q] = col < ncols;
     const int tap = pok[q] ? col / ctot : 0;
-    pch[q] = col - tap * ctot;
+    const int c = pok[q] ? col - tap * ctot : 0;
     pky[q] = tap / p.kw;
     pkx[q] = tap - pky[q] * p.kw;
+    const bool first = c < p.c0;
+    pbase[q] = first ? p.src0 + c : p.src1 + (c - p.c0);
+    pld[q] = first ? p.ld0 : p.ld1;
   }
+  // Staged pieces are kept RAW in registers across the stage's matrix work, with their validity as lane masks; the masks
+  // are applied when the pieces go to LDS (store_stage).  Applying them at the load (`x = in ? t : 0`) made every stage
+  // wait for its own prefetch before the first MFMA: vmcnt(3..0) right after the loads.
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
   f32x4 yr[YP], xr[XP];
+  int ykeep = 0, xkeep[XP];
 
   // Pixel cursor of this thread's staged row: decoded ONCE (two integer divisions) and then advanced by WG_BP pixels per
   // stage with compare-and-carry (the per-stage decode was ~80 VALU instructions next to 1 024 cycles of MFMA work).
@@ -105,20 +114,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const int m = cm;
     const bool ok = m < m_end;
     const int mc = m < p.M ? m : lastpix;
+    ykeep = ok ? -1 : 0;
 #pragma unroll
     for (int q = 0; q < YP; ++q) {
       const int nl = pc + 32 * q;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (nl < TN) {
+      if (nl < TN) {                                   // compile-time per piece
+        // One 16-byte load per piece, no tail path: the pixel stride ldy is a multiple of 4 floats >= N, so the vector at
+        // column n stays inside the row whenever n < ldy.  Columns >= N only feed output rows that are never stored.  (A
+        // scalar tail branch for N % 4 != 0 used to sit here: the divergent region made the compiler wait vmcnt(0)
+        // after EVERY dY load of the stage loop — four exposed L2 round trips per 4 096 cycles of matrix work.)
         const int n = n0 + nl;
-        if (n + 3 < p.N) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(p.dy + (size_t)mc * p.ldy + n);
-          v = ok ? t : v;
-        } else if (ok && n < p.N) {
-          for (int r = 0; r < 4; ++r) if (n + r < p.N) v[r] = p.dy[(size_t)m * p.ldy + n + r];
-        }
+        const int nc = n < p.ldy ? n : 0;
+        yr[q] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)mc * p.ldy + nc);
       }
-      yr[q] = v;
     }
 #pragma unroll
     for (int q = 0; q < XP; ++q) {
@@ -126,10 +134,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       const bool in = ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const int cy = in ? iy : 0, cx = in ? ix : 0, bb = in ? cb : 0;
       const size_t pix = (size_t)(bb * p.H + cy) * p.W + cx;
-      const int c = pok[q] ? pch[q] : 0;
-      const f32x4 t = (c < p.c0) ? *reinterpret_cast<const f32x4*>(p.src0 + pix * p.ld0 + c)
-                                 : *reinterpret_cast<const f32x4*>(p.src1 + pix * p.ld1 + (c - p.c0));
-      xr[q] = in ? t : (f32x4){0.f, 0.f, 0.f, 0.f};
+      xr[q] = *reinterpret_cast<const f32x4*>(pbase[q] + pix * pld[q]);
+      xkeep[q] = in ? -1 : 0;
     }
     // advance the cursor by one stage
     cm += WG_BP;
@@ -142,9 +148,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int q = 0; q < YP; ++q)
-      if (pc + 32 * q < TN) *reinterpret_cast<f32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = yr[q];
+      if (pc + 32 * q < TN)
+        *reinterpret_cast<i32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, yr[q]) & ykeep;
 #pragma unroll
-    for (int q = 0; q < XP; ++q) *reinterpret_cast<f32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = xr[q];
+    for (int q = 0; q < XP; ++q)
+      *reinterpret_cast<i32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, xr[q]) & xkeep[q];
   };
 
   // Square tiles (TN >= 64) run on v_mfma_f32_32x32x2_f32: a wave owns (TN/2) x (TC/2) as 32 x 32 blocks.  Operand lanes
