@@ -27,6 +27,7 @@ struct WgradParams {
   int M;                // batch * Ho * Wo
   int S, pix_per_split;
   int tiles_n, tiles_c;
+  int ablate;           // diagnostics build only (-DCCVPE_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no fragment reads
 };
 
 constexpr int WG_T = 64;    // tile: 64 output channels x 64 input channels
@@ -110,34 +111,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     cox = rem - coy * p.Wo;
   }
   const int lastpix = p.M - 1;
-  auto load_stage = [&](int /*m0*/) {
+  // A stage's staging work is cut into per-piece TASKS so that the stage loop can spread it between its groups of matrix
+  // instructions (one task per group) instead of running it as one burst in front of them: the ~160 vector-ALU instructions
+  // of a stage (address arithmetic, bounds tests, masks) are ~800 cycles, and a wave that is not issuing MFMAs is not hidden
+  // by its neighbour on the SIMD — both run the same loop in step.  Tasks 0 .. NPIECE-1 request piece k of the NEXT stage,
+  // tasks NPIECE .. 2*NPIECE-1 mask piece k and write it to LDS.
+  constexpr int NPIECE = YP + XP;
+  const int ldyb = p.ldy * 4;
+  auto load_piece = [&](int k) {          // k: compile-time after unrolling
     const int m = cm;
     const bool ok = m < m_end;
-    const int mc = m < p.M ? m : lastpix;
-    ykeep = ok ? -1 : 0;
-#pragma unroll
-    for (int q = 0; q < YP; ++q) {
+    if (k < YP) {
+      const int q = k;
       const int nl = pc + 32 * q;
-      if (nl < TN) {                                   // compile-time per piece
+      if (q == 0) ykeep = ok ? -1 : 0;
+      if (nl < TN) {
         // One 16-byte load per piece, no tail path: the pixel stride ldy is a multiple of 4 floats >= N, so the vector at
-        // column n stays inside the row whenever n < ldy.  Columns >= N only feed output rows that are never stored.  (A
-        // scalar tail branch for N % 4 != 0 used to sit here: the divergent region made the compiler wait vmcnt(0)
-        // after EVERY dY load of the stage loop — four exposed L2 round trips per 4 096 cycles of matrix work.)
+        // column n stays inside the row whenever n < ldy.  Columns >= N only feed output rows that are never stored.
+        const int mc = m < p.M ? m : lastpix;
         const int n = n0 + nl;
         const int nc = n < p.ldy ? n : 0;
-        yr[q] = *reinterpret_cast<const f32x4*>(p.dy + (size_t)mc * p.ldy + nc);
+        yr[q] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(p.dy) + (size_t)mc * ldyb + nc * 4);
       }
-    }
-#pragma unroll
-    for (int q = 0; q < XP; ++q) {
+    } else {
+      const int q = k - YP;
       const int iy = coy * p.stride - p.pad + pky[q], ix = cox * p.stride - p.pad + pkx[q];
       const bool in = ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const int cy = in ? iy : 0, cx = in ? ix : 0, bb = in ? cb : 0;
-      const size_t pix = (size_t)(bb * p.H + cy) * p.W + cx;
-      xr[q] = *reinterpret_cast<const f32x4*>(pbase[q] + pix * pld[q]);
+      const int pix = in ? (cb * p.H + iy) * p.W + ix : 0;        // 32-bit: the launcher checks pixels * pitch < 2^31 floats
+      xr[q] = *reinterpret_cast<const f32x4*>(pbase[q] + (size_t)(unsigned)(pix * pld[q]));
       xkeep[q] = in ? -1 : 0;
     }
-    // advance the cursor by one stage
+  };
+  auto advance_cursor = [&]() {
     cm += WG_BP;
     cox += WG_BP;
     while (cox >= p.Wo) {
@@ -145,14 +150,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       if (++coy == p.Ho) { coy = 0; ++cb; }
     }
   };
-  auto store_stage = [&](int buf) {
-#pragma unroll
-    for (int q = 0; q < YP; ++q)
+  auto store_piece = [&](int k, int buf) {
+    if (k < YP) {
+      const int q = k;
       if (pc + 32 * q < TN)
         *reinterpret_cast<i32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, yr[q]) & ykeep;
-#pragma unroll
-    for (int q = 0; q < XP; ++q)
+    } else {
+      const int q = k - YP;
       *reinterpret_cast<i32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, xr[q]) & xkeep[q];
+    }
+  };
+  auto load_stage = [&](int /*m0*/) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) load_piece(k);
+    advance_cursor();
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NPIECE; ++k) store_piece(k, buf);
   };
 
   // Square tiles (TN >= 64) run on v_mfma_f32_32x32x2_f32: a wave owns (TN/2) x (TC/2) as 32 x 32 blocks.  Operand lanes
@@ -187,8 +202,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   __syncthreads();
   for (int s = 0; s < nstage; ++s) {
     const int buf = s & 1;
-    const bool more = s + 1 < nstage;
-    if (more) load_stage(m_begin + (s + 1) * WG_BP);
     if constexpr (M32) {
       // pixel pairs: group g = pixels 2g, 2g+1 of the stage; fragments of group g+1 are read before the MFMAs of group g
       const int l31 = lane & 31, lh = lane >> 5;
@@ -202,10 +215,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int j = 0; j < NJ32; ++j) bd[j] = xrow[j * 32];
       };
       read_pair(0, a[0], bb[0]);
+      constexpr int NG32 = WG_BP / 2;              // 16 groups of NI32 * NJ32 matrix instructions
+      static_assert(2 * NPIECE <= NG32, "one staging task per MFMA group");
 #pragma unroll
-      for (int g = 0; g < WG_BP / 2; ++g) {
+      for (int g = 0; g < NG32; ++g) {
         const int cur = g & 1;
-        if (g + 1 < WG_BP / 2) read_pair(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+#ifdef CCVPE_ABLATE
+        if (g + 1 < NG32 && (!(p.ablate & 4) || s == 0)) read_pair(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+#else
+        if (g + 1 < NG32) read_pair(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+#endif
+        // staging tasks of the NEXT stage, one per group (see load_piece).  UNCONDITIONAL: after the last stage they fetch
+        // clamped addresses and write a buffer nobody reads — under `if (more)` the two paths merge in front of every task
+        // and the merged wait-count state makes each request wait for the previous one (vmcnt(0) per group).
+#ifdef CCVPE_ABLATE
+        if (g < NPIECE && !(p.ablate & 1)) load_piece(g);
+        if (g == NPIECE) advance_cursor();
+        if (g >= NG32 - NPIECE && !(p.ablate & 2)) store_piece(g - (NG32 - NPIECE), buf ^ 1);
+#else
+        if (g < NPIECE) load_piece(g);
+        if (g == NPIECE) advance_cursor();
+        if (g >= NG32 - NPIECE) store_piece(g - (NG32 - NPIECE), buf ^ 1);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NI32; ++i)
@@ -227,10 +258,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       for (int j = 0; j < NJ; ++j) bd[j] = xrow[j * 16];
     };
     read_group(0, a[0], bb[0]);
+    static_assert(NPIECE < WG_BP / 4, "one request task per MFMA group");
 #pragma unroll
     for (int g = 0; g < WG_BP / 4; ++g) {
       const int cur = g & 1;
       if (g + 1 < WG_BP / 4) read_group(g + 1, a[cur ^ 1], bb[cur ^ 1]);
+      // next stage's requests, one piece per group (unconditional, see above); written to LDS after the loop
+      if (g < NPIECE) load_piece(g);
+      if (g == NPIECE) advance_cursor();
       __builtin_amdgcn_sched_barrier(0);      // keep the reads of group g+1 ABOVE the MFMAs of group g (see above)
 #pragma unroll
       for (int i = 0; i < NI; ++i)
@@ -239,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[cur][i], bb[cur][j], acc[i][j], 0, 0, 0);
     }
     }
-    if (more) store_stage(buf ^ 1);
+    if constexpr (!M32) store_stage(buf ^ 1);
     __syncthreads();
   }
   // D (16x16): row (n) = (lane>>4)*4 + reg, col = lane&15; D (32x32): row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31.
@@ -321,13 +356,14 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
 
 using namespace ccvpe;
 
-static int wgrad_splits(int M, int tiles, int taps) {
+static int wgrad_splits(int M, int tiles, int taps, bool big = false) {
   (void)taps;
+  const int maxS = (M + WG_BP * 8 - 1) / (WG_BP * 8);
+  (void)big;   // (128 x 128 tiles: the smallest split that fills a round — S = 1 at level 6 — measured 110 TF against 115.5 with S = 8)
   // ~4 K workgroups: the stage loop is a chain of (global load -> LDS -> 8 MFMAs) with one stage of prefetch, so the
   // narrow layers (1-3 tiles, millions of pixels) need many co-resident workgroups to hide the load latency
   int S = 4096 / (tiles > 0 ? tiles : 1);
   if (S < 1) S = 1;
-  const int maxS = (M + WG_BP * 8 - 1) / (WG_BP * 8);
   if (S > maxS) S = maxS;
   if (S > 1024) S = 1024;
   return S < 1 ? 1 : S;
@@ -371,7 +407,7 @@ extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, in
   const long M = (long)batch * Ho * Wo;
   if (M <= 0 || M > 0x7fffffffL || ctot <= 0 || n <= 0) return CCVPE_EINVAL;
   const int tiles = wgrad_tile_count(n, kh * kw * ctot);
-  const int S = wgrad_splits((int)M, tiles, kh * kw);
+  const int S = wgrad_splits((int)M, tiles, kh * kw, wgrad_big(n, kh * kw * ctot));
   const long fl = (long)S * n * kh * kw * ctot;
   return fl > 0x7fffffffL ? CCVPE_EINVAL : (int)fl;
 }
@@ -382,6 +418,8 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   if (c0 <= 0 || c0 % 4 || c1 < 0 || c1 % 4 || ld0 % 4 || (c1 && ld1 % 4)) return fail(CCVPE_EINVAL, "conv_wgrad: channels/ld %% 4");
   if (c1 > 0 && !src1) return fail(CCVPE_EINVAL, "conv_wgrad: c1>0 but src1 null");
   if (!aligned16(src0) || (src1 && !aligned16(src1)) || !aligned16(dy) || ldy % 4) return fail(CCVPE_EINVAL, "conv_wgrad: alignment");
+  if ((double)batch * in_h * in_w * (double)(ld0 > ld1 ? ld0 : ld1) >= 2147483648.0)
+    return fail(CCVPE_EINVAL, "conv_wgrad: source larger than 2^31 floats (32-bit pixel offsets)");
   WgradParams p;
   p.src0 = src0; p.src1 = src1; p.dy = dy; p.part = scratch;
   p.c0 = c0; p.ld0 = ld0; p.c1 = c1; p.ld1 = ld1;
@@ -393,13 +431,17 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   const long M = (long)batch * p.Ho * p.Wo;
   if (M <= 0 || M > 0x7fffffffL) return fail(CCVPE_EINVAL, "conv_wgrad: bad M");
   p.M = (int)M;
+  p.ablate = 0;
+#ifdef CCVPE_ABLATE
+  p.ablate = getenv("CCVPE_WG_ABLATE") ? atoi(getenv("CCVPE_WG_ABLATE")) : 0;
+#endif
   const int ctot = c0 + c1;
   const bool big = wgrad_big(n, p.taps * ctot);
   const int tn = big ? 128 : wgrad_tn(n, p.taps * ctot);
   const int tcw = big ? 128 : WG_T;
   p.tiles_n = (n + tn - 1) / tn;
   p.tiles_c = (p.taps * ctot + tcw - 1) / tcw;
-  p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps);
+  p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps, big);
   p.pix_per_split = ((p.M + p.S - 1) / p.S + WG_BP - 1) / WG_BP * WG_BP;
   hipStream_t st = (hipStream_t)stream;
   const long blocks = (long)p.tiles_n * p.tiles_c * p.S;

@@ -11,6 +11,8 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 # (batch, hw, N, C, k)
 shapes = [(64, 256, 40, 56, 3), (64, 128, 80, 104, 3), (64, 512, 16, 16, 3), (64, 16, 640, 1344, 3), (64, 64, 160, 200, 3),
           (64, 32, 320, 432, 3), (64, 256, 32, 48, 3), (64, 32, 672, 112, 1), (64, 32, 112, 672, 1)]
+if os.environ.get("PROBE_SHAPE"):
+    shapes = [tuple(int(v) for v in os.environ["PROBE_SHAPE"].split(","))]
 for (b, hw, n, c, k) in shapes:
     x = torch.randn((b, hw, hw, c), device="cuda")
     dy = torch.randn((b, hw, hw, n), device="cuda")
