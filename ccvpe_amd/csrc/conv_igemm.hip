@@ -138,6 +138,7 @@ struct IgemmParams {
   int cpt0, cpt, total_chunks, stages;
   int ldd, ldres, act, out_mode, cout;
   int M;
+  long in_pixels;    // batch * H * W of the sources (igemm_kernel: 32-bit offsets when they are below 4 GB)
   int tiles_n, tiles_total;
   int tiles_x, tiles_y;  // conv3x3: spatial tiles per sample
   // split-K (igemm_kernel only; small-batch GEMMs with a handful of tiles and thousands of K stages): workgroup
@@ -288,11 +289,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  // byte offset of this lane's 16-byte piece inside W, per staged row (rows past the tile / Npad: any valid row, never
+  // stored): stage-invariant, so a W request is (scalar base + stage offset) + this register — no vector ALU work per stage
+  unsigned wrow[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it)
+    wrow[it] = ((unsigned)min(n0 + srow + 64 * it, p.Npad - 1) * (unsigned)p.Kpad + (unsigned)(ssub * E)) * (unsigned)sizeof(T);
   unsigned a_keep = 0;                      // bit `it`: piece `it` of the stage in a_reg is inside the image and the K range
   f32x4 g_r0 = {0.f, 0.f, 0.f, 0.f}, g_r1 = g_r0;   // SE gate of the FIRST staged row's sample (rows of a tile nearly always share it)
   int g_ch = 0;                             // channel of the staged piece, for the rare rows of another sample
   const bool gated = p.gate != nullptr;     // (1x1, single-source convs only)
   const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
+  // both sources below 4 GB (workgroup-uniform): 32-bit byte offsets, one v_mad per piece instead of 64-bit multiply-adds
+  const bool small32 = (double)p.in_pixels * (double)(ld0s > ld1s ? ld0s : ld1s) * sizeof(T) < 4294967296.0;
 
   auto load_stage = [&](int s) {
     const bool kvalid = kc < p.total_chunks;
@@ -306,18 +315,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       const int iy = a_y[it] + ky;
       const int ix = a_x[it] + kx;
       const bool ok = a_ok[it] && kvalid && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-      const int cb = ok ? a_b[it] : 0, cy = ok ? iy : 0, cx = ok ? ix : 0;
-      a_reg[it] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cb * p.H + cy) * p.W + cx) * ld + ch);
+      const int pix = ok ? (a_b[it] * p.H + iy) * p.W + ix : 0;
+      if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)pix * (unsigned)ld + (unsigned)ch) * (unsigned)sizeof(T));
+      else a_reg[it] = *reinterpret_cast<const f32x4*>(base + (size_t)pix * ld + ch);
       a_keep |= ok ? (1u << it) : 0u;
     }
     if (gated) {
       g_ch = ch;
       gate_load<T>(p.gate + (size_t)a_b[0] * p.c0 + ch, g_r0, g_r1);
     }
+    {
+      const char* wb = reinterpret_cast<const char*>(wp) + (size_t)s * (SK * sizeof(T));   // scalar base + per-lane row offset
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);     // rows past the tile / Npad: any valid row (never stored)
-      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + s * SK + ssub * E);
+      for (int it = 0; it < B_IT; ++it) b_reg[it] = *reinterpret_cast<const f32x4*>(wb + wrow[it]);
     }
     kc += CPS;
     r += CPS;
@@ -541,6 +551,8 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
   f32x4 g_r0 = {0.f, 0.f, 0.f, 0.f}, g_r1 = g_r0;
   const bool gated = p.gate != nullptr;
   const int ld0s = sgpr(p.ld0);
+  const unsigned ld0b = (unsigned)ld0s * (unsigned)sizeof(T);
+  const bool small32 = (double)p.M * (double)ld0s * sizeof(T) < 4294967296.0;
   auto load_stage = [&](int m0, int n0, int s) {
     const int kcol = s * KS + pc * E;         // first K element of this thread's piece
     k_ok = kcol < p.c0;
@@ -552,7 +564,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
       const int m = m0 + prow + it * (256 / PPR);
       const bool rok = m < p.M;
       const int mc = rok ? m : p.M - 1;
-      a_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (size_t)mc * ld0s + kc);
+      // 32-bit byte offset when the tensor allows it (workgroup-uniform switch): one v_mad instead of a 64-bit multiply-add
+      if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src0) + ((unsigned)mc * ld0b + (unsigned)kc * (unsigned)sizeof(T)));
+      else a_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (size_t)mc * ld0s + kc);
       row_ok |= rok ? (1u << it) : 0u;
     }
     if (gated) {
@@ -561,11 +575,13 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
       g_kc = kc;
       g_mend = (bf + 1) * hw;
     }
-    const int wkc = kcol < p.Kpad ? kcol : 0;
+    const unsigned wkb = (unsigned)(kcol < p.Kpad ? kcol : 0) * (unsigned)sizeof(T);
+    const unsigned kpb = (unsigned)p.Kpad * (unsigned)sizeof(T);
+    const char* wb = reinterpret_cast<const char*>(wp);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
-      const int nr = min(n0 + prow + it * (256 / PPR), p.Npad - 1);
-      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + wkc);
+      const unsigned nr = (unsigned)min(n0 + prow + it * (256 / PPR), p.Npad - 1);
+      b_reg[it] = *reinterpret_cast<const f32x4*>(wb + (nr * kpb + wkb));      // 32-bit offsets: W is far below 4 GB
     }
   };
   auto store_stage = [&]() {
@@ -1491,8 +1507,14 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
   const int k0end = 4 * p.cpt0;      // chunks belonging to the low-res source
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
+  unsigned wrow[B_IT];                      // stage-invariant byte offset of this lane's W piece per staged row (see igemm_kernel)
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it)
+    wrow[it] = ((unsigned)min(n0 + srow + 64 * it, p.Npad - 1) * (unsigned)p.Kpad + (unsigned)(ssub * E)) * (unsigned)sizeof(T);
   unsigned a_keep = 0;                      // bit `it`: piece `it` in a_reg is inside its image and the K range
   const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
+  // both sources below 4 GB (workgroup-uniform): 32-bit byte offsets, one v_mad per piece instead of 64-bit multiply-adds
+  const bool small32 = (double)p.M * 4.0 * (double)(ld0s > ld1s ? ld0s : ld1s) * sizeof(T) < 4294967296.0;
 
   // (an incrementally advanced cursor instead of the two divisions measured 5 % SLOWER: 96.8 vs 101.6 TF)
   // One unconditional load per piece (STAGING RULE): the source, its geometry and the tap offset are selected per thread
@@ -1520,14 +1542,15 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
     for (int it = 0; it < A_IT; ++it) {
       const int iy = mul * a_y[it] + dy, ix = mul * a_x[it] + dx;
       const bool ok = a_ok[it] && kvalid && (unsigned)iy < (unsigned)hh && (unsigned)ix < (unsigned)ww;
-      const int cb = ok ? a_b[it] : 0, cy = ok ? iy : 0, cx = ok ? ix : 0;
-      a_reg[it] = *reinterpret_cast<const f32x4*>(base + ((size_t)(cb * hh + cy) * ww + cx) * ld + ch);
+      const int pix = ok ? (a_b[it] * hh + iy) * ww + ix : 0;
+      if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + ((unsigned)pix * (unsigned)ld + (unsigned)ch) * (unsigned)sizeof(T));
+      else a_reg[it] = *reinterpret_cast<const f32x4*>(base + (size_t)pix * ld + ch);
       a_keep |= ok ? (1u << it) : 0u;
     }
+    {
+      const char* wb = reinterpret_cast<const char*>(wp) + (size_t)s * (SK * sizeof(T));   // scalar base + per-lane row offset
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);
-      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + s * SK + ssub * E);
+      for (int it = 0; it < B_IT; ++it) b_reg[it] = *reinterpret_cast<const f32x4*>(wb + wrow[it]);
     }
   };
   auto store_stage = [&](int buf) {
@@ -1688,13 +1711,15 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   f32x4 h_reg[H_IT], b_reg[B_IT], a_reg[A_IT];
   unsigned h_keep = 0, a_keep = 0;          // validity bits of the pieces in h_reg / a_reg, applied at the LDS store
   const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
+  const bool small32 = (double)p.M * 4.0 * (double)(ld0s > ld1s ? ld0s : ld1s) * sizeof(T) < 4294967296.0;   // 32-bit byte offsets
   auto load_halo = [&](int chunk) {         // raw loads from clamped addresses (STAGING RULE)
     h_keep = 0;
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
       const int ch = chunk * SK + h_sub[it] * E;
       const bool ok = h_pix[it] >= 0 && ch < p.c0;
-      h_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (ok ? (size_t)h_pix[it] * ld0s + ch : 0));
+      if (small32) h_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src0) + (ok ? ((unsigned)h_pix[it] * (unsigned)ld0s + (unsigned)ch) * (unsigned)sizeof(T) : 0u));
+      else h_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (ok ? (size_t)h_pix[it] * ld0s + ch : 0));
       h_keep |= ok ? (1u << it) : 0u;
     }
   };
@@ -1703,13 +1728,15 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     for (int it = 0; it < H_IT; ++it)
       if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(&Us[0][0] + h_off[it]) = keep_if(h_reg[it], (h_keep >> it) & 1u);
   };
-  auto load_w = [&](int kcol, bool ok) {        // kcol: first K column of this 64-byte piece row
-    const int kc = ok ? kcol : 0;               // (a piece beyond the channel range meets a zeroed activation piece)
+  unsigned wrow[B_IT];                          // stage-invariant byte offset of the staged W rows (see igemm_kernel)
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it) {
-      const int nr = min(n0 + srow + 64 * it, p.Npad - 1);
-      b_reg[it] = *reinterpret_cast<const f32x4*>(wp + (size_t)nr * p.Kpad + kc);
-    }
+  for (int it = 0; it < B_IT; ++it)
+    wrow[it] = (unsigned)min(n0 + srow + 64 * it, p.Npad - 1) * (unsigned)p.Kpad * (unsigned)sizeof(T);
+  auto load_w = [&](int kcol, bool ok) {        // kcol: first K column of this lane's 16-byte piece
+    const unsigned kb = (unsigned)(ok ? kcol : 0) * (unsigned)sizeof(T);   // (a piece beyond the channel range meets a zeroed activation piece)
+    const char* wb = reinterpret_cast<const char*>(wp);
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it) b_reg[it] = *reinterpret_cast<const f32x4*>(wb + (wrow[it] + kb));
   };
   auto store_w = [&](int buf) {
 #pragma unroll
@@ -1815,8 +1842,9 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
       for (int it = 0; it < A_IT; ++it) {
         const int iy = a_yy[it] + ky, ix = a_xx[it] + kx;
         const bool ok = kvalid && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
-        const int cy = ok ? iy : 0, cx = ok ? ix : 0;
-        a_reg[it] = *reinterpret_cast<const f32x4*>(src1 + ((size_t)(b * H2 + cy) * W2 + cx) * ld1s + ch);
+        const int pix = ok ? (b * H2 + iy) * W2 + ix : 0;
+        if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src1) + ((unsigned)pix * (unsigned)ld1s + (unsigned)ch) * (unsigned)sizeof(T));
+        else a_reg[it] = *reinterpret_cast<const f32x4*>(src1 + (size_t)pix * ld1s + ch);
         a_keep |= ok ? (1u << it) : 0u;
       }
     };
@@ -1959,6 +1987,7 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   p.out_f32 = out_f32;
   p.c0 = d->c0; p.ld0 = d->ld0; p.c1 = d->c1; p.ld1 = d->ld1;
   p.H = d->in_h; p.W = d->in_w;
+  p.in_pixels = (long)d->batch * d->in_h * d->in_w;
   p.Ho = (d->in_h + 2 * d->pad - d->kh) / d->stride + 1;
   p.Wo = (d->in_w + 2 * d->pad - d->kw) / d->stride + 1;
   p.kw = d->kw; p.stride = d->stride; p.pad = d->pad;
