@@ -185,3 +185,41 @@ extern "C" int ccvpe_adam_step_f32(const void* table, const float* hyper, const 
                      hyper, chunk_tensor, chunk_off, grad_scale);
   return check_launch("adam_kernel");
 }
+
+// ---------------------------------------------------------------------------------------------
+// Many small device-to-device copies in one launch (gradients -> their slots of the flat all-reduce arena,
+// ccvpe_amd/harness.py): ~420 tensors per training step, most of them BatchNorm / bias / SE vectors of 16-1280 floats; as
+// individual copies they were 420 launches and 1.9 ms of kernel time per step.  Pointers travel BY VALUE in the kernel
+// arguments (no table upload): up to CCVPE_MULTI_COPY_MAX tensors per launch, the host entry point loops.
+// ---------------------------------------------------------------------------------------------
+namespace ccvpe {
+constexpr int MC_MAX = 96, MC_CHUNKS = 16;
+struct MultiCopyArgs {
+  const float* src[MC_MAX];
+  float* dst[MC_MAX];
+  int n[MC_MAX];
+};
+__global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyArgs a) {
+  const int t = blockIdx.y;
+  const float* __restrict__ s = a.src[t];
+  float* __restrict__ d = a.dst[t];
+  const int n = a.n[t];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += MC_CHUNKS * 256) d[i] = s[i];
+}
+}  // namespace ccvpe
+
+extern "C" int ccvpe_multi_copy_f32(const void* const* srcs, void* const* dsts, const int* counts, int n, void* stream) {
+  if (n < 0 || (n > 0 && (!srcs || !dsts || !counts))) return fail(CCVPE_EINVAL, "multi_copy: bad arguments");
+  for (int i0 = 0; i0 < n; i0 += ccvpe::MC_MAX) {
+    ccvpe::MultiCopyArgs a;
+    const int m = n - i0 < ccvpe::MC_MAX ? n - i0 : ccvpe::MC_MAX;
+    for (int i = 0; i < m; ++i) {
+      if (counts[i0 + i] < 0 || !srcs[i0 + i] || !dsts[i0 + i]) return fail(CCVPE_EINVAL, "multi_copy: bad entry %d", i0 + i);
+      a.src[i] = static_cast<const float*>(srcs[i0 + i]);
+      a.dst[i] = static_cast<float*>(dsts[i0 + i]);
+      a.n[i] = counts[i0 + i];
+    }
+    hipLaunchKernelGGL(ccvpe::multi_copy_kernel, dim3(ccvpe::MC_CHUNKS, m), dim3(256), 0, (hipStream_t)stream, a);
+  }
+  return check_launch("multi_copy_kernel");
+}

@@ -205,6 +205,9 @@ int ccvpe_head_conv3x3_f32(const float* x, const float* w, const float* bias, fl
 int ccvpe_softmax_rows_f32(const float* logits, float* out, int rows, int n, void* stream);
 /* bf16 -> fp32 widening of an activation tensor (n_elems % 8 == 0, 16-byte aligned): the bf16 storage path runs its last
  * localisation-decoder levels through the fp32 kernels (models.py:299-320 decide the heat-map arg-max). */
+/* n device-to-device copies of fp32 vectors (counts[i] floats from srcs[i] to dsts[i]) in ceil(n / 96) launches; the three
+ * arrays are HOST arrays, read before the call returns.  Gradients -> slots of the flat all-reduce arena (harness.py). */
+int ccvpe_multi_copy_f32(const void* const* srcs, void* const* dsts, const int* counts, int n, void* stream);
 int ccvpe_cast_bf16_f32(const void* src, float* dst, long n_elems, void* stream);
 
 /* -------------------------------------------------------------------------------------------

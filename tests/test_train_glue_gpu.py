@@ -108,3 +108,21 @@ def test_targets_angle_wrap():
     for l in labs:
         assert torch.equal(l[0], l[1]) and torch.equal(l[2], l[3])
         assert float(l[0].sum()) > 0
+
+
+def test_multi_copy_many_small_vectors():
+    """ccvpe_multi_copy_f32 (gradients -> all-reduce arena slots): 230 vectors of ragged sizes, more than one launch batch."""
+    from ccvpe_amd import harness
+    g = torch.Generator().manual_seed(5)
+    sizes = [int(torch.randint(1, 3000, (1,), generator=g)) for _ in range(229)] + [65536]
+    srcs = [torch.randn((n,), generator=g).cuda() for n in sizes]
+    flat = torch.full((sum(sizes) + 7,), -1.0, device="cuda")
+    views, off = [], 3
+    for n in sizes:
+        views.append(flat[off:off + n])
+        off += n
+    harness._multi_copy([(s_.data_ptr(), v.data_ptr(), n) for s_, v, n in zip(srcs, views, sizes)])
+    torch.cuda.synchronize()
+    for s_, v in zip(srcs, views):
+        assert torch.equal(s_, v)
+    assert bool((flat[:3] == -1).all()) and bool((flat[off:] == -1).all())      # nothing written outside the slots

@@ -12,7 +12,7 @@ cd /tmp
 F32="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
 BF1="python3 $R/bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
 BF2="python3 $R/bench.py --precision bf16 --model vigor20 --batch 32 --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
-TRN="python3 $R/bench.py --train --model vigor20 --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events"
+TRN="python3 $R/bench.py --train --model vigor20 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f32 -o f32 -- $F32 > $OUT/f32.json 2> $OUT/f32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bf16_c1 -o bf16_c1 -- $BF1 > $OUT/bf16_c1.json 2> $OUT/bf16_c1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bf16_c2 -o bf16_c2 -- $BF2 > $OUT/bf16_c2.json 2> $OUT/bf16_c2.err
