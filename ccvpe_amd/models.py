@@ -414,13 +414,19 @@ class _CVMBase(nn.Module):
             if g is not None and g[0] == where:
                 g[1].replay()
                 self._pack_cache = g[2]
-            elif getattr(self, "_pack_where", None) == where:
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    pk = pack()
-                graph.replay()
-                self._pack_graph = (where, graph, pk)
-                self._pack_cache = pk
+            elif getattr(self, "_pack_where", None) == where and not getattr(self, "_pack_graph_failed", False):
+                # thread_local capture mode: the RCCL watchdog thread of a data-parallel job keeps polling events while this
+                # thread captures; a capture that fails for any reason leaves the eager path in charge for good
+                try:
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                        pk = pack()
+                    graph.replay()
+                    self._pack_graph = (where, graph, pk)
+                    self._pack_cache = pk
+                except Exception:                                   # noqa: BLE001
+                    self._pack_graph, self._pack_graph_failed = None, True
+                    self._pack_cache = pack()
             else:
                 self._pack_graph = None
                 self._pack_where = where
