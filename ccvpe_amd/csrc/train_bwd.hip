@@ -10,6 +10,7 @@
 // an elementwise apply that recomputes g.  The residual branch's gradient is dv itself (no kernel).
 // swish'(z) = s*(1 + z*(1-s)), s = sigmoid(z)   (efficientnet_pytorch/utils.py:71-75).
 #include "common.h"
+#include <type_traits>
 
 namespace ccvpe {
 
@@ -54,6 +55,37 @@ __device__ __forceinline__ void bn_bwd_g(const BnBwdParams& p, int b, size_t off
   }
 }
 
+// The same arithmetic for the two streaming kernels below, shaped for memory-level parallelism: the activation is a
+// compile-time constant (a runtime `act` inside the element loop is a scalar compare + branch per value), the per-(sample,
+// channel) gate / mean-branch vectors are loaded once per channel group instead of once per row, and the row loop handles
+// two rows per trip with their four loads issued together (one row per trip = one load in flight per thread).
+template <int ACT>
+__device__ __forceinline__ float act_grad_t(float z) {
+  if (ACT == CCVPE_ACT_SWISH) {
+    const float s = sigmoidf(z);
+    return s * (1.0f + z * (1.0f - s));
+  }
+  if (ACT == CCVPE_ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  return 1.f;
+}
+template <int ACT>
+__device__ __forceinline__ void bn_bwd_g_t(f32x4 xv, f32x4 du, const f32x4& gatev, const f32x4& dmeanv, const f32x4& mu,
+                                           const f32x4& istd, const f32x4& ga, const f32x4& be, float dcs, f32x4& g, f32x4& xh) {
+  du = du * gatev + dmeanv;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    xh[j] = (xv[j] - mu[j]) * istd[j];
+    const float z = xh[j] * ga[j] + be[j];
+    g[j] = du[j] * dcs * act_grad_t<ACT>(z);
+  }
+}
+#define CCVPE_BN_ACT_DISPATCH(act, body)                                              \
+  do {                                                                                \
+    if ((act) == CCVPE_ACT_SWISH) body(std::integral_constant<int, CCVPE_ACT_SWISH>{});       \
+    else if ((act) == CCVPE_ACT_RELU) body(std::integral_constant<int, CCVPE_ACT_RELU>{});    \
+    else body(std::integral_constant<int, CCVPE_ACT_NONE>{});                         \
+  } while (0)
+
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p, float* __restrict__ part /*[B*nblk][2][C]*/) {
   extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx][2] float4
   const int b = blockIdx.y;
@@ -78,12 +110,36 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const BnBwdParams p,
       f32x4 istd;
 #pragma unroll
       for (int j = 0; j < 4; ++j) istd[j] = 1.0f / sqrtf(vv[j] + p.eps);
-      for (int r = r0 + pl; r < r1; r += P) {
-        f32x4 g, xh;
-        bn_bwd_g(p, b, ((size_t)b * p.rows_per_sample + r) * p.C + c, c, mu, istd, ga, be, dcs, g, xh);
-        s0 += g;
-        s1 += g * xh;
-      }
+      const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 gatev = p.gate ? *reinterpret_cast<const f32x4*>(p.gate + (size_t)b * p.C + c) : one4;
+      const f32x4 dmeanv = p.dmean ? *reinterpret_cast<const f32x4*>(p.dmean + (size_t)b * p.C + c) : zero4;
+      const float* __restrict__ xb = p.x + ((size_t)b * p.rows_per_sample) * p.C + c;
+      const float* __restrict__ db_ = p.dv + ((size_t)b * p.rows_per_sample) * p.C + c;
+      auto rows = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        int r = r0 + pl;
+        for (; r + P < r1; r += 2 * P) {
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C);
+          const f32x4 da = *reinterpret_cast<const f32x4*>(db_ + (size_t)r * p.C);
+          const f32x4 xc = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + P) * p.C);
+          const f32x4 dc = *reinterpret_cast<const f32x4*>(db_ + (size_t)(r + P) * p.C);
+          f32x4 g, xh, g2, xh2;
+          bn_bwd_g_t<ACT>(xa, da, gatev, dmeanv, mu, istd, ga, be, dcs, g, xh);
+          bn_bwd_g_t<ACT>(xc, dc, gatev, dmeanv, mu, istd, ga, be, dcs, g2, xh2);
+          s0 += g;
+          s1 += g * xh;
+          s0 += g2;
+          s1 += g2 * xh2;
+        }
+        if (r < r1) {
+          f32x4 g, xh;
+          bn_bwd_g_t<ACT>(*reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C), *reinterpret_cast<const f32x4*>(db_ + (size_t)r * p.C),
+                          gatev, dmeanv, mu, istd, ga, be, dcs, g, xh);
+          s0 += g;
+          s1 += g * xh;
+        }
+      };
+      CCVPE_BN_ACT_DISPATCH(p.act, rows);
     }
     f32x4* red4 = reinterpret_cast<f32x4*>(red);
     if (pl < P) {
@@ -129,12 +185,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const BnBwdParams p, 
       f32x4 istd;
 #pragma unroll
       for (int j = 0; j < 4; ++j) istd[j] = 1.0f / sqrtf(vv[j] + p.eps);
-      for (int r = r0 + pl; r < r1; r += P) {
-        const size_t off = ((size_t)b * p.rows_per_sample + r) * p.C + c;
-        f32x4 g, xh;
-        bn_bwd_g(p, b, off, c, mu, istd, ga, be, dcs, g, xh);
-        *reinterpret_cast<f32x4*>(dx + off) = ga * istd * (g - db - xh * dg);
-      }
+      const f32x4 one4 = {1.f, 1.f, 1.f, 1.f}, zero4 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4 gatev = p.gate ? *reinterpret_cast<const f32x4*>(p.gate + (size_t)b * p.C + c) : one4;
+      const f32x4 dmeanv = p.dmean ? *reinterpret_cast<const f32x4*>(p.dmean + (size_t)b * p.C + c) : zero4;
+      const size_t base = ((size_t)b * p.rows_per_sample) * p.C + c;
+      const float* __restrict__ xb = p.x + base;
+      const float* __restrict__ dvb = p.dv + base;
+      float* __restrict__ dxb = dx + base;
+      const f32x4 k = ga * istd;
+      auto rows = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        int r = r0 + pl;
+        for (; r + P < r1; r += 2 * P) {
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C);
+          const f32x4 da = *reinterpret_cast<const f32x4*>(dvb + (size_t)r * p.C);
+          const f32x4 xc = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + P) * p.C);
+          const f32x4 dc = *reinterpret_cast<const f32x4*>(dvb + (size_t)(r + P) * p.C);
+          f32x4 g, xh, g2, xh2;
+          bn_bwd_g_t<ACT>(xa, da, gatev, dmeanv, mu, istd, ga, be, dcs, g, xh);
+          bn_bwd_g_t<ACT>(xc, dc, gatev, dmeanv, mu, istd, ga, be, dcs, g2, xh2);
+          *reinterpret_cast<f32x4*>(dxb + (size_t)r * p.C) = k * (g - db - xh * dg);
+          *reinterpret_cast<f32x4*>(dxb + (size_t)(r + P) * p.C) = k * (g2 - db - xh2 * dg);
+        }
+        if (r < r1) {
+          f32x4 g, xh;
+          bn_bwd_g_t<ACT>(*reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C), *reinterpret_cast<const f32x4*>(dvb + (size_t)r * p.C),
+                          gatev, dmeanv, mu, istd, ga, be, dcs, g, xh);
+          *reinterpret_cast<f32x4*>(dxb + (size_t)r * p.C) = k * (g - db - xh * dg);
+        }
+      };
+      CCVPE_BN_ACT_DISPATCH(p.act, rows);
     }
   }
 }

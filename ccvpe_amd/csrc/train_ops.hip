@@ -42,7 +42,18 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
       const f32x4 pivot = *reinterpret_cast<const f32x4*>(xc + (r0 + rr) * C);
       f32x4 s = {0.f, 0.f, 0.f, 0.f}, q = s;
       float cnt = 0.f;
-      for (long r = r0 + rr; r < r1; r += R) {
+      long r = r0 + rr;
+      for (; r + 3L * R < r1; r += 4L * R) {           // four rows per trip: four loads in flight per thread, fixed order
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(xc + r * C);
+        const f32x4 v1 = *reinterpret_cast<const f32x4*>(xc + (r + R) * C);
+        const f32x4 v2 = *reinterpret_cast<const f32x4*>(xc + (r + 2L * R) * C);
+        const f32x4 v3 = *reinterpret_cast<const f32x4*>(xc + (r + 3L * R) * C);
+        const f32x4 d0 = v0 - pivot, d1 = v1 - pivot, d2 = v2 - pivot, d3 = v3 - pivot;
+        s += (d0 + d1) + (d2 + d3);
+        q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        cnt += 4.f;
+      }
+      for (; r < r1; r += R) {
         const f32x4 d = *reinterpret_cast<const f32x4*>(xc + r * C) - pivot;
         s += d;
         q += d * d;
@@ -180,9 +191,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
         sc[j] = ga[j] / sqrtf(vv[j] + eps);
         sh[j] = be[j] - mu[j] * sc[j];
       }
-      for (int r = r0 + pl; r < r1; r += P) {
-        const size_t off = ((size_t)b * rows_per_sample + r) * C + c;
-        f32x4 v = *reinterpret_cast<const f32x4*>(x + off) * sc + sh;
+      auto one = [&](size_t off, f32x4 xv, f32x4 rv) {
+        f32x4 v = xv * sc + sh;
         if (act == CCVPE_ACT_SWISH) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
@@ -191,9 +201,23 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ x
           for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
         }
         v *= dcs;
-        if (residual) v += *reinterpret_cast<const f32x4*>(residual + off);
+        if (residual) v += rv;
         *reinterpret_cast<f32x4*>(y + off) = v;
         sum += v;
+      };
+      const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+      int r = r0 + pl;
+      for (; r + P < r1; r += 2 * P) {                 // two rows per trip: their loads are issued together
+        const size_t o0 = ((size_t)b * rows_per_sample + r) * C + c, o1 = o0 + (size_t)P * C;
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(x + o0), x1 = *reinterpret_cast<const f32x4*>(x + o1);
+        const f32x4 q0 = residual ? *reinterpret_cast<const f32x4*>(residual + o0) : zero4;
+        const f32x4 q1 = residual ? *reinterpret_cast<const f32x4*>(residual + o1) : zero4;
+        one(o0, x0, q0);
+        one(o1, x1, q1);
+      }
+      if (r < r1) {
+        const size_t o0 = ((size_t)b * rows_per_sample + r) * C + c;
+        one(o0, *reinterpret_cast<const f32x4*>(x + o0), residual ? *reinterpret_cast<const f32x4*>(residual + o0) : zero4);
       }
     }
     if (se_partial) {
