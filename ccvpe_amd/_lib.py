@@ -53,6 +53,7 @@ PROTOTYPES = {
     "ccvpe_multi_copy_f32": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p]),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
+    "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "ccvpe_upconv3x3_f32": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
@@ -136,7 +137,7 @@ weights_epoch = 0
 
 def build(verbose=False):
     """Compile libccvpe_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    cmd = ["make", "-C", CSRC_DIR, "-j4"]
+    cmd = ["make", "-C", CSRC_DIR, "-j8"]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or res.returncode != 0:
         print(res.stdout)

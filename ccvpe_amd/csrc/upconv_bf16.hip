@@ -1,0 +1,3 @@
+// folded deconv + 3x3 kernels, bf16 storage (upconv_impl.h).
+#include "upconv_impl.h"
+extern "C" int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* d, void* stream) { return ccvpe::upconv_any<ccvpe::bf16_t>(d, stream); }

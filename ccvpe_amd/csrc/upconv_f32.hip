@@ -1,0 +1,3 @@
+// folded deconv + 3x3 kernels, fp32 (upconv_impl.h).
+#include "upconv_impl.h"
+extern "C" int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* d, void* stream) { return ccvpe::upconv_any<float>(d, stream); }

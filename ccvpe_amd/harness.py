@@ -127,13 +127,17 @@ class GradientAllReducer:
         self._flat = None
         self._arena = None
         self._done_in_backward = False
-        self.allreduce_calls = 0              # collectives issued so far (tests / diagnostics)
+        self.allreduce_calls = 0              # collectives issued so far (tests / diagnostics / bench.py's config.collective)
+        self.bytes_reduced_last_step = 0      # payload bytes handed to all-reduce by the last arena step
 
     # ---- arena mode: reduce inside the model's backward -------------------------------------------------
     def attach(self, model, optimizer=None):
         """Build the flat gradient arena for `model` (a ccvpe_amd CVM_* module) and register with it: its backward then
-        calls begin() / ready() (after each of the three gradient groups) / finish().  `optimizer`: a
-        ccvpe_amd.optim.Adam whose grad_scale absorbs the 1/world when the backend cannot average in the collective."""
+        calls begin() / ready() (after each of the three gradient groups) / finish().  After finish() every `p.grad` holds
+        the MEAN over the ranks, whatever the backend: RCCL averages inside the collective (ncclAvg); a backend that can
+        only SUM (gloo, a build without ncclAvg) gets one in-place 1/world pass over the reduced slice (~230 MB, once per
+        step) — the scale is NOT deferred to the optimizer, so clipping / logging between backward() and step() see the
+        same numbers on every backend.  `optimizer` is accepted for source compatibility and not touched."""
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and "._fc." not in n]
         named.sort(key=lambda np_: grad_group(np_[0]))           # stable: keeps parameter order inside a group
         off, slots, bounds = 0, {}, [[None, None] for _ in range(3)]
@@ -158,8 +162,11 @@ class GradientAllReducer:
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def arena_ok(self):
-        """The arena path needs fresh gradients (p.grad None, or still this arena's view from an earlier step that the
-        caller zeroed): accumulation across several backward passes goes through autograd's own accumulation instead."""
+        """The arena path needs FRESH gradients: every p.grad is None (`zero_grad(set_to_none=True)`, torch's default).
+        Any live .grad — including this arena's own view from the previous step, which may or may not have been zeroed —
+        means the caller may be accumulating over several backward passes: that step goes through autograd's own
+        accumulation and the caller's `reducer()` after backward() averages it with the bucketed path (no overlap).
+        begin_fallback() is what the backward calls in that case."""
         if self._arena is None:
             return False
         for n, (o, cnt, shp, g, p) in self._arena["slots"].items():
@@ -167,10 +174,15 @@ class GradientAllReducer:
                 return False
         return True
 
+    def begin_fallback(self):
+        """The backward of this step did NOT reduce (arena bypassed): the next reducer() call must do the work."""
+        self._done_in_backward = False
+
     def begin(self):
         self._pending, self._sent = [], set()
         self._done_in_backward = False
         self._group = 0
+        self.bytes_reduced_last_step = 0
 
     def ready(self, grads):
         """Called by the backward after each gradient group with the dict of gradients finished so far.  Arena mode:
@@ -213,20 +225,17 @@ class GradientAllReducer:
         if self.active():
             work, scale = _allreduce_mean(ar["flat"][lo:hi])
             self.allreduce_calls += 1
+            self.bytes_reduced_last_step += (hi - lo) * 4
             self._pending.append((work, scale, ar["flat"][lo:hi], None, None))
 
     def finish(self, grads):
         """Wait for the collectives; arena mode: hand the arena views to the parameters as their .grad and drop those
         entries from `grads` (nothing is returned to autograd for them)."""
-        opt = getattr(self, "_optimizer", None)
         for work, scale, flat, names, shapes in self._pending:
             if work is not None:
                 work.wait()
             if scale != 1.0:
-                if opt is not None and self._arena is not None and hasattr(opt, "grad_scale"):
-                    opt.grad_scale = scale               # folded into the Adam kernel's gradient load
-                else:
-                    flat.mul_(scale)
+                flat.mul_(scale)                         # SUM backends: p.grad is the mean here too (see attach)
             if names is not None:
                 off = 0
                 for n, shp in zip(names, shapes):
@@ -289,15 +298,18 @@ class _GlobalRatio(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loss_local, den_local, group):
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        pair = torch.stack([loss_local.detach().reshape(()) * den_local.detach().reshape(()), den_local.detach().reshape(())])
+        den = den_local.detach().reshape(())
+        # a rank whose shard carries no label mass has loss_local = 0/0: its numerator is 0, not NaN * 0
+        num = torch.where(den > 0, loss_local.detach().reshape(()) * den, torch.zeros_like(den))
+        pair = torch.stack([num, den])
         if world > 1:
             dist.all_reduce(pair, op=dist.ReduceOp.SUM, group=group)
-        ctx.save_for_backward(den_local.detach().reshape(()) * float(world) / pair[1])
+        ctx.save_for_backward(den * float(world) / pair[1])
         return pair[0] / pair[1]
 
     @staticmethod
     def backward(ctx, g):
-        (k,) = ctx.saved_tensors
+        (k,) = ctx.saved_tensors          # 0 on a rank without label mass: its local ratio (0/0) contributes nothing
         return g * k, None, None
 
 

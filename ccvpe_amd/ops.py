@@ -73,6 +73,23 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+ROUTE_FAMILIES = {0: "igemm", 1: "pw_gemm", 2: "conv3x3"}
+
+
+def conv_route(desc, is_bf16, out_f32=False):
+    """(family, MT, NT, WN) of the kernel ccvpe_conv_igemm_f32 / _bf16 runs for `desc` (ccvpe_conv_igemm_route: the
+    library's own dispatch, nothing is launched)."""
+    r = _lib.load().ccvpe_conv_igemm_route(ctypes.byref(desc), int(bool(is_bf16)), int(bool(out_f32)))
+    if r < 0:
+        check(int(r), "ccvpe_conv_igemm_route")
+    return ROUTE_FAMILIES[r & 0xff], (r >> 8) & 0xf, (r >> 12) & 0xf, (r >> 16) & 0xf
+
+
+def conv_route_name(desc, is_bf16, out_f32=False, f32_names=False):
+    fam, mt, nt, wn = conv_route(desc, is_bf16, out_f32)
+    return "%s_f32_kernel<%d,%d,%d>" % (fam, mt, nt, wn)
+
+
 def _ptr(t):
     if t is None:
         return None
@@ -96,7 +113,7 @@ def _act_dtype(t):
 
 def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1, pad=0,
                src1=None, c1=0, gate=None, scale=None, shift=None, residual=None, act=ACT_NONE,
-               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None, algo_k=None, out_f32=False):
+               out_mode=OUT_NHWC, dst=None, ldd=None, ld0=None, ld1=None, algo_k=None, out_f32=False, route_only=False):
     """Implicit-GEMM conv / deconv / linear (ccvpe_conv_igemm_f32 / _bf16 by src0.dtype).
     src tensors are NHWC.  out_f32 (bf16 only): write an fp32 result."""
     lib = _lib.load()
@@ -132,6 +149,8 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     d.ldd = ldd
     d.ldres = residual.shape[-1] if residual is not None else 0
     d.act, d.out_mode = act, out_mode
+    if route_only:        # (family, MT, NT, WN) the one-pass entry point would run for this call; nothing is launched
+        return conv_route(d, dt != torch.float32, bool(out_f32))
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
     want = lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), int(dt != torch.float32)) if SPLIT_K else 0
@@ -158,12 +177,10 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         esz = 4.0 if dt == torch.float32 else 2.0
         nbytes = esz * (batch * in_h * in_w * (c0 + c1) + m * n + n * k_alg
                         + (m * n if residual is not None else 0))
-        is3x3 = (kh == 3 and kw == 3 and stride == 1 and pad == 1 and out_mode == OUT_NHWC and gate is None)
-        name = igemm_tile(n, is3x3)
-        if (want <= 0 and kh == 1 and kw == 1 and stride == 1 and pad == 0 and src1 is None and out_mode == OUT_NHWC
-                and act not in (ACT_RELU, ACT_RELU_MASK) and n > 48):
-            name = name.replace("igemm_f32_kernel<", "pw_gemm_f32_kernel<")      # mirrors is_pw in conv_igemm_any()
-            name = name.replace("pw_gemm_f32_kernel<4,5,1>", "pw_gemm_f32_kernel<4,3,2>")
+        if want > 0:      # split-K: always the generic gather kernel with the tile pick_cfg() chose
+            name = igemm_tile(n, False)
+        else:             # ask the library which kernel it ran (no Python mirror of the dispatch rules)
+            name = conv_route_name(d, dt != torch.float32, bool(out_f32), f32_names=True)
         if dt != torch.float32:
             name = name.replace("_f32_kernel<", "_kernel<bf16,")
         rec.end(name, "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)

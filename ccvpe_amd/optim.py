@@ -25,7 +25,7 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False))
         self._layout = None
-        self.grad_scale = 1.0        # set by harness.GradientAllReducer when the all-reduce left a SUM in the gradients
+        self.grad_scale = 1.0        # caller-set multiplier applied to every gradient inside the update kernel (e.g. loss scaling)
 
     # ---- static launch geometry: rebuilt only when the parameter set changes --------------------------------
     def _build_layout(self):

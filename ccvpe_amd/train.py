@@ -424,6 +424,8 @@ class CVMFunction(torch.autograd.Function):
                 grads = backward_train(model, tape, gout, on_ready=sync.ready)
                 sync.finish(grads)
             else:
+                if sync is not None:
+                    sync.begin_fallback()       # this step was NOT reduced in the backward: the caller's reducer() must do it
                 grads = backward_train(model, tape, gout)
         live = tape["live"]
         ctx.tape = None

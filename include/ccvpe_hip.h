@@ -94,6 +94,13 @@ int ccvpe_conv_igemm_f32(const ccvpe_conv_desc* desc, void* stream);
  *       (call ccvpe_conv_igemm_* instead); negative = error.
  *   ccvpe_conv_igemm_splitk_f32 / _bf16: same contract as ccvpe_conv_igemm_f32 / _bf16, with that scratch. */
 int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* desc, int is_bf16);
+/* Which kernel the one-pass entry points (ccvpe_conv_igemm_f32 / _bf16) run for `desc`; launches nothing.  Returns
+ * CCVPE_ROUTE_* | MT << 8 | NT << 12 | WN << 16 (workgroup tile = 16*MT*(4/WN) pixels x 16*NT*WN channels), or a negative
+ * error code.  For tests ("did this shape reach the pointwise kernel?") and for bench.py's per-kernel accounting. */
+#define CCVPE_ROUTE_IGEMM 0   /* generic gather kernel */
+#define CCVPE_ROUTE_PW_GEMM 1 /* deep-stage pointwise kernel (1x1, stride 1, one source) */
+#define CCVPE_ROUTE_CONV3X3 2 /* LDS-halo 3x3 kernel */
+int ccvpe_conv_igemm_route(const ccvpe_conv_desc* desc, int is_bf16, int out_f32);
 int ccvpe_conv_igemm_splitk_f32(const ccvpe_conv_desc* desc, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------

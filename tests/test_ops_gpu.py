@@ -66,9 +66,9 @@ def test_igemm_1x1_all_tile_configs(ops, cin, cout):
 
 
 @pytest.mark.parametrize("cin,cout,ldd", [(112, 126, 128), (1280, 126, 128), (200, 36, 40), (16, 24, 24)])
-def test_pointwise_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd):
-    """pw_gemm_kernel: several M tiles + M tail, K not a multiple of the 256-byte stage, N not a multiple of 16 written
-    into wider rows (the fused ground-descriptor conv: N = 126, ldd = 128), residual rows read with 16-byte loads."""
+def test_generic_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd):
+    """GENERIC igemm kernel (ReLU keeps a 1x1 conv away from pw_gemm_kernel, as in the model's fused ground-descriptor
+    conv: N = 126, ldd = 128): several M tiles + M tail, ragged N written into wider rows, residual rows."""
     b, h, w = 3, 19, 23                                  # M = 1311
     x = synth.normal((b, cin, h, w), 410 + cin)
     wt = synth.normal((cout, cin, 1, 1), 420 + cout, (1.0 / cin) ** 0.5)
@@ -78,11 +78,66 @@ def test_pointwise_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd):
     resp[..., :cout] = nhwc(res)
     want = torch.relu(F.conv2d(x, wt) + sh.view(1, -1, 1, 1)) + res
     dst = torch.full((b, h, w, ldd), -7.0, device="cuda")
-    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, batch=b, in_h=h, in_w=w, shift=dev(sh),
-                         act=ops.ACT_RELU, residual=dev(resp), dst=dst, ldd=ldd)
-    close(nchw(got[..., :cout]), want, 1e-4, "pw ragged %d->%d" % (cin, cout))
+    kw = dict(batch=b, in_h=h, in_w=w, shift=dev(sh), act=ops.ACT_RELU, residual=dev(resp), dst=dst, ldd=ldd)
+    assert ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, route_only=True, **kw)[0] == "igemm"
+    got = ops.conv_igemm(dev(nhwc(x)), cin, dev(pack_conv(wt)), cout, **kw)
+    close(nchw(got[..., :cout]), want, 1e-4, "generic ragged %d->%d" % (cin, cout))
     if ldd > cout:
         assert float((got[..., cout:] + 7.0).abs().max()) == 0.0, "columns beyond N were written"
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+@pytest.mark.parametrize("act", ["none", "swish"])
+@pytest.mark.parametrize("cin,cout,ldd,with_res", [(112, 126, 128, True), (1280, 126, 128, False), (200, 70, 72, True),
+                                                    (72, 50, 56, True), (96, 101, 104, False), (40, 242, 248, True)])
+def test_pw_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd, with_res, act, dtype):
+    """pw_gemm_kernel proper (the route is ASSERTED: 1x1, stride 1, one source, act NONE / SWISH, N > 48): N % 4 != 0 and
+    N % 8 != 0 (the `full == false` element tail of its 16-byte residual / store path, fp32 and bf16), K not a multiple of
+    the 128-byte stage, several M tiles + an M tail, output and residual rows wider than N (ldd > N)."""
+    b, h, w = 3, 19, 23                                  # M = 1311
+    bf = dtype == "bf16"
+    tdt = torch.bfloat16 if bf else torch.float32
+    x = synth.normal((b, cin, h, w), 510 + cin)
+    wt = synth.normal((cout, cin, 1, 1), 520 + cout, (1.0 / cin) ** 0.5)
+    sc = synth.uniform((cout,), 529, 0.5, 1.5)
+    sh = synth.normal((cout,), 530, 0.1)
+    res = synth.normal((b, cout, h, w), 531)
+    if bf:      # the oracle sees the values the kernel reads
+        x, wt, res = x.bfloat16().float(), wt.bfloat16().float(), res.bfloat16().float()
+    resp = torch.zeros((b, h, w, ldd))
+    resp[..., :cout] = nhwc(res)
+    want = F.conv2d(x, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if act == "swish":
+        want = O.swish(want)
+    if with_res:
+        want = want + res
+    from ccvpe_amd.models import _pack_conv
+    dst = torch.full((b, h, w, ldd), -7.0, device="cuda", dtype=tdt)
+    kw = dict(batch=b, in_h=h, in_w=w, scale=dev(sc), shift=dev(sh), act=ops.ACT_SWISH if act == "swish" else ops.ACT_NONE,
+              residual=dev(resp.to(tdt)) if with_res else None, dst=dst, ldd=ldd)
+    xs, wp = dev(nhwc(x).to(tdt)), dev(_pack_conv(wt, tdt))
+    route = ops.conv_igemm(xs, cin, wp, cout, route_only=True, **kw)
+    assert route[0] == "pw_gemm", route
+    got = ops.conv_igemm(xs, cin, wp, cout, **kw)
+    close(nchw(got[..., :cout].float()), want, 1.2e-2 if bf else 1e-4, "pw ragged %d->%d %s %s" % (cin, cout, act, dtype))
+    if ldd > cout:
+        assert float((got[..., cout:].float() + 7.0).abs().max()) == 0.0, "columns beyond N were written"
+
+
+def test_conv_route_matches_dispatch_rules(ops):
+    """ccvpe_conv_igemm_route: 3x3 s1 p1 -> conv3x3; 1x1 N > 48 act NONE/SWISH -> pw_gemm; ReLU / narrow N / gather forms ->
+    the generic kernel (csrc/conv_igemm.hip: conv_igemm_any)."""
+    x = torch.zeros((1, 8, 8, 64), device="cuda")
+    w1 = torch.zeros((96, 64), device="cuda")
+    w3 = torch.zeros((96, 9 * 64), device="cuda")
+    w2 = torch.zeros((96, 4 * 64), device="cuda")
+    r = lambda **k: ops.conv_igemm(x, 64, k.pop("w", w1), k.pop("n", 96), batch=1, in_h=8, in_w=8, route_only=True, **k)
+    assert r()[0] == "pw_gemm" and r(act=ops.ACT_SWISH)[0] == "pw_gemm"
+    assert r(act=ops.ACT_RELU)[0] == "igemm"
+    assert r(n=48, w=torch.zeros((48, 64), device="cuda"))[0] == "igemm"
+    assert r(w=w3, kh=3, kw=3, pad=1)[0] == "conv3x3"
+    assert r(w=w2, kh=2, kw=2, stride=2)[0] == "igemm"
+    assert r(n=80, w=torch.zeros((80, 64), device="cuda")) == ("pw_gemm", 4, 3, 2)      # 256 x 80 tile re-routed to 128 x 96
 
 
 def test_igemm_gate_and_residual(ops):
