@@ -16,11 +16,15 @@ One JSON line on rank 0 with, besides the contract fields:
                  region / their HIP-event durations; peak from MI355X_MICROARCH.md; traffic = PMC HBM bytes per launch from
                  the committed profiles/ pass (`traffic_source` names it), else null; `whole_step` prices the entire step.
   cpu_baseline — the CPU oracle (oracle/ccvpe_oracle.py, kind "port") on the host cores, bounded sample, rank 0 / N=1.
-  extra        — side measurements in the SAME line, each with its own roofline (and cpu_baseline where one exists):
-                 train_fwd_bwd_vigor_b64 (BASELINE metric's "(fwd+bwd) VIGOR bs=64": the full training step),
-                 C2_bf16 (configs[2]), C1_bf16 (C1 model in bf16 storage); for N>1 additionally train_dp_kitti_b64
-                 (configs[3]: the data-parallel training step with the RCCL gradient all-reduce), so a multi-GPU run of
-                 the default command exercises the collective path.
+  config       — besides the workload description, COMPACT summaries of the side measurements the default command also runs
+                 (the driver's record keeps `config` and `roofline`; it drops unknown top-level keys):
+                 fwd_bwd_vigor_b64 (BASELINE metric's "(fwd+bwd) VIGOR bs=64": the full training step, with its CPU
+                 baseline), C2_bf16 (configs[2]), C1_bf16 (C1 model in bf16 storage), C4_bf16_graph_b256 (configs[4]);
+                 for N>1 additionally train_dp_kitti_b64 (configs[3]: the data-parallel training step with the RCCL
+                 gradient all-reduce) and `collective` (backend, ranks as RCCL counts them, all-reduce calls and bytes per
+                 step).  Each summary: ms_per_step, pairs_per_s, whole-step fraction of the governing roof, dominant kernel
+                 and its fraction.  A failure of the data-parallel leg prints the line and then EXITS NON-ZERO.
+The per-kernel tables of every leg go to stderr (one JSON object per leg, prefix "[bench kernels]"), not into the line.
 `--train` makes the training step the headline (`--model kitti` = C3).
 """
 import argparse
@@ -55,7 +59,10 @@ def parse():
     ap.add_argument("--model", choices=["prior0", "vigor20", "prior180_fov180", "kitti", "oxford"], default="prior0",
                     help="prior0 = C1 (default); vigor20 = C2 (N_rot=20); prior180_fov180 = C4; kitti = C3 forward")
     ap.add_argument("--per-layer", action="store_true", help="print a per-launch-shape table to stderr")
-    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements attached as `extra`")
+    ap.add_argument("--no-extra", action="store_true", help="skip the side measurements (config.<leg> summaries)")
+    ap.add_argument("--legs", default="c2,c1bf16,c4,train,dp",
+                    help="side measurements of the default command: c2, c1bf16, c4, train (fwd+bwd VIGOR), dp (data-parallel "
+                         "KITTI step; runs only under a process group)")
     ap.add_argument("--train", action="store_true",
                     help="time full training steps (forward + losses + backward + gradient all-reduce + Adam) instead "
                          "of the eval forward: BASELINE config C3 with --model kitti")
@@ -153,10 +160,41 @@ def _traffic(name, workload):
     return d.get(name), src
 
 
-def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
-    """summ: ops.LaunchRecorder.summary().  Dominant kernel = the largest total time among the recorded dense launches."""
-    if not summ:
+def whole_step_roof(precision, batch, kind, ms_step, train=False):
+    """The whole step against the governing roof (forward GFLOP / activation MB per pair; fwd+bwd =
+    3 x forward FLOPs).  Needs only the wall time of a step: also available for hipGraph replays."""
+    gf = GFLOP_PER_PAIR.get(kind)
+    if gf is None or not ms_step:
         return None
+    mult = 3.0 if train else 1.0
+    step_tf = mult * gf * batch / ms_step          # GFLOP / ms = TFLOP/s
+    ws = {"algorithmic_tflop_per_step": round(mult * gf * batch / 1e3, 3), "achieved_tflops": round(step_tf, 2)}
+    if precision == "bf16":
+        step_gbs = MB_PER_PAIR_FP32[kind] / 2 * batch / ms_step        # MB / ms = GB/s
+        ws.update(bound="hbm", algorithmic_gb_per_step=round(MB_PER_PAIR_FP32[kind] / 2 * batch / 1e3, 2),
+                  achieved_GBps=round(step_gbs, 1), frac=round(step_gbs / HBM_PEAK_GBS, 4),
+                  mfma_bf16_frac=round(step_tf / BF16_MATRIX_PEAK_TFLOPS, 4))
+    else:
+        ws.update(bound="mfma", frac=round(step_tf / FP32_MATRIX_PEAK_TFLOPS, 4))
+    return ws
+
+
+def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
+    """summ: ops.LaunchRecorder.summary() (None / empty for a hipGraph replay: events cannot be recorded inside one — the
+    roofline then prices the whole step only).  Dominant kernel = the largest total time among the recorded dense launches.
+    Returns (roofline dict, per-kernel table or None)."""
+    ws = whole_step_roof(precision, batch, kind, ms_step, train)
+    if not summ:
+        if ws is None:
+            return None, None
+        if ws["bound"] == "hbm":
+            roof = {"bound": "hbm", "kernel": "(whole step; hipGraph replay: no per-launch events)", "achieved": ws["achieved_GBps"],
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac"], "traffic": None}
+        else:
+            roof = {"bound": "mfma", "kernel": "(whole step; hipGraph replay: no per-launch events)", "achieved": ws["achieved_tflops"],
+                    "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ws["frac"], "traffic": None}
+        roof["whole_step"] = ws
+        return roof, None
     tot_ms = sum(d["ms"] for d in summ.values())
     name, d = max(summ.items(), key=lambda kv: kv[1]["ms"])
     tfl = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -188,27 +226,46 @@ def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
                 algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
                 algorithmic_mb_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2),
                 share_of_recorded_time=round(d["ms"] / tot_ms, 3))
-    # the whole step against the governing roof (BASELINE.md §3 figures: forward GFLOP / activation MB per pair;
-    # fwd+bwd = 3 x forward FLOPs)
-    gf = GFLOP_PER_PAIR.get(kind)
-    if gf is not None and ms_step:
-        mult = 3.0 if train else 1.0
-        step_tf = mult * gf * batch / ms_step          # GFLOP / ms = TFLOP/s
-        ws = {"algorithmic_tflop_per_step": round(mult * gf * batch / 1e3, 3), "achieved_tflops": round(step_tf, 2)}
-        if precision == "bf16":
-            step_gbs = MB_PER_PAIR_FP32[kind] / 2 * batch / ms_step        # MB / ms = GB/s
-            ws.update(bound="hbm", algorithmic_gb_per_step=round(MB_PER_PAIR_FP32[kind] / 2 * batch / 1e3, 2),
-                      achieved_GBps=round(step_gbs, 1), frac=round(step_gbs / HBM_PEAK_GBS, 4),
-                      mfma_bf16_frac=round(step_tf / BF16_MATRIX_PEAK_TFLOPS, 4))
-        else:
-            ws.update(bound="mfma", frac=round(step_tf / FP32_MATRIX_PEAK_TFLOPS, 4))
+    if ws is not None:
         roof["whole_step"] = ws
-    roof["all_kernels"] = {k: {"ms_per_step": round(v["ms"] / steps, 3),
-                               "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                               "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
-                               "launches_per_step": v["calls"] // steps}
-                           for k, v in sorted(summ.items())}
-    return roof
+    table = {k: {"ms_per_step": round(v["ms"] / steps, 3),
+                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                 "algo_GBps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                 "launches_per_step": v["calls"] // steps}
+             for k, v in sorted(summ.items())}
+    return roof, table
+
+
+def emit_kernel_table(tag, table):
+    """Per-kernel table of one leg -> stderr (kept out of the JSON line: the driver's 2 000-character tail must show the
+    line's head, and its record keeps `config` / `roofline` only)."""
+    if table:
+        print("[bench kernels] " + json.dumps({tag: table}), file=sys.stderr)
+        sys.stderr.flush()
+
+
+def compact(entry):
+    """Driver-visible summary of a side measurement (goes under config.<leg>)."""
+    if "error" in entry:
+        return {"error": entry["error"][:300]}
+    out = {"ms_per_step": entry["ms_per_step"], "pairs_per_s": entry["value"], "n_gpus": entry.get("n_gpus", 1),
+           "batch_per_gpu": entry.get("batch_per_gpu"), "steps": entry.get("steps"), "dtype": entry.get("dtype")}
+    r = entry.get("roofline") or {}
+    ws = r.get("whole_step") or {}
+    if ws:
+        out["whole_step_bound"] = ws.get("bound")
+        out["whole_step_frac"] = ws.get("frac")
+    if r.get("kernel"):
+        out["kernel"], out["kernel_frac"], out["kernel_bound"] = r["kernel"], r.get("frac"), r.get("bound")
+    cb = entry.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline_pairs_per_s"] = round(cb["value"], 3)
+        out["cpu_cores"] = cb["cores"]
+        out["cpu_sample"] = cb["sample"]
+    for k in ("loss_after_last_step", "peak_hbm_gib", "launch"):
+        if k in entry:
+            out[k] = entry[k]
+    return out
 
 
 def per_layer_table(rec, steps):
@@ -249,7 +306,7 @@ def forward_measure(fwd, grd, sat, dev, steps, warmup, record):
 def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record=False, exact_infonce=False):
     """Times `steps` training steps as train_VIGOR.py:112-150 / train_KITTI.py:120-151 run them: ground truth, forward
     (train mode), the three losses on all levels, backward, data-parallel gradient averaging (RCCL all-reduce), Adam.
-    Returns dict(elapsed = max-over-ranks seconds, loss, peak_gib, rec)."""
+    Returns dict(elapsed = max-over-ranks seconds, loss, peak_gib, rec, allreduce_calls_per_step, allreduce_bytes_per_step)."""
     import torch
     from ccvpe_amd import harness, losses, ops, optim, synth, targets
 
@@ -264,11 +321,12 @@ def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record=
     nce_fn = losses.infoNCELoss_global if exact_infonce else losses.infoNCELoss
     last = {}
     rec = ops.LaunchRecorder() if record else None
-    state = {"n": 0}
+    state = {"n": 0, "calls0": 0}
 
     def step():
         if state["n"] == warmup:
             ops.set_recorder(rec)
+            state["calls0"] = reducer.allreduce_calls
         state["n"] += 1
         opt.zero_grad(set_to_none=True)
         gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, n_rot)
@@ -287,10 +345,15 @@ def train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record=
         elapsed = harness.timed_steps(step, steps, warmup, sync_fn=torch.cuda.synchronize, device=dev)
     finally:
         ops.set_recorder(None)
-    return dict(elapsed=elapsed, loss=float(last["loss"]), peak_gib=torch.cuda.max_memory_allocated(dev) / 2 ** 30, rec=rec)
+    loss = float(last["loss"])
+    if loss != loss or loss in (float("inf"), float("-inf")):
+        raise RuntimeError("training step produced a non-finite loss (%r)" % loss)
+    return dict(elapsed=elapsed, loss=loss, peak_gib=torch.cuda.max_memory_allocated(dev) / 2 ** 30, rec=rec,
+                allreduce_calls_per_step=(reducer.allreduce_calls - state["calls0"]) / float(steps),
+                allreduce_bytes_per_step=reducer.bytes_reduced_last_step)
 
 
-def train_entry(net, kind, grd, sat, dev, batch, steps, warmup, rank, world, n_rot, record, exact_infonce=False):
+def train_entry(net, kind, grd, sat, dev, batch, steps, warmup, rank, world, n_rot, record, exact_infonce=False, tag="train"):
     """One training measurement as a JSON-able dict (value = whole-job pairs/s) + its roofline."""
     m = train_measure(net, grd, sat, dev, batch, steps, warmup, rank, n_rot, record, exact_infonce)
     ms = 1e3 * m["elapsed"] / steps
@@ -299,13 +362,29 @@ def train_entry(net, kind, grd, sat, dev, batch, steps, warmup, rank, world, n_r
                        % (type(net).__name__, "RCCL gradient all-reduce in 3 groups overlapped with the backward, "
                           if world > 1 else "", batch),
            "value": round(batch * world * steps / m["elapsed"], 2), "unit": "img-pairs/s", "n_gpus": world,
-           "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
-           "loss_after_last_step": round(m["loss"], 5), "peak_hbm_gib": round(m["peak_gib"], 2),
-           "parity": "tests/test_train_backward_gpu.py: gradients vs the reference's autograd golden (520 tensors); "
-                     "tests/test_train_trajectory_gpu.py: 10-step loss trajectory vs the oracle + torch Adam"}
-    if m["rec"] is not None:
-        out["roofline"] = roofline_from(m["rec"].summary(), steps, "fp32", batch, kind, ms, train=True)
+           "batch_per_gpu": batch, "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
+           "loss_after_last_step": round(m["loss"], 5), "peak_hbm_gib": round(m["peak_gib"], 2)}
+    roof, table = roofline_from(m["rec"].summary() if m["rec"] is not None else None, steps, "fp32", batch, kind, ms, train=True)
+    out["roofline"] = roof
+    if rank == 0:
+        emit_kernel_table(tag, table)
     return out, m
+
+
+def harness_active():
+    from ccvpe_amd import harness
+    return harness.GradientAllReducer.active()
+
+
+def collective_info(dev, m, world):
+    """What the collective layer actually did in the timed region of a data-parallel training leg (N > 1)."""
+    import torch
+    import torch.distributed as dist
+    ones = torch.ones((1,), device=dev)
+    dist.all_reduce(ones)                                   # every rank adds 1: the world size as RCCL itself counts it
+    return {"backend": "%s (RCCL)" % dist.get_backend(), "world_size_env": world, "ranks_counted_by_allreduce": int(ones.item()),
+            "allreduce_calls_per_step": m["allreduce_calls_per_step"], "bytes_per_step": int(m["allreduce_bytes_per_step"]),
+            "op": "ncclAvg in place on the flat gradient arena, 3 groups, issued from inside the backward"}
 
 
 def main():
@@ -316,13 +395,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under a launcher (RANK set) the process group is created even for one rank: `torchrun --nproc-per-node 1` then
+    # exercises the exact collective code path of the multi-GPU runs (tests/test_bench_torchrun_gpu.py)
+    use_pg = world > 1 or "RANK" in os.environ
+    if use_pg:
         dist.init_process_group("nccl", device_id=dev)      # RCCL
 
     from ccvpe_amd import models, ops, synth, _lib
@@ -345,11 +427,17 @@ def main():
     grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank)
     grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
     record = not args.no_kernel_events
+    failed = []                                             # legs whose failure must fail the run (after the line is printed)
 
-    def finish():
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
+    def finish(code=0):
+        if use_pg:
+            try:
+                dist.barrier()
+                dist.destroy_process_group()
+            except Exception:                               # noqa: BLE001 — already failing
+                pass
+        if code:
+            sys.exit(code)
 
     # ---------------------------------------------------------------------------------------------------
     if args.train:
@@ -358,6 +446,7 @@ def main():
         n_rot = synth.MODEL_SPECS[kind]["n_rot"]
         entry, m = train_entry(net, kind, grd, sat, dev, args.batch, args.steps, args.warmup, rank, world, n_rot, record,
                                args.exact_infonce)
+        coll = collective_info(dev, m, world) if use_pg else None
         if rank == 0:
             line = {"metric": "train image-pairs/sec (fwd+bwd)", "value": entry["value"], "unit": "img-pairs/s", "n_gpus": world,
                     "steps": args.steps, "warmup": args.warmup, "ms_per_step": entry["ms_per_step"], "higher_is_better": True,
@@ -370,6 +459,8 @@ def main():
                                "loss_after_last_step": entry["loss_after_last_step"], "peak_hbm_gib": entry["peak_hbm_gib"],
                                "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
                     "roofline": entry.get("roofline"), "cpu_baseline": None}
+            if coll is not None:
+                line["config"]["collective"] = coll
             if m["rec"] is not None and args.per_layer:
                 per_layer_table(m["rec"], args.steps)
             if world == 1 and not args.no_cpu_baseline and kind in ("vigor", "kitti"):
@@ -418,8 +509,9 @@ def main():
             # RobotCar variant, hardware not stated (/root/reference/README.md:21)
             line["vs_baseline"] = round(value / 14.0, 2)
             line["config"]["baseline"] = "14 FPS per frame (reference README, hardware not stated)"
-        line["roofline"] = (roofline_from(rec.summary(), args.steps, args.precision, args.batch, kind, ms_step)
-                            if rec is not None else None)
+        line["roofline"], table = roofline_from(rec.summary() if rec is not None else None, args.steps, args.precision,
+                                                args.batch, kind, ms_step)
+        emit_kernel_table("headline", table)
         if rec is not None and args.per_layer:
             per_layer_table(rec, args.steps)
         if world == 1 and not args.no_cpu_baseline and args.model == "prior0":
@@ -429,73 +521,103 @@ def main():
 
     default_run = (args.model == "prior0" and args.precision == "fp32" and not args.graph and not args.no_extra)
     if default_run:
-        extra = {}
+        legs = {}
+        want = set(args.legs.split(","))
         del fwd
         # (1) BASELINE configs[2] "C2": CVM_VIGOR, N_rot = 20, batch 32, bf16 storage; (2) the C1 model in bf16 at batch 64
-        #     (the north-star's ">= 10 000 pairs/s forward at batch 64" is a bf16 goal: fp32 MFMA ceiling is 2.8 k)
-        for tag, ctor, b2, seed, what in (
-                ("C2_bf16", lambda: models.CVM_VIGOR(dev, True), 32, 4321,
+        #     (the north-star's ">= 10 000 pairs/s forward at batch 64" is a bf16 goal: fp32 MFMA ceiling is 2.8 k);
+        # (3) configs[4] "C4": ori_prior(180), FoV 180 ground input, bf16, hipGraph replay at batch 256
+        for tag, ctor, b2, gsh, seed, graph, what in (
+                ("C2_bf16", lambda: models.CVM_VIGOR(dev, True), 32, "vigor", 4321, False,
                  "C2: CVM_VIGOR eval forward, N_rot=20, batch 32, bf16 storage (fp32 accumulate)"),
-                ("C1_bf16", lambda: models.CVM_VIGOR_ori_prior(dev, 0, True), args.batch, 1234,
-                 "C1 model CVM_VIGOR_ori_prior(0) eval forward, batch %d, bf16 storage (fp32 accumulate)" % args.batch)):
+                ("C1_bf16", lambda: models.CVM_VIGOR_ori_prior(dev, 0, True), args.batch, "vigor", 1234, False,
+                 "C1 model CVM_VIGOR_ori_prior(0) eval forward, batch %d, bf16 storage (fp32 accumulate)" % args.batch),
+                ("C4_bf16_graph_b256", lambda: models.CVM_VIGOR_ori_prior(dev, 180, False), 256, "vigor_fov180", 777, True,
+                 "C4: CVM_VIGOR_ori_prior(180, circular_padding=False), FoV 180, batch 256, bf16 storage, hipGraph replay")):
+            if {"C2_bf16": "c2", "C1_bf16": "c1bf16", "C4_bf16_graph_b256": "c4"}[tag] not in want:
+                continue
             try:
                 net2 = ctor()
                 net2.load_state_dict(sd, strict=True)
                 net2 = net2.to(dev).eval().set_precision("bf16")
-                g2, s2 = synth.synthetic_pair(b2, "vigor", seed + rank)
+                g2, s2 = synth.synthetic_pair(b2, gsh, seed + rank)
                 g2, s2 = g2.to(dev), s2.to(dev)
-                e2, r2 = forward_measure(net2, g2, s2, dev, 5, 2, record)
+                f2 = net2
+                if graph:
+                    from ccvpe_amd.graph import GraphedForward
+                    f2 = GraphedForward(net2, g2, s2)
+                e2, r2 = forward_measure(f2, g2, s2, dev, 5, 2, record and not graph)
                 if rank == 0:
-                    extra[tag] = {"workload": what + ", grd 3x320x640 + sat 3x512x512", "value": round(b2 * world * 5 / e2, 2),
-                                  "unit": "img-pairs/s", "n_gpus": world, "ms_per_step": round(1e3 * e2 / 5, 3), "steps": 5,
-                                  "warmup": 2, "dtype": "bf16",
-                                  "parity": "tests/test_bf16_gpu.py: heat-map arg-max equal to the fp32 oracle on the golden cases, "
-                                            "logits / scores within the tolerances written there",
-                                  "roofline": (roofline_from(r2.summary(), 5, "bf16", b2, "vigor", 1e3 * e2 / 5)
-                                               if r2 is not None else None)}
-                del net2, g2, s2, r2
-            except Exception as ex:      # the headline must not depend on a side measurement
+                    roof, table = roofline_from(r2.summary() if r2 is not None else None, 5, "bf16", b2, "vigor", 1e3 * e2 / 5)
+                    emit_kernel_table(tag, table)
+                    legs[tag] = {"workload": what, "value": round(b2 * world * 5 / e2, 2), "n_gpus": world, "batch_per_gpu": b2,
+                                 "ms_per_step": round(1e3 * e2 / 5, 3), "steps": 5, "dtype": "bf16", "roofline": roof,
+                                 "launch": "hipGraph replay" if graph else "eager"}
+                del net2, g2, s2, r2, f2
+                torch.cuda.empty_cache()
+            except Exception as ex:      # the headline must not depend on a side measurement; the error is driver-visible
                 if rank == 0:
-                    extra[tag] = {"error": repr(ex)}
-        # (3) BASELINE.json's metric string names "(fwd+bwd) VIGOR bs=64": the full training step of CVM_VIGOR (N_rot = 20)
+                    legs[tag] = {"error": repr(ex)}
+        # (4) BASELINE.json's metric string names "(fwd+bwd) VIGOR bs=64": the full training step of CVM_VIGOR (N_rot = 20)
         #     at batch 64 per GPU: ground truth, train-mode forward, losses, backward, (all-reduce,) Adam
         try:
             del net
             torch.cuda.empty_cache()
+            if "train" not in want:
+                raise KeyError("skipped")
             net3 = models.CVM_VIGOR(dev, True)
             net3.load_state_dict(sd, strict=True)
             net3 = net3.to(dev)
-            ent, _ = train_entry(net3, "vigor", grd, sat, dev, args.batch, 3, 2, rank, world, 20, record)   # 2 warm-up steps: the 2nd captures the re-pack hipGraph
+            ent, _ = train_entry(net3, "vigor", grd, sat, dev, args.batch, 3, 2, rank, world, 20, record,
+                                 tag="fwd_bwd_vigor_b64")   # 2 warm-up steps: the 2nd captures the re-pack hipGraph
             if rank == 0:
                 if world == 1 and not args.no_cpu_baseline:
                     ent["cpu_baseline"] = cpu_baseline_train(sd, "vigor")
-                extra["train_fwd_bwd_vigor_b64"] = ent
+                legs["fwd_bwd_vigor_b64"] = ent
             del net3
+        except KeyError:
+            pass
         except Exception as ex:
             if rank == 0:
-                extra["train_fwd_bwd_vigor_b64"] = {"error": repr(ex)}
-        # (4) N > 1: BASELINE configs[3] "C3" — CVM_KITTI data-parallel training step, batch 64 per GPU, gradients averaged by
-        #     RCCL all-reduce over xGMI: a multi-GPU run of the default command exercises the collective path
-        if world > 1:
+                legs["fwd_bwd_vigor_b64"] = {"error": repr(ex)}
+        # (5) under a process group (N > 1): BASELINE configs[3] "C3" — CVM_KITTI data-parallel training step, batch 64 per
+        #     GPU, gradients averaged by RCCL all-reduce over xGMI.  This is the ONLY leg with a data-path collective: if it
+        #     fails the line is still printed (with the error) and the process exits non-zero.
+        if use_pg and "dp" in want:
+            coll = None
             try:
                 torch.cuda.empty_cache()
+                if os.environ.get("CCVPE_BENCH_FAIL_DP") == "1":        # tests: the failure path of this leg
+                    raise RuntimeError("injected failure (CCVPE_BENCH_FAIL_DP=1)")
                 sdk = synth.synthetic_state_dict("kitti", 0)
                 net4 = models.CVM_KITTI(dev)
                 net4.load_state_dict(sdk, strict=True)
                 net4 = net4.to(dev)
                 g4, s4 = synth.synthetic_pair(args.batch, "kitti", 1234 + rank)
-                ent, _ = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, 3, 2, rank, world, 16, record)
+                ent, m4 = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, 3, 2, rank, world, 16, record,
+                                      tag="train_dp_kitti_b64")
+                coll = collective_info(dev, m4, world)
+                if coll["ranks_counted_by_allreduce"] != world:
+                    raise RuntimeError("all-reduce counted %d ranks, WORLD_SIZE is %d" % (coll["ranks_counted_by_allreduce"], world))
+                if harness_active() and coll["allreduce_calls_per_step"] < 1:
+                    raise RuntimeError("no gradient all-reduce ran in the timed region")
                 if rank == 0:
-                    extra["train_dp_kitti_b64"] = ent
+                    legs["train_dp_kitti_b64"] = ent
             except Exception as ex:
+                failed.append("train_dp_kitti_b64: %r" % (ex,))
                 if rank == 0:
-                    extra["train_dp_kitti_b64"] = {"error": repr(ex)}
+                    legs["train_dp_kitti_b64"] = {"error": repr(ex)}
+            if rank == 0 and coll is not None:
+                line["config"]["collective"] = coll
         if rank == 0:
-            line["extra"] = extra
+            for tag, ent in legs.items():
+                line["config"][tag] = compact(ent)
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
-    finish()
+    if failed:
+        print("bench.py: FAILED legs: " + "; ".join(failed), file=sys.stderr)
+    finish(1 if failed else 0)
 
 
 if __name__ == "__main__":

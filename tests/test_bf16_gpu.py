@@ -221,40 +221,89 @@ def test_forward_bf16_vs_oracle(case, synth_sd):
     for a, bb in zip(out[3:], ref[3:]):
         assert (a.cpu() - bb).abs().max().item() < 2e-2
     assert abs(out[1].sum().item() - 2.0) < 1e-3
-    # the orientation at the arg-max pixel (what the evaluation reads, train_VIGOR.py:310-324) within bf16 resolution
+    # the orientation at the arg-max pixel (what the evaluation reads, train_VIGOR.py:310-324): vector within bf16
+    # resolution, and the 18-degree orientation BIN equal to the oracle's (north_star: "orientation bin exact") wherever
+    # the oracle's angle is further from a bin edge than the angle the vector bound allows (asin(3e-2) = 1.7 deg -> 2 deg)
     for b in range(2):
         i = int(rl[b].argmax())
         o_got, o_ref = out[2][b].reshape(2, -1)[:, i].cpu(), ref[2][b].reshape(2, -1)[:, i]
         assert (o_got - o_ref).abs().max().item() < 3e-2
+        same, near_edge = ori_bin_check(o_got, o_ref)
+        assert same or near_edge, "bf16 orientation bin differs away from a bin edge"
     # fp32 precision is restored by switching back (packed weights are re-derived)
     net.set_precision("fp32")
     out32 = net(grd.cuda(), sat.cuda())
     assert ((out32[0].cpu() - rl).abs().max() / rl.abs().max()).item() < 1e-3
 
 
-def test_bf16_argmax_match_rate(synth_sd):
-    """Arg-max pixel of the bf16 storage path (default fp32 tail) against the fp32 HIP path — itself arg-max exact against
-    the reference's goldens (tests/test_forward_gpu.py) — over 64 seeded pairs of CVM_VIGOR (N_rot = 20).  Measured 64/64
-    with the tail, 63/64 without; the bar leaves room for ONE near-tie (fp32 margins go down to 1.5e-3 of the logit range
-    while the bf16 logit error is ~4e-3 of it)."""
+LOGIT_ERR_BOUND = 6e-3        # bf16 storage path (default fp32 tail): max |logit error| / logit range, asserted below (measured 4.5e-3)
+ORI_EDGE_DEG = 2.0            # asin(3e-2): the angle the asserted orientation-vector bound can move
+
+
+def ori_bin_check(o_got, o_ref):
+    """(bins equal, oracle angle within ORI_EDGE_DEG of an 18-degree bin edge) for two (cos, sin) vectors."""
+    ang = lambda v: float(torch.atan2(v[1], v[0]) * 180 / 3.14159265) % 360
+    a_g, a_r = ang(o_got), ang(o_ref)
+    d = a_r % 18.0
+    return int(a_g // 18) == int(a_r // 18), min(d, 18.0 - d) < ORI_EDGE_DEG
+
+
+def test_bf16_argmax_margin_rule(synth_sd):
+    """Arg-max pixel + orientation bin of the bf16 storage path (default fp32 tail) against the fp32 HIP path — itself arg-max
+    and bin exact against the reference's goldens (tests/test_forward_gpu.py) — over 64 seeded pairs of CVM_VIGOR (N_rot = 20).
+
+    The rule (no "63 of 64" allowance): (1) the logit error is bounded: |bf16 - fp32| <= LOGIT_ERR_BOUND x range for every
+    pixel of every sample; (2) wherever the fp32 top-1 / top-2 margin exceeds TWICE that bound the arg-max pixel is EQUAL;
+    (3) the samples inside the bound ("near ties") are counted and reported, and if the bf16 arg-max moves there it moves to a
+    pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) the orientation bin at the fp32
+    arg-max pixel is equal wherever the fp32 angle is further than ORI_EDGE_DEG from a bin edge.  Pure bf16 storage
+    (fp32_tail_levels = 0) is held to the same rule with its own measured bound (first 32 pairs)."""
     from ccvpe_amd import models
     net = models.CVM_VIGOR("cuda", True)
     net.load_state_dict(synth_sd("vigor", 0), strict=True)
     net = net.to("cuda:0").eval()
-    same_tail = same_pure = total = 0
-    worst = 0.0
+    stats = {"tail": dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0),
+             "pure": dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0)}
+    bound = {"tail": LOGIT_ERR_BOUND, "pure": 8e-3}
+
+    def account(st, E, ref, got, ref_ori, got_ori):
+        rng = ref.max(1)[0] - ref.min(1)[0]
+        err = (got - ref).abs().max(1)[0] / rng
+        top2 = ref.topk(2, dim=1)[0]
+        margin = (top2[:, 0] - top2[:, 1]) / rng
+        ia, ib = ref.argmax(1), got.argmax(1)
+        for b in range(ref.shape[0]):
+            st["n"] += 1
+            st["worst"] = max(st["worst"], float(err[b]))
+            near = float(margin[b]) <= 2 * E
+            st["near"] += int(near)
+            if int(ia[b]) == int(ib[b]):
+                st["same"] += 1
+            else:
+                assert near, "arg-max moved although the fp32 margin %.2e exceeds twice the error bound" % float(margin[b])
+                drop = float((ref[b, ia[b]] - ref[b, ib[b]]) / rng[b])
+                st["moved_far"] += int(drop > 2 * E)
+            o_g = got_ori[b].reshape(2, -1)[:, ia[b]].cpu()
+            o_r = ref_ori[b].reshape(2, -1)[:, ia[b]].cpu()
+            same, edge = ori_bin_check(o_g, o_r)
+            st["bins_edge"] += int(edge)
+            st["bins_bad"] += int(not same and not edge)
+
     for c0 in range(0, 64, 16):
         grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0)
         grd, sat = grd.cuda(), sat.cuda()
-        ref = net.set_precision("fp32")(grd, sat)[0]
-        got = net.set_precision("bf16")(grd, sat)[0]
-        pure = net.set_precision("bf16", fp32_tail_levels=0)(grd, sat)[0]
-        rng = ref.max(1)[0] - ref.min(1)[0]
-        worst = max(worst, float(((got - ref).abs().max(1)[0] / rng).max()))
-        same_tail += int((got.argmax(1) == ref.argmax(1)).sum())
-        same_pure += int((pure.argmax(1) == ref.argmax(1)).sum())
-        total += 16
-    print("bf16 arg-max match rate: %d/%d with the fp32 tail, %d/%d pure bf16; worst logit error %.2e of the range"
-          % (same_tail, total, same_pure, total, worst))
-    assert same_tail >= total - 1 and same_pure >= total - 3
-    assert worst < 1e-2
+        r = net.set_precision("fp32")(grd, sat)
+        ref, ref_ori = r[0].clone(), r[2].clone()
+        g = net.set_precision("bf16")(grd, sat)
+        account(stats["tail"], bound["tail"], ref, g[0], ref_ori, g[2])
+        if c0 < 32:
+            g = net.set_precision("bf16", fp32_tail_levels=0)(grd, sat)
+            account(stats["pure"], bound["pure"], ref, g[0], ref_ori, g[2])
+    for k, st in stats.items():
+        print("bf16 (%s): arg-max equal %d/%d, near ties (margin <= 2 x %.0e of range) %d, worst logit error %.2e of range, "
+              "orientation bins: %d at a bin edge, %d wrong" % (k, st["same"], st["n"], bound[k], st["near"], st["worst"],
+                                                                st["bins_edge"], st["bins_bad"]))
+        assert st["worst"] <= bound[k], "logit error bound exceeded"
+        assert st["moved_far"] == 0, "the arg-max moved to a pixel outside the error bound"
+        assert st["same"] >= st["n"] - st["near"]
+        assert st["bins_bad"] == 0, "orientation bin differs away from a bin edge"

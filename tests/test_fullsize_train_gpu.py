@@ -1,0 +1,110 @@
+"""The BENCHED training step (BASELINE metric "(fwd+bwd) VIGOR bs=64": CVM_VIGOR, train mode, batch 64) and the single
+weight-gradient launches it makes, at size — every other training test runs B <= 3, so the tile choices that only engage at
+B = 64 (conv_wgrad_kernel<128,128> with pixel splits, up to 1 024 splits for the 16-channel 512^2 layers, the k-way
+BatchNorm merge over thousands of partial rows, 96-tensor gradient copies) are pinned here:
+  * conv_wgrad at the benched layer shapes against a float64 CPU convolution backward (torch.nn.grad.conv2d_weight);
+  * the whole step: finite loss, BIT-identical gradients across two runs from the same state (fixed-order merges, no
+    atomics), and gradients invariant under a permutation of the batch up to summation order (the loss, BatchNorm batch
+    statistics and every weight gradient are sums over the batch)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from ccvpe_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+@pytest.mark.parametrize("name,b,c0,c1,n,k,hw,tile,min_splits", [
+    ("conv6.2 (640 -> 640 @16^2)", 64, 640, 0, 640, 3, 16, (128, 128), 8),
+    ("conv6.0 (1024 + 320 -> 640 @16^2, two sources)", 64, 1024, 320, 640, 3, 16, (128, 128), 8),
+    ("conv3.0 (80 + 24 -> 80 @128^2)", 64, 80, 24, 80, 3, 128, (80, 64), 64),
+    ("conv2_ori.2 (32 -> 32 @256^2)", 16, 32, 0, 32, 3, 256, (32, 64), 256),
+    ("conv1.0 (16 -> 16 @512^2)", 16, 16, 0, 16, 3, 512, (16, 64), 1024),
+    ("block-2 expand (24 -> 144 @128^2, 1x1)", 64, 24, 0, 144, 1, 128, None, 512),
+])
+def test_conv_wgrad_at_benched_shapes(name, b, c0, c1, n, k, hw, tile, min_splits):
+    from ccvpe_amd import _lib, backward as bw
+    lib = _lib.load()
+    ctot = c0 + c1
+    t = lib.ccvpe_conv_wgrad_tile(n, k * k * ctot)
+    assert tile is None or (t >> 16, t & 0xffff) == tile, "tile for %s changed: %s" % (name, (t >> 16, t & 0xffff))
+    floats = lib.ccvpe_conv_wgrad_scratch_floats(b, hw, hw, k, k, 1, k // 2, ctot, n)
+    splits = floats // (n * k * k * ctot)
+    assert splits >= min_splits, "%s: %d pixel splits" % (name, splits)
+    x = synth.normal((b, ctot, hw, hw), 8100 + n)
+    dy = synth.normal((b, n, hw, hw), 8101 + n)
+    want = torch.nn.grad.conv2d_weight(x.double(), (n, ctot, k, k), dy.double(), padding=k // 2)
+    xs = nhwc(x)
+    x0 = xs[..., :c0].contiguous().cuda()
+    x1 = xs[..., c0:].contiguous().cuda() if c1 else None
+    got = bw.conv_wgrad(x0, nhwc(dy).cuda(), n, k, k, 1, k // 2, x1).cpu().double()
+    scale = want.abs().max().item()
+    err = (got - want).abs().max().item()
+    assert err <= 2e-4 * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+    again = bw.conv_wgrad(x0, nhwc(dy).cuda(), n, k, k, 1, k // 2, x1).cpu().double()
+    assert torch.equal(got, again), "%s: two runs differ (a non-deterministic merge)" % name
+
+
+def _step(net, grd, sat, masks, center, angle):
+    from ccvpe_amd import losses, targets
+    for p in net.parameters():
+        p.grad = None
+    gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, 20)
+    out = net(grd, sat, drop_masks=masks)
+    nce = 0.0
+    for lvl in range(6):                                   # the loss mix of train_VIGOR.py:131-150, as bench.py times it
+        nce = nce + losses.infoNCELoss(torch.flatten(out[3 + lvl], start_dim=1), torch.flatten(labels[lvl], start_dim=1))
+    loss = losses.cross_entropy_loss(out[0], gt_flat) + 1e4 * nce / 6 + 1e1 * losses.orientation_loss(out[2], gt_ori, gt)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+
+
+def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_sd):
+    from ccvpe_amd import models
+    batch = 64
+    net = models.CVM_VIGOR("cuda", True)
+    net.load_state_dict(synth_sd("vigor", 0), strict=True)
+    net = net.to("cuda:0").train()
+    sd0 = {k: v.clone() for k, v in net.state_dict().items()}          # running statistics are updated in place
+    grd, sat = synth.synthetic_pair(batch, "vigor", 1234)
+    grd, sat = grd.cuda(), sat.cuda()
+    u = synth.uniform((batch, 3), 99)
+    center, angle = ((u[:, :2] - 0.5) * 384.0).cuda(), (u[:, 2] * 359.99).cuda()
+    keys = [("%s_efficientnet" % e, i) for e in ("grd", "sat") for i in range(16)]
+    masks = {k: (synth.uniform((batch,), 7000 + j) > 0.1).float().cuda() for j, k in enumerate(keys)}
+
+    loss_a, g_a = _step(net, grd, sat, masks, center, angle)
+    assert loss_a == loss_a and abs(loss_a) < 1e9, "non-finite loss %r" % loss_a
+    assert len(g_a) >= 500 and all(torch.isfinite(g).all() for g in g_a.values())
+    net.load_state_dict(sd0, strict=True)
+    loss_b, g_b = _step(net, grd, sat, masks, center, angle)
+    assert loss_a == loss_b
+    for n in g_a:
+        assert torch.equal(g_a[n], g_b[n]), "gradient of %s differs between two identical steps" % n
+
+    perm = torch.randperm(batch, generator=torch.Generator().manual_seed(5)).cuda()
+    net.load_state_dict(sd0, strict=True)
+    loss_p, g_p = _step(net, grd[perm].contiguous(), sat[perm].contiguous(), {k: v[perm].contiguous() for k, v in masks.items()},
+                        center[perm].contiguous(), angle[perm].contiguous())
+    assert abs(loss_p - loss_a) <= 1e-5 * abs(loss_a), (loss_a, loss_p)
+    top = max(float(g.norm()) for g in g_a.values())
+    worst = (0.0, "")
+    for n in g_a:
+        na = float(g_a[n].norm())
+        d = float((g_a[n] - g_p[n]).norm())
+        if na < 1e-6 * top:                        # mathematically zero gradients (42 tensors): noise level on both sides
+            assert float(g_p[n].norm()) < 1e-4 * top, n
+            continue
+        worst = max(worst, (d / na, n))
+    print("B=64 training step: loss %.6f; worst relative gradient change under a batch permutation %.2e (%s)"
+          % (loss_a, worst[0], worst[1]))
+    assert worst[0] <= PERM_RTOL, worst
+
+
+PERM_RTOL = 1e-4      # summation order over 64 samples x up to 2.6e5 pixels changes; measured worst printed by the test

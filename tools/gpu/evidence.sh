@@ -1,22 +1,28 @@
 #!/bin/bash
-# Round-2 evidence: the default bench line, rocprofv3 kernel stats of the measured workloads, PMC traffic and MFMA-busy passes.
-# Everything lands in gpurun_out/ev_r02/; the summaries to be judged are then copied into profiles/r02/ (tracked).
+# Round evidence: the default bench line, rocprofv3 kernel stats of the measured workloads, PMC traffic and MFMA-busy passes.
+#   usage (on the GPU box, through gpurun): bash tools/gpu/evidence.sh <round tag, e.g. r03> <commit> [stats|pmc|all]
+# Everything lands in gpurun_out/ev_<round>/; the summaries to be judged are then copied into profiles/<round>/ (tracked).
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/ev_r02
-COMMIT=${1:-unknown}
+TAG=${1:-r03}
+OUT=$R/gpurun_out/ev_$TAG
+COMMIT=${2:-unknown}
+WHAT=${3:-all}
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd $R
-python3 bench.py --steps 20 --warmup 5 > $OUT/bench_r02_n1.json 2> $OUT/bench_r02_n1.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_${TAG}_n1.json 2> $OUT/bench_${TAG}_n1.err
 cd /tmp
 F32="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
 BF1="python3 $R/bench.py --precision bf16 --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
 BF2="python3 $R/bench.py --precision bf16 --model vigor20 --batch 32 --steps 5 --warmup 2 --no-cpu-baseline --no-extra --no-kernel-events"
 TRN="python3 $R/bench.py --train --model vigor20 --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-events"
+if [ "$WHAT" != pmc ]; then
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/f32 -o f32 -- $F32 > $OUT/f32.json 2> $OUT/f32.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bf16_c1 -o bf16_c1 -- $BF1 > $OUT/bf16_c1.json 2> $OUT/bf16_c1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bf16_c2 -o bf16_c2 -- $BF2 > $OUT/bf16_c2.json 2> $OUT/bf16_c2.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train -o train -- $TRN > $OUT/train.json 2> $OUT/train.err
+fi
+[ "$WHAT" = stats ] && { find $OUT -name '*kernel_trace.csv' -size +8M -delete; ls -la $OUT; exit 0; }
 # PMC passes (counters only with --kernel-trace; FETCH and WRITE in separate passes)
 for w in f32 train bf16; do
   case $w in f32) CMD="$F32";; train) CMD="$TRN";; bf16) CMD="$BF1";; esac
