@@ -73,7 +73,8 @@ PROTOTYPES = {
     "ccvpe_cast_bf16_f32": (c_int, [c_void_p, c_void_p, ctypes.c_long, c_void_p]),
     "ccvpe_softmax_rows_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_eval_postprocess_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "ccvpe_infonce_loss_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "ccvpe_infonce_scratch_floats": (c_int, [c_int, c_int]),
+    "ccvpe_infonce_loss_f32": (c_int, [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_cross_entropy_loss_f32": (c_int, [c_void_p] * 4 + [c_int, c_int, c_void_p]),
     "ccvpe_orientation_loss_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "ccvpe_stem_conv_raw_f32": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p]),

@@ -172,28 +172,74 @@ __global__ __launch_bounds__(1024) void softmax_rows_kernel(const float* __restr
 // Losses (losses.py).  Stage 1: one workgroup per sample writes partial (num, den); stage 2: one
 // wave combines them in fixed order.  masked_select is rewritten as a masked sum (graph-capturable).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void infonce_rows_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
-                                                            float inv_t, float* __restrict__ part, int n) {
+// infoNCE, ONE pass over (scores, labels): workgroup (chunk, sample) reduces its NCE_CH elements to
+//   z = sum exp(s/T)   a = sum_{label > 1e-2} (s/T) * label   den = sum_{label > 1e-2} label          (losses.py:12-17)
+// and the finish kernel merges the chunks of a row in fixed order: num_b = a_b - log(z_b) * den_b (= sum (s/T - log z) * label,
+// losses.py:16-17).  rows[b] = (num_b, den_b, z_b, 0) stays around for the backward, which therefore needs no statistics pass
+// of its own.  (The first version ran ONE workgroup per sample — 64 workgroups on 256 CUs, each walking 1.3 M scores twice.)
+constexpr int NCE_CH = 8192;
+__global__ __launch_bounds__(256) void infonce_part_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
+                                                           float inv_t, float* __restrict__ part, int n, int chunks) {
   __shared__ float sh[16];
-  const float* s = sc + (size_t)blockIdx.x * n;
-  const float* l = lab + (size_t)blockIdx.x * n;
-  float z = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) z += expf(s[i] * inv_t);   // losses.py:12,15
-  z = block_sum(z, sh);
-  const float logz = logf(z);
-  float num = 0.f, den = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float lv = l[i];
-    if (lv > 1e-2f) {                                                            // losses.py:13
-      num = fmaf(s[i] * inv_t - logz, lv, num);                                  // losses.py:16-17
-      den += lv;
+  const size_t row = (size_t)blockIdx.y * n;
+  const int i0 = blockIdx.x * NCE_CH, i1 = min(n, i0 + NCE_CH);
+  float z = 0.f, a = 0.f, den = 0.f;
+  if ((n & 3) == 0) {
+    for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(sc + row + i);
+      const f32x4 l = *reinterpret_cast<const f32x4*>(lab + row + i);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float t = v[q] * inv_t;
+        z += expf(t);
+        if (l[q] > 1e-2f) { a = fmaf(t, l[q], a); den += l[q]; }               // losses.py:13
+      }
+    }
+  } else {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float t = sc[row + i] * inv_t, lv = lab[row + i];
+      z += expf(t);
+      if (lv > 1e-2f) { a = fmaf(t, lv, a); den += lv; }
     }
   }
-  num = block_sum(num, sh);
+  z = block_sum(z, sh);
+  a = block_sum(a, sh);
   den = block_sum(den, sh);
   if (threadIdx.x == 0) {
-    part[2 * blockIdx.x] = num;
-    part[2 * blockIdx.x + 1] = den;
+    float* o = part + ((size_t)blockIdx.y * chunks + blockIdx.x) * 4;
+    o[0] = z; o[1] = a; o[2] = den;
+  }
+}
+
+// one workgroup: wave w merges the chunk partials of rows w, w+4, ... (lane-strided, then a butterfly: fixed order), then
+// wave 0 adds the rows: loss = -sum(num)/sum(den) (losses.py:18-20), rows[4B] = sum(den) for the backward
+__global__ __launch_bounds__(256) void infonce_finish_kernel(const float* __restrict__ part, float* __restrict__ rows,
+                                                             float* __restrict__ loss, int B, int chunks) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = wave; b < B; b += 4) {
+    float z = 0.f, a = 0.f, den = 0.f;
+    for (int c = lane; c < chunks; c += 64) {
+      const float* q = part + ((size_t)b * chunks + c) * 4;
+      z += q[0]; a += q[1]; den += q[2];
+    }
+    z = wave_sum(z); a = wave_sum(a); den = wave_sum(den);
+    if (lane == 0) {
+      rows[4 * b] = a - logf(z) * den;
+      rows[4 * b + 1] = den;
+      rows[4 * b + 2] = z;
+      rows[4 * b + 3] = 0.f;
+    }
+  }
+  __threadfence_block();
+  __syncthreads();
+  if (wave == 0) {
+    float num = 0.f, den = 0.f;
+    for (int b = lane; b < B; b += 64) { num += rows[4 * b]; den += rows[4 * b + 1]; }
+    num = wave_sum(num); den = wave_sum(den);
+    if (lane == 0) {
+      loss[0] = -num / den;
+      rows[4 * B] = den;
+    }
   }
 }
 
@@ -310,7 +356,7 @@ using namespace ccvpe;
 thread_local char ccvpe::g_err[512] = "";
 
 extern "C" const char* ccvpe_last_error(void) { return g_err; }
-extern "C" int ccvpe_abi_version(void) { return 3; }
+extern "C" int ccvpe_abi_version(void) { return 4; }
 
 extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
                                            float* out, int B, int h, int w, void* stream) {
@@ -367,12 +413,21 @@ extern "C" int ccvpe_eval_postprocess_f32(const float* heatmap, const float* ori
   return check_launch("eval_post_kernel");
 }
 
+extern "C" int ccvpe_infonce_scratch_floats(int B, int n) {
+  if (B <= 0 || n <= 0) return CCVPE_EINVAL;
+  const long fl = (long)B * ((n + NCE_CH - 1) / NCE_CH) * 4;
+  return fl > 0x7fffffffL ? CCVPE_EINVAL : (int)fl;
+}
+
 extern "C" int ccvpe_infonce_loss_f32(const float* scores, const float* labels, float temperature, float* loss,
-                                      float* scratch, int B, int n, void* stream) {
+                                      float* rows, float* scratch, int B, int n, void* stream) {
   if (B <= 0 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce: bad args");
+  if (B > 65535) return fail(CCVPE_EINVAL, "infonce: batch > 65535");
+  if ((n & 3) == 0 && (!aligned16(scores) || !aligned16(labels))) return fail(CCVPE_EINVAL, "infonce: 16-byte alignment required");
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(infonce_rows_kernel, dim3(B), dim3(1024), 0, st, scores, labels, 1.0f / temperature, scratch, n);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, scratch, loss, B, 0);
+  const int chunks = (n + NCE_CH - 1) / NCE_CH;
+  hipLaunchKernelGGL(infonce_part_kernel, dim3(chunks, B), dim3(256), 0, st, scores, labels, 1.0f / temperature, scratch, n, chunks);
+  hipLaunchKernelGGL(infonce_finish_kernel, dim3(1), dim3(256), 0, st, scratch, rows, loss, B, chunks);
   return check_launch("infonce");
 }
 

@@ -436,40 +436,33 @@ extern "C" int ccvpe_stem_conv_wgrad_f32(const float* x_nchw, const float* dy, f
 // ---------------------------------------------------------------------------------------------
 namespace ccvpe {
 
-__global__ __launch_bounds__(1024) void infonce_den_kernel(const float* __restrict__ lab, float* __restrict__ den_rows, int n) {
-  __shared__ float sh[16];
-  const float* l = lab + (size_t)blockIdx.x * n;
-  float d = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float lv = l[i];
-    if (lv > 1e-2f) d += lv;
-  }
-  d = block_sum_b(d, sh);
-  if (threadIdx.x == 0) den_rows[blockIdx.x] = d;
-}
-
-__global__ __launch_bounds__(1024) void infonce_bwd_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
-                                                           float inv_t, const float* __restrict__ dloss,
-                                                           const float* __restrict__ den_rows,
-                                                           float* __restrict__ dsc, int n, int B) {
-  __shared__ float sh[16];
-  const float* s = sc + (size_t)blockIdx.x * n;
-  const float* l = lab + (size_t)blockIdx.x * n;
-  float z = 0.f, den = 0.f;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    z += expf(s[i] * inv_t);
-    const float lv = l[i];
-    if (lv > 1e-2f) den += lv;
-  }
-  z = block_sum_b(z, sh);
-  den = block_sum_b(den, sh);
-  float D = 0.f;                                   // batch total of the masked labels (same order in every workgroup)
-  for (int b = 0; b < B; ++b) D += den_rows[b];
-  const float k = dloss[0] * inv_t / D;
-  float* o = dsc + (size_t)blockIdx.x * n;
-  for (int i = threadIdx.x; i < n; i += blockDim.x) {
-    const float lv = l[i];
-    o[i] = k * (den * expf(s[i] * inv_t) / z - (lv > 1e-2f ? lv : 0.f));
+// one pass: the row statistics (z_b, den_b) and the batch label mass D come from the forward (rows[b] = (num, den, z, 0),
+// rows[4B] = D: csrc/heads.hip), workgroup (chunk, sample) writes its NCE_BCH gradients
+constexpr int NCE_BCH = 8192;
+__global__ __launch_bounds__(256) void infonce_bwd_kernel(const float* __restrict__ sc, const float* __restrict__ lab,
+                                                          float inv_t, const float* __restrict__ dloss,
+                                                          const float* __restrict__ rows, float* __restrict__ dsc, int n, int B) {
+  const size_t row = (size_t)blockIdx.y * n;
+  const float den = rows[4 * blockIdx.y + 1], rz = 1.0f / rows[4 * blockIdx.y + 2];
+  // (an upstream gradient of exactly 0 — a rank without label mass under the global-ratio loss, harness._GlobalRatio —
+  // gives 0, not 0 / 0)
+  const float g = dloss[0];
+  const float k = g == 0.f ? 0.f : g * inv_t / rows[4 * B];
+  const int i0 = blockIdx.x * NCE_BCH, i1 = min(n, i0 + NCE_BCH);
+  if ((n & 3) == 0) {
+    for (int i = i0 + threadIdx.x * 4; i < i1; i += 1024) {
+      const cc_f32x4 v = *reinterpret_cast<const cc_f32x4*>(sc + row + i);
+      const cc_f32x4 l = *reinterpret_cast<const cc_f32x4*>(lab + row + i);
+      cc_f32x4 o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) o[q] = k * (den * expf(v[q] * inv_t) * rz - (l[q] > 1e-2f ? l[q] : 0.f));
+      *reinterpret_cast<cc_f32x4*>(dsc + row + i) = o;
+    }
+  } else {
+    for (int i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float lv = lab[row + i];
+      dsc[row + i] = k * (den * expf(sc[row + i] * inv_t) * rz - (lv > 1e-2f ? lv : 0.f));
+    }
   }
 }
 
@@ -513,11 +506,13 @@ __global__ __launch_bounds__(256) void ori_bwd_kernel(const float* __restrict__ 
 }  // namespace ccvpe
 
 extern "C" int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
-                                          float* dscores, float* scratch, int batch, int n, void* stream) {
-  if (batch <= 0 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce_bwd: bad args");
-  hipLaunchKernelGGL(infonce_den_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, labels, scratch, n);
-  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(batch), dim3(1024), 0, (hipStream_t)stream, scores, labels, 1.0f / temperature,
-                     dloss, scratch, dscores, n, batch);
+                                          const float* rows, float* dscores, int batch, int n, void* stream) {
+  if (batch <= 0 || batch > 65535 || n <= 0 || temperature <= 0.f) return fail(CCVPE_EINVAL, "infonce_bwd: bad args");
+  if ((n & 3) == 0 && (!aligned16(scores) || !aligned16(labels) || !aligned16(dscores)))
+    return fail(CCVPE_EINVAL, "infonce_bwd: 16-byte alignment required");
+  const int chunks = (n + NCE_BCH - 1) / NCE_BCH;
+  hipLaunchKernelGGL(infonce_bwd_kernel, dim3(chunks, batch), dim3(256), 0, (hipStream_t)stream, scores, labels, 1.0f / temperature,
+                     dloss, rows, dscores, n, batch);
   return check_launch("infonce_bwd_kernel");
 }
 

@@ -5,20 +5,25 @@
 // L channels, takes a norm, a repeat()-ed product, a sum and a division, then stacks, maxes,
 // F.normalize()s X again and cats — about 20x the algorithmic traffic.
 //
-// Here: one kernel reads X once from HBM (second touch of the tile comes from L2), and writes
-// the score volume (NCHW, returned to the caller) and the decoder input
-// [X/||X||, max score, (level-1 orientation scores), 0-pad] exactly once.
+// Here: one kernel reads X ONCE from HBM — a (TP pixels x all C channels) tile is staged in LDS and serves the
+// norms, the scores AND the normalised copy — and writes the score volume (NCHW, returned to the caller) and the decoder
+// input [X/||X||, max score, (level-1 orientation scores), 0-pad] exactly once, as whole rows.
+// (Round 2 walked the channels in 32-wide slabs and re-read the tile from global memory for the normalised copy: the PMC
+// pass showed 2.5x the algorithmic read traffic at B = 64 — the "second touch is L2-hot" assumption did not hold, and a
+// 128-byte slab of a 160-byte pixel row touches two cache lines per row per slab.)
 //
-// HBM-bound: bytes/pixel = 4*C read + 4*ldo write + 4*n_shifts scores; the arithmetic
+// HBM-bound: bytes/pixel = esz*C read + esz*ldo write + 4*n_shifts scores; the arithmetic
 // (n_shifts*C FMAs per pixel) is <1% of the forward's FLOPs, so it stays on the VALU.
 //
-// Mapping: lane = pixel.  A 256-pixel x 32-channel tile is loaded coalesced (128 B per pixel row)
-// and transposed into LDS so that the per-lane channel walk is conflict-free; the ground
-// descriptor is shared by every pixel of a sample, so it sits in LDS as a doubled table
-// gg[k] = g_ext[k mod C] (k < 2C, g_ext = g zero-extended to C) and each FMA's second operand is
-// a wave-uniform LDS broadcast:  dot_i = sum_c' x[c'] * gg[c' + off_i],  off_i = (-i*stride) mod C.
-// For partial windows (L < C: FoV < 360, KITTI) the window norm uses the same trick with a 0/1
-// table; for L == C it is the pixel's total norm.
+// Mapping: 256 threads; LPP lanes share one pixel (LPP = 1 for C <= 48 ... 32 for C = 1280), so a workgroup owns
+// TP = 256/LPP pixels and the tile is ~45 KB whatever the level (2-3 workgroups per CU, ~11 16-byte loads in flight per
+// thread).  The tile is stored pixel-major with a row pitch S chosen so that S/4 = LPP * odd: the ds_read_b128 of a lane
+// group (16 lanes = 16/LPP pixels x LPP consecutive 16-byte pieces) then covers all 64 banks exactly once.  Lane `sub` of
+// a pixel walks the 4-channel groups sub, sub + LPP, ...; the ground descriptor is shared by every pixel of a sample, so it
+// sits in LDS as a doubled table gg[k] = g_ext[k mod C] (k < 2C, g_ext = g zero-extended to C):
+//   dot_i = sum_c' x[c'] * gg[c' + off_i],  off_i = (-i*stride - window_offset) mod C;
+// the LPP partial sums are combined with a butterfly.  For partial windows (L < C: FoV < 360, KITTI) the window norm uses the
+// same trick with a 0/1 table; for L == C it is the pixel's total norm.
 #include "common.h"
 
 namespace ccvpe {
@@ -30,33 +35,61 @@ struct MatchOffsets {
   int off[CCVPE_MAX_SHIFTS];
 };
 
-constexpr int MCK = 32;  // channels per staged tile
+// lanes per pixel and tile row pitch (floats) for C channels
+static inline int match_lpp(int C) { int l = 1; while (l < 32 && C > 48 * l) l *= 2; return l; }
+static inline int match_pitch(int C, int lpp) {
+  if (lpp >= 16) return C + 4;                    // a lane group reads 256 contiguous bytes of ONE pixel: any pitch works
+  int s = C + 4;                                  // (C % 8 == 0)  ->  s/4 = lpp * odd
+  while ((s / 4) % lpp || ((s / 4) / lpp) % 2 == 0) s += 4;
+  return s;
+}
 
 // TX = storage type of X and of the concat output (float or bf16); scores, g and all math are fp32.
 template <typename TX, int NPAD, bool PARTIAL, int VEC>
 __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, int ldx, const float* __restrict__ g,
                                                     int ldg, int L, const MatchOffsets mo, int n_shifts, int n_max,
                                                     int n_tail, float* __restrict__ scores,
-                                                    TX* __restrict__ dstx, int ldo, int hw, int C) {
+                                                    TX* __restrict__ dstx, int ldo, int hw, int C, int lpp_log2, int S) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  const int TPB = blockDim.x;
-  const int XLD = TPB + 1;
+  const int LPP = 1 << lpp_log2;
+  const int TP = 256 >> lpp_log2;                   // pixels per workgroup
   float* gg = sm;                                   // [2C]
   float* ww = gg + 2 * C;                           // [2C] (PARTIAL only)
-  float* xs = ww + (PARTIAL ? 2 * C : 0);           // [MCK][XLD]
-  float* inv_s = xs + MCK * XLD;                    // [TPB]
-  float* red = inv_s + TPB;                         // [4]
+  float* xs = ww + (PARTIAL ? 2 * C : 0);           // [TP][S]   the tile, pixel-major
+  float* sc_s = xs + TP * S;                        // [NPAD][TP] scores of the tile (written out coalesced)
+  float* inv_s = sc_s + NPAD * TP;                  // [TP]  1 / max(||x||, 1e-12)
+  float* mx_s = inv_s + TP;                         // [TP]  max score
+  float* red = mx_s + TP;                           // [4]
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  const int p0 = blockIdx.x * TPB;
-  const int p = p0 + tid;
-  const bool pvalid = p < hw;
-  const TX* xb = x + (size_t)b * hw * ldx;
+  const int p0 = blockIdx.x * TP;
+  const int npx = min(TP, hw - p0);
+  const TX* xb = x + ((size_t)b * hw + p0) * ldx;
 
+  // ---- phase 1: the tile, global -> LDS (whole pixel rows, 4 channels per request, 4 requests in flight per thread) ----
+  const int c4n = C >> 2;
+  {
+    const int total = npx * c4n;
+    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
+      f32x4 v[4];
+      int dsto[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = min(i0 + u * 256, total - 1);
+        const int pp = idx / c4n;
+        const int c4 = idx - pp * c4n;
+        v[u] = ld4<TX>(xb + (size_t)pp * ldx + c4 * 4);
+        dsto[u] = pp * S + c4 * 4;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (i0 + u * 256 < total) *reinterpret_cast<f32x4*>(xs + dsto[u]) = v[u];
+    }
+  }
   // descriptor tables + ||g||
   float gsq = 0.f;
-  for (int k = tid; k < 2 * C; k += TPB) {
+  for (int k = tid; k < 2 * C; k += 256) {
     const int kk = k < C ? k : k - C;
     const float v = kk < L ? g[(size_t)b * ldg + kk] : 0.f;
     gg[k] = v;
@@ -66,47 +99,36 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   gsq = wave_sum(gsq);
   if ((tid & 63) == 0) red[tid >> 6] = gsq;
   __syncthreads();
-  float gnorm = 0.f;
-  for (int i = 0; i < (TPB >> 6); ++i) gnorm += red[i];
-  gnorm = sqrtf(gnorm);
+  const float gnorm = sqrtf(red[0] + red[1] + red[2] + red[3]);
 
+  // ---- phase 2: lane (pixel pl, part sub) walks its 4-channel groups ---------------------------------------------------
+  const int sub = tid & (LPP - 1);
+  const int pl = tid >> lpp_log2;
   float acc[NPAD], nrm[PARTIAL ? NPAD : 1];
 #pragma unroll
   for (int i = 0; i < NPAD; ++i) acc[i] = 0.f;
 #pragma unroll
   for (int i = 0; i < (PARTIAL ? NPAD : 1); ++i) nrm[i] = 0.f;
   float tot = 0.f;
-
-  const int f4_per_row = MCK / 4;  // 8 float4 per pixel row of the tile
-  for (int c0 = 0; c0 < C; c0 += MCK) {
-    const int ck = min(MCK, C - c0);
-    // cooperative, coalesced tile load -> transposed LDS
-    for (int idx = tid; idx < TPB * f4_per_row; idx += TPB) {
-      const int pp = idx / f4_per_row;
-      const int cq = (idx - pp * f4_per_row) * 4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (p0 + pp < hw && cq < ck) v = ld4<TX>(xb + (size_t)(p0 + pp) * ldx + c0 + cq);
-      xs[(cq + 0) * XLD + pp] = v[0];
-      xs[(cq + 1) * XLD + pp] = v[1];
-      xs[(cq + 2) * XLD + pp] = v[2];
-      xs[(cq + 3) * XLD + pp] = v[3];
-    }
-    __syncthreads();
-    for (int cc = 0; cc < ck; cc += 4) {
+  if (pl < npx) {
+    const float* xrow = xs + pl * S;
+    for (int t = sub; t < c4n; t += LPP) {
+      const int c = t * 4;
+      const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow + c);
       float xv[4], x2[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        xv[j] = xs[(cc + j) * XLD + tid];
+        xv[j] = xq[j];
         x2[j] = xv[j] * xv[j];
         tot += x2[j];
       }
 #pragma unroll
       for (int i = 0; i < NPAD; ++i) {
-        const int k = c0 + cc + mo.off[i];
+        const int k = c + mo.off[i];
         float gv[4];
         if (VEC == 4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(gg + k);
-          gv[0] = t[0]; gv[1] = t[1]; gv[2] = t[2]; gv[3] = t[3];
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(gg + k);
+          gv[0] = t4[0]; gv[1] = t4[1]; gv[2] = t4[2]; gv[3] = t4[3];
         } else if (VEC == 2) {
           const f32x2 t0 = *reinterpret_cast<const f32x2*>(gg + k);
           const f32x2 t1 = *reinterpret_cast<const f32x2*>(gg + k + 2);
@@ -119,8 +141,8 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
         if (PARTIAL) {
           float wv[4];
           if (VEC == 4) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(ww + k);
-            wv[0] = t[0]; wv[1] = t[1]; wv[2] = t[2]; wv[3] = t[3];
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(ww + k);
+            wv[0] = t4[0]; wv[1] = t4[1]; wv[2] = t4[2]; wv[3] = t4[3];
           } else if (VEC == 2) {
             const f32x2 t0 = *reinterpret_cast<const f32x2*>(ww + k);
             const f32x2 t1 = *reinterpret_cast<const f32x2*>(ww + k + 2);
@@ -133,40 +155,60 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
         }
       }
     }
-    __syncthreads();
   }
-
-  // scores, max (NaN-propagating like torch.max), extras
-  float mx = 0.f;
-  if (pvalid) {
-    TX* drow = dstx + ((size_t)b * hw + p) * ldo;
-    const int tail0 = n_shifts - n_tail;
+  // combine the LPP parts of a pixel (adjacent lanes; fixed butterfly order)
+  for (int o = 1; o < LPP; o <<= 1) {
+    tot += __shfl_xor(tot, o, 64);
+#pragma unroll
+    for (int i = 0; i < NPAD; ++i) acc[i] += __shfl_xor(acc[i], o, 64);
+    if (PARTIAL) {
+#pragma unroll
+      for (int i = 0; i < NPAD; ++i) nrm[PARTIAL ? i : 0] += __shfl_xor(nrm[PARTIAL ? i : 0], o, 64);
+    }
+  }
+  // scores, max (NaN-propagating like torch.max) -> LDS
+  if (sub == 0 && pl < npx) {
+    float mx = 0.f;
 #pragma unroll
     for (int i = 0; i < NPAD; ++i) {
       if (i < n_shifts) {
         const float wn = sqrtf(PARTIAL ? nrm[PARTIAL ? i : 0] : tot);
         const float s = acc[i] / (wn * gnorm);
-        scores[((size_t)b * n_shifts + i) * hw + p] = s;
+        sc_s[i * TP + pl] = s;
         if (i == 0) mx = s;
         else if (i < n_max && (s > mx || s != s)) mx = s;
-        if (i >= tail0) drow[C + 1 + (i - tail0)] = (TX)s;
       }
     }
-    drow[C] = (TX)mx;
-    for (int c = C + 1 + n_tail; c < ldo; ++c) drow[c] = (TX)0.f;
+    mx_s[pl] = mx;
+    inv_s[pl] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   }
-  inv_s[tid] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   __syncthreads();
 
-  // second (coalesced) pass: X * inv_norm -> dstx[:, 0:C]; the tile was just read, so it is L2-hot
-  const int c4n = C >> 2;
-  const int npx = min(TPB, hw - p0);
-  for (int idx = tid; idx < npx * c4n; idx += TPB) {
-    const int pp = idx / c4n;
-    const int c4 = (idx - pp * c4n) * 4;
-    f32x4 v = ld4<TX>(xb + (size_t)(p0 + pp) * ldx + c4);
-    v *= inv_s[pp];
-    st4<TX>(dstx + ((size_t)b * hw + p0 + pp) * ldo + c4, v);
+  // ---- phase 3: whole output rows [X * inv_norm | max | tail scores | 0-pad], and the score volume (NCHW), coalesced -----
+  const int tail0 = n_shifts - n_tail;
+  {
+    const int o4n = ldo >> 2;
+    TX* drow0 = dstx + ((size_t)b * hw + p0) * ldo;
+    for (int idx = tid; idx < npx * o4n; idx += 256) {
+      const int pp = idx / o4n;
+      const int c = (idx - pp * o4n) * 4;
+      f32x4 v;
+      if (c < C) {
+        v = *reinterpret_cast<const f32x4*>(xs + pp * S + c) * inv_s[pp];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int e = c + j - C;                 // 0: max score; 1..n_tail: orientation scores; beyond: zero padding
+          v[j] = e == 0 ? mx_s[pp] : (e <= n_tail ? sc_s[(tail0 + e - 1) * TP + pp] : 0.f);
+        }
+      }
+      st4<TX>(drow0 + (size_t)pp * ldo + c, v);
+    }
+  }
+  for (int idx = tid; idx < n_shifts * TP; idx += 256) {
+    const int i = idx >> (8 - lpp_log2);           // idx / TP
+    const int pp = idx & (TP - 1);
+    if (pp < npx) scores[((size_t)b * n_shifts + i) * hw + p0 + pp] = sc_s[i * TP + pp];
   }
 }
 
@@ -178,17 +220,22 @@ template <typename TX, int NPAD, bool PARTIAL, int VEC>
 static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, const MatchOffsets& mo, int n_shifts,
                         int n_max, int n_tail, float* scores, TX* dstx, int ldo, int B, int hw, int C,
                         hipStream_t st) {
-  const int tpb = hw >= 256 ? 256 : ((hw + 63) / 64) * 64;
-  const size_t smem = sizeof(float) * ((size_t)2 * C * (PARTIAL ? 2 : 1) + (size_t)MCK * (tpb + 1) + tpb + 4);
+  const int lpp = match_lpp(C);
+  int lpp_log2 = 0;
+  while ((1 << lpp_log2) < lpp) ++lpp_log2;
+  const int S = match_pitch(C, lpp);
+  const int tp = 256 / lpp;
+  const size_t smem = sizeof(float) * ((size_t)2 * C * (PARTIAL ? 2 : 1) + (size_t)tp * S + (size_t)NPAD * tp + 2 * tp + 4);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level: C=%d needs %zu B of LDS", C, smem);
   auto kern = match_kernel<TX, NPAD, PARTIAL, VEC>;
   if (smem > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "match_level: set smem attr: %s", hipGetErrorString(e));
   }
-  dim3 grid((hw + tpb - 1) / tpb, B);
-  hipLaunchKernelGGL(kern, grid, dim3(tpb), smem, st, x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dstx,
-                     ldo, hw, C);
+  if (B > 65535) return fail(CCVPE_EINVAL, "match_level: batch > 65535");
+  dim3 grid((hw + tp - 1) / tp, B);
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dstx,
+                     ldo, hw, C, lpp_log2, S);
   return check_launch("match_kernel");
 }
 

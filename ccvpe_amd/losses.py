@@ -19,21 +19,21 @@ class _InfoNCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, scores, labels, temperature):
         s, l = _flat2(scores), _flat2(labels)
-        ctx.save_for_backward(s, l)
+        loss, den, rows = ops.infonce_loss(s, l, temperature, want_den=True, want_rows=True)
+        ctx.save_for_backward(s, l, rows)
         ctx.temperature, ctx.shape = float(temperature), scores.shape
-        loss, den = ops.infonce_loss(s, l, temperature, want_den=True)
+        den = den.clone()
         ctx.mark_non_differentiable(den)
         return loss.reshape(()), den.reshape(())
 
     @staticmethod
     def backward(ctx, dloss, _dden=None):
-        s, l = ctx.saved_tensors
+        s, l, rows = ctx.saved_tensors
         lib = _lib.load()
         out = torch.empty_like(s)
         g = dloss.reshape(1).contiguous().float()
-        scratch = torch.empty((s.shape[0],), device=s.device, dtype=torch.float32)
-        check(lib.ccvpe_infonce_loss_bwd_f32(ops._ptr(s), ops._ptr(l), ctx.temperature, ops._ptr(g), ops._ptr(out),
-                                             ops._ptr(scratch), s.shape[0], s.shape[1], ops._stream()),
+        check(lib.ccvpe_infonce_loss_bwd_f32(ops._ptr(s), ops._ptr(l), ctx.temperature, ops._ptr(g), ops._ptr(rows),
+                                             ops._ptr(out), s.shape[0], s.shape[1], ops._stream()),
               "ccvpe_infonce_loss_bwd_f32")
         return out.reshape(ctx.shape), None, None
 

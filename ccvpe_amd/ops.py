@@ -211,7 +211,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
         flops = algo_flops if algo_flops is not None else 2.0 * m * n * k_eff
         esz = 4.0 if dt == torch.float32 else 2.0
         nbytes = esz * (batch * h1 * w1 * c0 + m * c1 + m * n + 4 * n * k_eff)
-        kname = "upconv_halo_kernel" if w1 >= 16 else "upconv_kernel"     # mirrors launch_up() in conv_igemm.hip
+        kname = "upconv_s2d_kernel" if w1 >= 16 else "upconv_kernel"      # mirrors launch_up() in csrc/upconv_impl.h
         name = igemm_tile(n).replace("igemm_f32_kernel<", "%s<%s," % (kname, "f32" if dt == torch.float32 else "bf16"))
         rec.end(name, "up3x3 M%d N%d Keff%d" % (m, n, k_eff), flops, nbytes, ev0)
     return dst
@@ -453,16 +453,28 @@ def _loss_common(fn, name, tensors, extra):
     return lib, loss, scratch, b
 
 
-def infonce_loss(scores, labels, temperature=0.1, want_den=False):
+def infonce_loss(scores, labels, temperature=0.1, want_den=False, want_rows=False):
     """losses.py:4 infoNCELoss — forward value only (device scalar).  want_den: also return the batch's label mass
-    sum(labels > 1e-2) (the loss's denominator, losses.py:18) from the kernel's per-row partials."""
-    lib, loss, scratch, b = _loss_common(None, "infonce", (scores, labels), None)
-    n = scores.shape[1]
-    check(lib.ccvpe_infonce_loss_f32(_ptr(scores), _ptr(labels), float(temperature), _ptr(loss), _ptr(scratch),
+    sum(labels > 1e-2) (the loss's denominator, losses.py:18); want_rows: also return the per-sample statistics
+    [4*B + 4] the backward kernel reads (ccvpe_infonce_loss_bwd_f32)."""
+    lib = _lib.load()
+    _chk(scores, "infonce scores")
+    _chk(labels, "infonce labels")
+    b, n = scores.shape
+    loss = torch.empty((1,), device=scores.device, dtype=torch.float32)
+    rows = torch.empty((4 * b + 4,), device=scores.device, dtype=torch.float32)
+    nfl = lib.ccvpe_infonce_scratch_floats(b, n)
+    if nfl <= 0:
+        raise _lib.CcvpeError("ccvpe_infonce_scratch_floats rejected [%d, %d]" % (b, n))
+    scratch = torch.empty((nfl,), device=scores.device, dtype=torch.float32)
+    check(lib.ccvpe_infonce_loss_f32(_ptr(scores), _ptr(labels), float(temperature), _ptr(loss), _ptr(rows), _ptr(scratch),
                                      b, n, _stream()), "ccvpe_infonce_loss_f32")
+    out = (loss[0],)
     if want_den:
-        return loss[0], scratch.view(b, 2)[:, 1].sum()
-    return loss[0]
+        out = out + (rows[4 * b],)
+    if want_rows:
+        out = out + (rows,)
+    return out if len(out) > 1 else out[0]
 
 
 def cross_entropy_loss(logits, labels):

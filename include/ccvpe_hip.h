@@ -231,11 +231,15 @@ int ccvpe_eval_postprocess_f32(const float* heatmap, const float* ori, float* ou
  * Losses (losses.py:4-29), device scalars out.  `acc` is caller-provided scratch.
  *   infoNCE: accumulates num = sum_{label>1e-2} log(softmax(s/T))*label and den = sum label over
  *            the whole batch; loss = -num/den.            scores/labels [B,n]
+ *            ONE pass over the data with (chunk, sample) workgroups.  rows [4*B + 4] floats out: per sample
+ *            (num_b, den_b, z_b = sum exp(s/T), 0), then the batch label mass — the backward reads them instead of
+ *            recomputing row statistics.  scratch: ccvpe_infonce_scratch_floats(batch, n) floats.
  *   CE     : -sum(labels*log_softmax(logits))/B           [B,n]
  *   ori    : sum(||gt_ori-ori||^2 * gt)/B                 ori/gt_ori [B,2,hw], gt [B,hw]
  * ----------------------------------------------------------------------------------------- */
+int ccvpe_infonce_scratch_floats(int batch, int n);
 int ccvpe_infonce_loss_f32(const float* scores, const float* labels, float temperature, float* loss,
-                           float* scratch, int batch, int n, void* stream);
+                           float* rows, float* scratch, int batch, int n, void* stream);
 int ccvpe_cross_entropy_loss_f32(const float* logits, const float* labels, float* loss, float* scratch,
                                  int batch, int n, void* stream);
 int ccvpe_orientation_loss_f32(const float* ori, const float* gt_ori, const float* gt, float* loss,
@@ -361,9 +365,9 @@ int ccvpe_match_level_bwd_f32(const float* x, int ldx, const float* g, int ldg, 
                               int batch, int hw, int channels, void* stream);
 
 /* Loss gradients w.r.t. the prediction (losses.py:4-29); dloss = upstream scalar gradient (device pointer).
- * infoNCE scratch: batch floats. */
+ * infoNCE: `rows` is what ccvpe_infonce_loss_f32 wrote for the same (scores, labels); one pass, no statistics recomputed. */
 int ccvpe_infonce_loss_bwd_f32(const float* scores, const float* labels, float temperature, const float* dloss,
-                               float* dscores, float* scratch, int batch, int n, void* stream);
+                               const float* rows, float* dscores, int batch, int n, void* stream);
 int ccvpe_cross_entropy_loss_bwd_f32(const float* logits, const float* labels, const float* dloss, float* dlogits,
                                      int batch, int n, void* stream);
 int ccvpe_orientation_loss_bwd_f32(const float* ori, const float* gt_ori, const float* gt, const float* dloss,

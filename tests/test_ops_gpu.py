@@ -204,6 +204,20 @@ def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
     (64, 64, 32, 16, 32, 7, 6, False),        # ori branch: plain input
     (88, 81, 40, 16, 40, 6, 7, True),
     (648, 641, 320, 112, 320, 3, 4, True),
+    # w1 >= 16: the low-res-halo kernels (upconv_s2d_kernel; tiles + ragged borders in both directions, channel counts that
+    # do not fill the last 64-byte chunk of either source, 1- and 2-column tiles, every tile family of the decoder)
+    (48, 41, 16, 0, 16, 17, 33, False),       # level 1 (no skip), <4,1,1>
+    (88, 81, 40, 16, 40, 18, 16, False),      # level 2, <4,3,1>
+    (168, 161, 80, 24, 80, 9, 20, False),     # level 3, <4,5,1>
+    (328, 321, 160, 40, 160, 7, 17, False),   # level 4, <4,5,2>
+    (648, 641, 320, 112, 320, 5, 16, False),  # level 5, 2 x <4,5,2>
+    (64, 64, 32, 16, 32, 19, 35, False),      # ori level 2, <4,1,2>
+    (128, 128, 64, 24, 64, 8, 32, False),     # ori level 3, <4,2,2>
+    (256, 256, 128, 40, 128, 6, 16, False),   # ori level 4, <4,4,2>
+    (88, 81, 40, 16, 40, 18, 16, True),
+    (168, 161, 80, 24, 80, 9, 20, True),
+    (648, 641, 320, 112, 320, 5, 16, True),
+    (64, 64, 32, 16, 32, 19, 35, True),
 ])
 def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf16):
     """relu(conv3x3(cat[deconv2x2s2(x)+b, skip])+b)  ==  the folded per-parity GEMM (incl. borders)."""

@@ -1,4 +1,4 @@
-"""A whole optimisation TRAJECTORY, not one gradient: 10 training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
+"""A whole optimisation TRAJECTORY, not one gradient: 6 training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
 ground truth, train-mode forward with running-statistic updates, the reference's loss mix train_VIGOR.py:137-146, the HIP
 backward through the gradient arena, the one-launch Adam) against the CPU oracle driven by autograd + torch.optim.Adam on
 the same weights, pairs, drop_connect draws and targets.  Per-step gradients agree to ~1 % per tensor (golden_util
@@ -13,7 +13,7 @@ from oracle import ccvpe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-STEPS = 10
+STEPS = 6      # (10 in round 2: 150 s of CPU oracle steps; 6 keeps the GPU suite inside its time box)
 LR = 1e-4                      # train_VIGOR.py:104
 
 
@@ -76,8 +76,8 @@ def test_ten_step_trajectory_vs_oracle_and_torch_adam(synth_sd):
     print("loss trajectory  hip: %s\n                 ref: %s\n  rel diff per step: %s" % (np.round(hip, 4), np.round(ref, 4), np.round(rel, 6)))
     assert rel[0] < 1e-4, "first loss (identical weights) differs: %g" % rel[0]
     assert rel.max() < 5e-3, "loss trajectories diverge: %s" % rel
-    assert ref[-1] < ref[0] and hip[-1] < hip[0], "10 Adam steps did not reduce the loss"
-    # displacement of the parameters after 10 steps (Adam's early steps are ~ lr * sign(g): entries whose gradient is
+    assert ref[-1] < ref[0] and hip[-1] < hip[0], "the Adam steps did not reduce the loss"
+    # displacement of the parameters after the steps (Adam's early steps are ~ lr * sign(g): entries whose gradient is
     # round-off-level noise move in arbitrary directions on both sides, so the bar is on the big, well-conditioned tensors)
     live = dict(net.named_parameters())
     checked = 0
