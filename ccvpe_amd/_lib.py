@@ -87,6 +87,8 @@ PROTOTYPES = {
     "ccvpe_conv_wgrad_scratch_floats": (c_int, [c_int] * 9),
     "ccvpe_conv_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                      c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ccvpe_conv_wgrad_bias_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
+                                          c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ccvpe_colsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ccvpe_bn_bwd_nblk": (c_int, [c_int]),
     "ccvpe_bn_act_bwd_f32": (c_int, [c_void_p] * 9 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
@@ -158,7 +160,10 @@ def load():
             "libccvpe_hip.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(or `make -C ccvpe_amd/csrc`).  ccvpe_amd has no CPU fallback." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    lax = bool(os.environ.get("CCVPE_LIB")) and os.environ.get("CCVPE_LIB_ALLOW_MISSING") == "1"   # tools/ A/B runs against an older build
     for name, (res, args) in PROTOTYPES.items():
+        if lax and not hasattr(lib, name):
+            continue
         fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args

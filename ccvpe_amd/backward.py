@@ -19,9 +19,10 @@ from ._lib import check
 from .models import _pack_conv, _pack_deconv
 
 
-def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None):
+def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None, want_bias=False):
     """d(conv2d)/d(weight) in the reference OIHW layout.  x0 [B,H,W,ld0] (+ x1 [B,H,W,ld1] concatenated),
-    dy [B,Ho,Wo,ldy]; c0 / c1 select the first channels of wider pixel rows (default: all)."""
+    dy [B,Ho,Wo,ldy]; c0 / c1 select the first channels of wider pixel rows (default: all).
+    want_bias: also return the conv's bias gradient sum_pixels dy[:, n] from the SAME launch (ccvpe_conv_wgrad_bias_f32)."""
     lib = _lib.load()
     for t, nm in ((x0, "x0"), (x1, "x1"), (dy, "dy")):
         ops._chk(t, nm)
@@ -37,15 +38,22 @@ def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None):
     dw = torch.empty((n, kh * kw, ctot), device=x0.device, dtype=torch.float32)
     rec = ops._recorder
     ev0 = rec.begin() if rec is not None else None
-    check(lib.ccvpe_conv_wgrad_f32(ops._ptr(x0), c0, ld0, ops._ptr(x1), c1, ld1, ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
-                                   ops._ptr(scratch), b, h, w, kh, kw, stride, pad, n, ops._stream()),
-          "ccvpe_conv_wgrad_f32")
+    dbias = torch.empty((n,), device=x0.device, dtype=torch.float32) if want_bias else None
+    if want_bias:
+        check(lib.ccvpe_conv_wgrad_bias_f32(ops._ptr(x0), c0, ld0, ops._ptr(x1), c1, ld1, ops._ptr(dy), dy.shape[-1],
+                                            ops._ptr(dw), ops._ptr(dbias), ops._ptr(scratch), b, h, w, kh, kw, stride, pad, n,
+                                            ops._stream()), "ccvpe_conv_wgrad_bias_f32")
+    else:
+        check(lib.ccvpe_conv_wgrad_f32(ops._ptr(x0), c0, ld0, ops._ptr(x1), c1, ld1, ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
+                                       ops._ptr(scratch), b, h, w, kh, kw, stride, pad, n, ops._stream()),
+              "ccvpe_conv_wgrad_f32")
     if rec is not None:
         m = dy.numel() // dy.shape[-1]
         tile = lib.ccvpe_conv_wgrad_tile(n, kh * kw * ctot)
         rec.end("conv_wgrad_kernel<%d,%d>" % (tile >> 16, tile & 0xffff), "%dx%d s%d M%d N%d C%d" % (kh, kw, stride, m, n, ctot),
                 2.0 * m * n * kh * kw * ctot, 4.0 * (b * h * w * ctot + m * n + n * kh * kw * ctot), ev0)
-    return dw.reshape(n, kh, kw, ctot).permute(0, 3, 1, 2)                 # OIHW view
+    dw = dw.reshape(n, kh, kw, ctot).permute(0, 3, 1, 2)                   # OIHW view
+    return (dw, dbias) if want_bias else dw
 
 
 def deconv_wgrad(x, dy_hi):

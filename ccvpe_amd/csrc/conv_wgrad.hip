@@ -10,6 +10,7 @@
 // 32-cycle fp32 MFMA that costs nothing.  The pixel range is split over S workgroups per (tile, tap);
 // partials go to scratch and a second kernel adds them in fixed order (deterministic, no atomics).
 #include "common.h"
+#include <cstdlib>
 
 namespace ccvpe {
 
@@ -27,6 +28,7 @@ struct WgradParams {
   int M;                // batch * Ho * Wo
   int S, pix_per_split;
   int tiles_n, tiles_c;
+  float* bias_part;     // optional [S][N]: column sums of dY (the conv's bias gradient) from the tiles with tc == 0, else nullptr
   int ablate;           // diagnostics build only (-DCCVPE_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no fragment reads
 };
 
@@ -96,6 +98,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   f32x4 yr[YP], xr[XP];
   int ykeep = 0, xkeep[XP];
+  // bias gradient = column sums of dY: the first column tile of every row tile adds up the dY pieces it stages anyway
+  // (one pass over dY instead of a second kernel reading it again: ccvpe_colsum_f32 was 3.3 ms of the B = 64 training step)
+  const bool bias_on = p.bias_part != nullptr && tc == 0;
+  f32x4 ysum[YP];
+#pragma unroll
+  for (int q = 0; q < YP; ++q) ysum[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // Pixel cursor of this thread's staged row: decoded ONCE (two integer divisions) and then advanced by WG_BP pixels per
   // stage with compare-and-carry (the per-stage decode was ~80 VALU instructions next to 1 024 cycles of MFMA work).
@@ -153,8 +161,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   auto store_piece = [&](int k, int buf) {
     if (k < YP) {
       const int q = k;
-      if (pc + 32 * q < TN)
-        *reinterpret_cast<i32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, yr[q]) & ykeep;
+      if (pc + 32 * q < TN) {
+        const i32x4 kept = __builtin_bit_cast(i32x4, yr[q]) & ykeep;
+        *reinterpret_cast<i32x4*>(&Ys[(buf * WG_BP + prow) * YLD + pc + 32 * q]) = kept;
+        if (bias_on) ysum[q] += __builtin_bit_cast(f32x4, kept);
+      }
     } else {
       const int q = k - YP;
       *reinterpret_cast<i32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, xr[q]) & xkeep[q];
@@ -277,6 +288,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     if constexpr (!M32) store_stage(buf ^ 1);
     __syncthreads();
   }
+  if (bias_on) {        // (workgroup-uniform) the 32 staging rows of a column -> one sum, fixed order; Ys is dead (loop ended on a barrier)
+#pragma unroll
+    for (int q = 0; q < YP; ++q)
+      if (pc + 32 * q < TN) *reinterpret_cast<f32x4*>(&Ys[prow * YLD + pc + 32 * q]) = ysum[q];
+    __syncthreads();
+    for (int n = tid; n < TN; n += 256) {
+      float t = 0.f;
+#pragma unroll 8
+      for (int r = 0; r < WG_BP; ++r) t += Ys[r * YLD + n];
+      if (n0 + n < p.N) p.bias_part[(size_t)split * p.N + n0 + n] = t;
+    }
+  }
   // D (16x16): row (n) = (lane>>4)*4 + reg, col = lane&15; D (32x32): row = (reg&3) + 8*(reg>>2) + 4*(lane>>5), col = lane&31.
   // dw layout [n][tap][c] == [n][col]
   float* out = p.part + (size_t)split * p.N * ncols;
@@ -387,10 +410,13 @@ static int wgrad_pick(int n, int ncols) {
 }
 static int wgrad_tn(int n, int ncols) { const int t = wgrad_pick(n, ncols); return t == 128 ? 64 : t; }
 static bool wgrad_big(int n, int ncols) { return wgrad_pick(n, ncols) == 128; }
+// (an 80 x 128 tile — 4 waves of 80 x 32, twice the matrix work per stage — measured SLOWER than 80 x 64: 93 vs 102 TF on
+// the N = 80 3x3 layer, 94 vs 104 on N = 160: one workgroup less per CU costs more than the longer stage gains)
+static int wgrad_tc(int n, int ncols) { return wgrad_big(n, ncols) ? 128 : WG_T; }
 static int wgrad_tile_count(int n, int ncols) {
   if (wgrad_big(n, ncols)) return ((n + 127) / 128) * ((ncols + 127) / 128);
-  const int tn = wgrad_tn(n, ncols);
-  return ((n + tn - 1) / tn) * ((ncols + WG_T - 1) / WG_T);
+  const int tn = wgrad_tn(n, ncols), tcw = wgrad_tc(n, ncols);
+  return ((n + tn - 1) / tn) * ((ncols + tcw - 1) / tcw);
 }
 
 // which tile the kernel will use for an [n] x [ncols = taps * channels] weight gradient: (rows << 16) | columns
@@ -398,7 +424,7 @@ static int wgrad_tile_count(int n, int ncols) {
 extern "C" int ccvpe_conv_wgrad_tile(int n, int ncols) {
   if (n <= 0 || ncols <= 0) return CCVPE_EINVAL;
   if (wgrad_big(n, ncols)) return (128 << 16) | 128;
-  return (wgrad_tn(n, ncols) << 16) | WG_T;
+  return (wgrad_tn(n, ncols) << 16) | wgrad_tc(n, ncols);
 }
 
 extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int kw, int stride, int pad,
@@ -408,13 +434,13 @@ extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, in
   if (M <= 0 || M > 0x7fffffffL || ctot <= 0 || n <= 0) return CCVPE_EINVAL;
   const int tiles = wgrad_tile_count(n, kh * kw * ctot);
   const int S = wgrad_splits((int)M, tiles, kh * kw, wgrad_big(n, kh * kw * ctot));
-  const long fl = (long)S * n * kh * kw * ctot;
+  const long fl = (long)S * ((long)n * kh * kw * ctot + n);     // + the bias-gradient partials of ccvpe_conv_wgrad_bias_f32
   return fl > 0x7fffffffL ? CCVPE_EINVAL : (int)fl;
 }
 
-extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
-                                    const float* dy, int ldy, float* dw, float* scratch, int batch, int in_h,
-                                    int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
+static int conv_wgrad_impl(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
+                           const float* dy, int ldy, float* dw, float* dbias, float* scratch, int batch, int in_h,
+                           int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
   if (c0 <= 0 || c0 % 4 || c1 < 0 || c1 % 4 || ld0 % 4 || (c1 && ld1 % 4)) return fail(CCVPE_EINVAL, "conv_wgrad: channels/ld %% 4");
   if (c1 > 0 && !src1) return fail(CCVPE_EINVAL, "conv_wgrad: c1>0 but src1 null");
   if (!aligned16(src0) || (src1 && !aligned16(src1)) || !aligned16(dy) || ldy % 4) return fail(CCVPE_EINVAL, "conv_wgrad: alignment");
@@ -438,11 +464,12 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   const int ctot = c0 + c1;
   const bool big = wgrad_big(n, p.taps * ctot);
   const int tn = big ? 128 : wgrad_tn(n, p.taps * ctot);
-  const int tcw = big ? 128 : WG_T;
+  const int tcw = wgrad_tc(n, p.taps * ctot);
   p.tiles_n = (n + tn - 1) / tn;
   p.tiles_c = (p.taps * ctot + tcw - 1) / tcw;
   p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps, big);
   p.pix_per_split = ((p.M + p.S - 1) / p.S + WG_BP - 1) / WG_BP * WG_BP;
+  p.bias_part = dbias ? scratch + (size_t)p.S * n * p.taps * ctot : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const long blocks = (long)p.tiles_n * p.tiles_c * p.S;
   const size_t lds = sizeof(float) * 2 * WG_BP * ((size_t)(tn + 4) + (tcw + 4));
@@ -461,7 +488,22 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
   else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   const long n_elem = (long)n * p.taps * ctot;
   launch_sum_parts(scratch, p.S, n_elem, (int)n_elem, dw, st);
+  if (dbias) launch_sum_parts(p.bias_part, p.S, n, n, dbias, st);
   return check_launch("conv_wgrad");
+}
+
+extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
+                                    const float* dy, int ldy, float* dw, float* scratch, int batch, int in_h,
+                                    int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
+  return conv_wgrad_impl(src0, c0, ld0, src1, c1, ld1, dy, ldy, dw, nullptr, scratch, batch, in_h, in_w, kh, kw, stride, pad, n,
+                         stream);
+}
+extern "C" int ccvpe_conv_wgrad_bias_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
+                                         const float* dy, int ldy, float* dw, float* dbias, float* scratch, int batch,
+                                         int in_h, int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
+  if (!dbias) return fail(CCVPE_EINVAL, "conv_wgrad_bias: dbias is NULL");
+  return conv_wgrad_impl(src0, c0, ld0, src1, c1, ld1, dy, ldy, dw, dbias, scratch, batch, in_h, in_w, kh, kw, stride, pad, n,
+                         stream);
 }
 
 extern "C" int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch,

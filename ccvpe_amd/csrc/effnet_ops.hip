@@ -26,12 +26,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
     ssh[threadIdx.x] = RAW ? 0.f : shift[threadIdx.x];
   }
   __syncthreads();
+  // output rows go through LDS: a thread owns one pixel (32 channels = 128 bytes), so storing from registers made every
+  // store instruction touch 64 different cache lines with 16 bytes each (1.66 TB/s algorithmic on a pure streaming kernel);
+  // staged [pixel][32 + 4 pad] the workgroup writes its 256 pixels x 128 bytes as one contiguous 32 KB run
+  __shared__ __attribute__((aligned(16))) float ot[256 * 36];
   const long total = (long)B * Ho * Wo;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= total) return;
-  const int ox = (int)(idx % Wo);
-  const int oy = (int)((idx / Wo) % Ho);
-  const int b = (int)(idx / ((long)Wo * Ho));
+  const bool live = idx < total;
+  const long idc = live ? idx : total - 1;
+  const int ox = (int)(idc % Wo);
+  const int oy = (int)((idc / Wo) % Ho);
+  const int b = (int)(idc / ((long)Wo * Ho));
 
   float acc[32];
 #pragma unroll
@@ -57,7 +62,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       }
     }
   }
-  T* out = y + (size_t)idx * 32;
 #pragma unroll
   for (int c4 = 0; c4 < 8; ++c4) {
     f32x4 o;
@@ -67,7 +71,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
       const float v = acc[c] * ssc[c] + ssh[c];
       o[j] = RAW ? acc[c] : swishf(v);
     }
-    st4<T>(out + c4 * 4, o);
+    *reinterpret_cast<f32x4*>(&ot[threadIdx.x * 36 + c4 * 4]) = o;
+  }
+  __syncthreads();
+  const long p0 = (long)blockIdx.x * 256;
+  const int npx = (int)(total - p0 < 256 ? total - p0 : 256);
+  T* out = y + (size_t)p0 * 32;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int piece = it * 256 + threadIdx.x;      // consecutive lanes -> consecutive 16-byte (fp32) / 8-byte (bf16) pieces
+    const int pp = piece >> 3, c4 = piece & 7;
+    if (pp < npx) st4<T>(out + (size_t)pp * 32 + c4 * 4, *reinterpret_cast<const f32x4*>(&ot[pp * 36 + c4 * 4]));
   }
 }
 

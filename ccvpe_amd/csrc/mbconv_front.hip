@@ -46,38 +46,41 @@ struct MbFrontParams {
   float* se_partial;
   int H, W, Cin, kpad, mid, Ho, Wo, circular;
   int tiles_x, tiles_y, nchunks, total_blocks;
+  int ngroups, cpg;      // the chunk loop of a tile is cut into ngroups workgroups of cpg chunks when there are few tiles
 };
 
 constexpr int MBF_MAX_KK = 3;   // Cin <= 48 (fp32) / 96 (bf16)
-constexpr int MBF_PITCH = 20;   // floats per LDS pixel (16 channels + 4 pad)
 
-template <int K, int S>
+// TOH = output rows of the tile (16 columns wide).  The x fragments of the whole halo tile stay in REGISTERS across the
+// channel-chunk loop (TPW tiles x NKK pieces of 16 bytes per lane), so TOH is chosen per (k, stride, Cin) to keep that at
+// <= ~14 registers-of-4 (mbf_toh below; the choice must not depend on the storage type: it fixes the squeeze-partial rows).
+template <int K, int S, int TOH>
 struct MbfGeom {
-  static constexpr int TOW = 16;
-  static constexpr int TOH = S == 1 ? 16 : 8;
+  static constexpr int NOUT = TOH / 4;               // adjacent output columns per depthwise thread (256 = 4 cg x 16/NOUT x TOH)
   static constexpr int IH = (TOH - 1) * S + K;
-  static constexpr int IW = (TOW - 1) * S + K;
+  static constexpr int IW = 15 * S + K;
   static constexpr int NPX = IH * IW;
   static constexpr int NT = (NPX + 15) / 16;         // 16-pixel MFMA tiles of the halo
   static constexpr int TPW = (NT + 3) / 4;           // tiles per wave
-  static constexpr int LDS_FLOATS = NT * 16 * MBF_PITCH + 2 * K * K * 16 + 64;
+  // LDS pixel pitch (floats): neighbouring column groups of the depthwise phase are NOUT*S pixels apart; their 16-byte reads
+  // are conflict-free when that distance is 16 or 48 floats modulo 64
+  static constexpr int PITCH = (NOUT * S == 2) ? 24 : 20;
+  static constexpr int LDS_FLOATS = NT * 16 * PITCH + 2 * K * K * 16 + 64;
 };
 
 // TE = storage type of x / w_exp / y (float or bf16).  NKK counts 64-byte K pieces: 16 fp32 or 32 bf16
 // input channels each; the LDS tile (expanded tensor) and all depthwise math stay fp32 either way.
-template <typename TE, int K, int S, int NKK>
+template <typename TE, int K, int S, int NKK, int TOH>
 __global__ __launch_bounds__(256, 3) void mbconv_front_kernel(const MbFrontParams p) {
-  using G = MbfGeom<K, S>;
+  using G = MbfGeom<K, S, TOH>;
   constexpr int E = 16 / sizeof(TE);
   constexpr int SK = 4 * E;
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;   // pad before (224-schedule SAME)
-  constexpr int TOH = G::TOH, IW = G::IW, NPX = G::NPX, NT = G::NT, TPW = G::TPW;
-  constexpr int GT = NKK == 1 ? 4 : 2;      // tiles whose loads are in flight together
+  constexpr int IW = G::IW, NPX = G::NPX, NT = G::NT, TPW = G::TPW, PITCH = G::PITCH;
   constexpr int KYU = 1;
-  constexpr int NGR = (TPW + GT - 1) / GT;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* tile = sm;                                  // [NT*16][MBF_PITCH]
-  float* wdw = sm + NT * 16 * MBF_PITCH;             // [2][K*K][16]
+  float* tile = sm;                                  // [NT*16][PITCH]
+  float* wdw = sm + NT * 16 * PITCH;                 // [2][K*K][16]
   float* red = wdw + 2 * K * K * 16;                 // [4 waves][4 cg][4]
 
   const int tid = threadIdx.x;
@@ -90,127 +93,118 @@ __global__ __launch_bounds__(256, 3) void mbconv_front_kernel(const MbFrontParam
     const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
     lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
+  const int grp = lb % p.ngroups;                    // chunk groups of one tile are neighbours: they re-read the same x halo
+  lb /= p.ngroups;
   const int tx = lb % p.tiles_x;                     // neighbouring tiles (shared halo) on one XCD
   const int ty = (lb / p.tiles_x) % p.tiles_y;
   const int b = lb / (p.tiles_x * p.tiles_y);
   const int oy0 = ty * TOH, ox0 = tx * 16;
   const int iy0 = oy0 * S - PB, ix0 = ox0 * S - PB;
+  const int kq = (lane >> 4) * E;                    // first input channel of this lane's k group inside a 64-byte piece
+  const int q4 = (lane >> 4) * 4;                    // D rows (channels) of this lane: q4 .. q4+3
 
-  // ---- expand-phase coordinates: this wave's tiles t = wave + 4*i; lane -> pixel q = 16*t + (lane & 15) of the halo.
-  // The address of a tile's pixel is recomputed where it is needed (a dozen integer instructions per 16-pixel tile) instead
-  // of being kept in a register array: the first version held offsets + two fully unrolled register sets and needed 200-256
-  // VGPRs (1-2 waves per SIMD).
+  // ---- the x halo tile, ONCE: this wave's 16-pixel tiles t = wave + 4*i, lane -> pixel q = 16*t + (lane & 15), straight
+  // from global memory in MFMA operand layout (16 bytes of k group lane>>4); all TPW*NKK loads in flight together.  Pixels
+  // outside the image read a clamped address; their EXPANDED value is forced to zero below (the depthwise conv pads the
+  // expanded tensor); k groups beyond Cin re-read the pixel's first channels and meet the zero padding of the packed weights.
   const TE* xb = reinterpret_cast<const TE*>(p.x) + (size_t)b * p.H * p.W * p.Cin;
-  auto pixel_offset = [&](int i, bool& ok) -> unsigned {
+  f32x4 xr[TPW][NKK];
+  unsigned pvalid = 0;
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
     const int q = 16 * (wave + 4 * i) + (lane & 15);
     const int hy = q / IW, hx = q - hy * IW;
     const int gy = iy0 + hy;
     int gx = ix0 + hx;
     if (p.circular) gx = gx < 0 ? gx + p.W : (gx >= p.W ? gx - p.W : gx);
-    ok = q < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-    return ok ? (unsigned)((gy * p.W + gx) * p.Cin) * (unsigned)sizeof(TE) : 0u;
-  };
-  const int kq = (lane >> 4) * E;                    // first input channel of this lane's k group inside a 64-byte piece
-  const int q4 = (lane >> 4) * 4;                    // D rows (channels) of this lane: q4 .. q4+3
+    const bool ok = q < NPX && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    pvalid |= ok ? (1u << i) : 0u;
+    const unsigned off = ok ? (unsigned)((gy * p.W + gx) * p.Cin) * (unsigned)sizeof(TE) : 0u;
+#pragma unroll
+    for (int kk = 0; kk < NKK; ++kk) {
+      const int ch = kk * SK + kq;
+      xr[i][kk] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) + off + (unsigned)(ch < p.Cin ? ch : 0) * (unsigned)sizeof(TE));
+    }
+  }
 
   // ---- depthwise-phase coordinates -----------------------------------------------------------------------------------------
-  constexpr int NOUT = 4 / S;                        // adjacent output columns per thread: 4 (s1) / 2 (s2)
+  constexpr int NOUT = G::NOUT;
   constexpr int NCOLS = (NOUT - 1) * S + K;          // input columns read per kernel row
   constexpr int XG = 16 / NOUT;                      // column groups per tile row
   const int cg = tid & 3;
   const int oxg = (tid >> 2) % XG;
-  const int oyl = (tid >> 2) / XG;                   // 0 .. TOH-1   (256 threads = 4 cg x XG x TOH)
+  const int oyl = (tid >> 2) / XG;                   // 0 .. TOH-1
   const int oy = oy0 + oyl;
   const int oxl = oxg * NOUT;
   const bool row_ok = oy < p.Ho;
   TE* yrow = reinterpret_cast<TE*>(p.y) + ((size_t)(b * p.Ho + (row_ok ? oy : 0)) * p.Wo) * p.mid;
-  const float* trow = tile + ((oyl * S) * IW + oxl * S) * MBF_PITCH + cg * 4;
+  const float* trow = tile + ((oyl * S) * IW + oxl * S) * PITCH + cg * 4;
 
-  for (int chunk = 0; chunk < p.nchunks; ++chunk) {
+  // ---- per-chunk parameters: loaded one chunk AHEAD (under the previous chunk's depthwise phase) ------------------------------
+  f32x4 wf[NKK], sc0, sh0, sc1, sh1, wdr;
+  auto load_chunk_params = [&](int chunk) {
     const int c0 = chunk * 16;
-    // depthwise weights of this chunk -> LDS (double-buffered across chunks: no extra barrier)
-    float* wd = wdw + (chunk & 1) * K * K * 16;
-    if (tid < K * K * 4) *reinterpret_cast<f32x4*>(wd + tid * 4) =
-        *reinterpret_cast<const f32x4*>(p.w_dw + (size_t)(tid >> 2) * p.mid + c0 + (tid & 3) * 4);
-    // expand weights (MFMA A operand: row n = lane&15, k group = lane>>4) and BN0 of this chunk
-    f32x4 wf[NKK];
 #pragma unroll
-    for (int kk = 0; kk < NKK; ++kk)
+    for (int kk = 0; kk < NKK; ++kk)   // expand weights: MFMA A operand, row n = lane&15, k group = lane>>4
       wf[kk] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const TE*>(p.w_exp) + (size_t)(c0 + (lane & 15)) * p.kpad + kk * SK + kq);
-    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(p.s0 + c0 + q4);
-    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(p.b0 + c0 + q4);
+    sc0 = *reinterpret_cast<const f32x4*>(p.s0 + c0 + q4);
+    sh0 = *reinterpret_cast<const f32x4*>(p.b0 + c0 + q4);
+    sc1 = *reinterpret_cast<const f32x4*>(p.s1 + c0 + cg * 4);
+    sh1 = *reinterpret_cast<const f32x4*>(p.b1 + c0 + cg * 4);
+    const int wi = tid < K * K * 4 ? tid : 0;        // depthwise weights [tap][16]: one 16-byte piece per thread
+    wdr = *reinterpret_cast<const f32x4*>(p.w_dw + (size_t)(wi >> 2) * p.mid + c0 + (wi & 3) * 4);
+  };
+  const int chunk_begin = grp * p.cpg, chunk_end = min(p.nchunks, chunk_begin + p.cpg);
+  load_chunk_params(chunk_begin);
 
-    // ---- expand: groups of GT tiles, the loads of group g+1 in flight under the MFMAs / swish of group g ----------------
-    f32x4 xv[2][GT][NKK];
-    unsigned okm[2] = {0u, 0u};                      // per register set: bit u = the tile's pixel of this lane is inside the image
-    auto load_group = [&](int g, auto set_tag) {
-      constexpr int SET = decltype(set_tag)::value;
-      okm[SET] = 0;
+  for (int chunk = chunk_begin; chunk < chunk_end; ++chunk) {
+    const int c0 = chunk * 16;
+    float* wd = wdw + (chunk & 1) * K * K * 16;
+    if (tid < K * K * 4) *reinterpret_cast<f32x4*>(wd + tid * 4) = wdr;
+    // ---- expand: registers -> MFMA -> BN0 + swish -> LDS tile (no global loads in this phase) ------------------------------
 #pragma unroll
-      for (int u = 0; u < GT; ++u) {
-        const int i = g * GT + u;
-        bool ok;
-        const unsigned off = pixel_offset(i < TPW ? i : TPW - 1, ok);
-        okm[SET] |= (ok && i < TPW) ? (1u << u) : 0u;
+    for (int i = 0; i < TPW; ++i) {
+      if (wave + 4 * i < NT) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
-          const int ch = kk * SK + kq;
-          xv[SET][u][kk] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(xb) + off +
-                                                           (unsigned)(ch < p.Cin ? ch : 0) * (unsigned)sizeof(TE));
-        }
-      }
-    };
-    auto compute_group = [&](int g, auto set_tag) {
-      constexpr int SET = decltype(set_tag)::value;
+          if (sizeof(TE) == 4) {
 #pragma unroll
-      for (int u = 0; u < GT; ++u) {
-        const int i = g * GT + u;
-        if (i < TPW && wave + 4 * i < NT) {
-          f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-          for (int kk = 0; kk < NKK; ++kk) {
-            // (k groups beyond Cin inside the last 64-byte piece re-read the pixel's first channels — the address is clamped —
-            // and meet the zero padding of the packed weights)
-            const f32x4 xq = xv[SET][u][kk];
-            if (sizeof(TE) == 4) {
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xq[r], acc, 0, 0, 0);
-            } else {
-              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]), __builtin_bit_cast(cc_bf16x8, xq),
-                                                            acc, 0, 0, 0);
-            }
+            for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[kk][r], xr[i][kk][r], acc, 0, 0, 0);
+          } else {
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]), __builtin_bit_cast(cc_bf16x8, xr[i][kk]),
+                                                          acc, 0, 0, 0);
           }
-          // D: row = channel q4 + reg, col = pixel lane & 15
-          f32x4 o;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) o[r] = swishf(acc[r] * sc0[r] + sh0[r]);
-          o = keepv(o, (okm[SET] >> u) & 1u);
-          *reinterpret_cast<f32x4*>(tile + (16 * (wave + 4 * i) + (lane & 15)) * MBF_PITCH + q4) = o;
         }
+        // D: row = channel q4 + reg, col = pixel lane & 15
+        f32x4 o;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = swishf(acc[r] * sc0[r] + sh0[r]);
+        // one mask word per tile, made from its bit when it is needed (a vector `keep ? -1 : 0` select was hoisted out of the
+        // chunk loop as FOUR mask registers per tile: 36 VGPRs for 9 tiles)
+        const bool inside = (pvalid >> i) & 1u;      // a lane mask in scalar registers, four selects
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] = inside ? o[r] : 0.f;
+        *reinterpret_cast<f32x4*>(tile + (16 * (wave + 4 * i) + (lane & 15)) * PITCH + q4) = o;
       }
-    };
-    load_group(0, std::integral_constant<int, 0>{});
-#pragma unroll 1
-    for (int g = 0; g < NGR; g += 2) {
-      if (g + 1 < NGR) load_group(g + 1, std::integral_constant<int, 1>{});
-      compute_group(g, std::integral_constant<int, 0>{});
-      if (g + 2 < NGR) load_group(g + 2, std::integral_constant<int, 0>{});
-      if (g + 1 < NGR) compute_group(g + 1, std::integral_constant<int, 1>{});
+      // two tiles at a time (two independent accumulator chains); without the fence the scheduler issues the MFMAs of all
+      // TPW tiles first and keeps every accumulator + swish temporary live
+      if (i & 1) __builtin_amdgcn_sched_barrier(0);
     }
+    const f32x4 sc1c = sc1, sh1c = sh1;              // this chunk's BN1 (the registers are re-loaded below)
     __syncthreads();
+    if (chunk + 1 < chunk_end) load_chunk_params(chunk + 1);   // in flight under the depthwise phase
 
     // ---- depthwise: NOUT adjacent outputs of one row for 4 channels, window slid through registers -------------------------
-    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(p.s1 + c0 + cg * 4);
-    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(p.b1 + c0 + cg * 4);
     f32x4 acc[NOUT];
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // k = 5: one kernel row of window reads in flight at a time (fully unrolled the scheduler hoists all 35-40 ds_read_b128)
+    // one kernel row of window reads in flight at a time (fully unrolled the scheduler hoists all of them: 200+ VGPRs)
 #pragma unroll KYU
     for (int ky = 0; ky < K; ++ky) {
       f32x4 col[NCOLS];
 #pragma unroll
-      for (int j = 0; j < NCOLS; ++j) col[j] = *reinterpret_cast<const f32x4*>(trow + (ky * IW + j) * MBF_PITCH);
+      for (int j = 0; j < NCOLS; ++j) col[j] = *reinterpret_cast<const f32x4*>(trow + (ky * IW + j) * PITCH);
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         const f32x4 wv = *reinterpret_cast<const f32x4*>(wd + (ky * K + kx) * 16 + cg * 4);
@@ -222,7 +216,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_front_kernel(const MbFrontParam
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) {
       const int ox = ox0 + oxl + t;
-      f32x4 o = acc[t] * sc1 + sh1;
+      f32x4 o = acc[t] * sc1c + sh1c;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[r] = swishf(o[r]);
       if (row_ok && ox < p.Wo) {
@@ -248,9 +242,20 @@ __global__ __launch_bounds__(256, 3) void mbconv_front_kernel(const MbFrontParam
   }
 }
 
-static bool mbf_supported(int W, int cin, int mid, int k, int sk = 16) {
-  (void)W; (void)k;
-  return cin % 8 == 0 && cin <= sk * MBF_MAX_KK && mid % 16 == 0;
+// output rows per tile for (k, stride, Cin): keeps TPW * ceil(Cin / 16) register fragments per lane small (see MbfGeom);
+// depends on Cin through the fp32 piece count for BOTH storage types
+static int mbf_toh(int k, int stride, int cin) {
+  const int n = (cin + 15) / 16;
+  if (stride == 2) return n == 1 ? 8 : 4;
+  return (n == 1 && k == 3) ? 16 : 8;
+}
+
+// (k = 5, stride 2 with more than 32 input channels is not instantiated: 11 tiles x 3 pieces of x do not fit the register
+// budget of 3 waves per SIMD; EfficientNet-B0 has no such block.)  `stride` < 0: any.
+static bool mbf_supported(int W, int cin, int mid, int k, int sk = 16, int stride = -1) {
+  (void)W;
+  if (k == 5 && stride == 2 && cin > 32) return false;
+  return cin % 8 == 0 && cin <= 16 * MBF_MAX_KK && cin <= sk * MBF_MAX_KK && mid % 16 == 0;
 }
 
 }  // namespace ccvpe
@@ -260,10 +265,10 @@ using namespace ccvpe;
 // number of squeeze-partial rows per sample = spatial tiles per sample (0 => use the unfused kernels)
 extern "C" int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int k, int stride) {
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return CCVPE_EINVAL;
-  if (!mbf_supported(in_w, cin, mid, k)) return 0;
+  if (!mbf_supported(in_w, cin, mid, k, 16, stride)) return 0;
   const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
   const int Ho = (in_h + total_pad - k) / stride + 1, Wo = (in_w + total_pad - k) / stride + 1;
-  const int toh = stride == 1 ? 16 : 8;
+  const int toh = mbf_toh(k, stride, cin);
   return ((Ho + toh - 1) / toh) * ((Wo + 15) / 16);
 }
 
@@ -273,7 +278,7 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
                             int H, int W, int cin, int mid, int k, int stride, int circular, void* stream) {
   constexpr int SK = 4 * (16 / (int)sizeof(TE));
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "mbconv_front: k/stride unsupported");
-  if (!mbf_supported(W, cin, mid, k, SK)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
+  if (!mbf_supported(W, cin, mid, k, SK, stride)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
   if (kpad % SK || kpad < cin) return fail(CCVPE_EINVAL, "mbconv_front: bad kpad");
   if (!aligned16(x) || !aligned16(w_exp) || !aligned16(s0) || !aligned16(b0) || !aligned16(s1) || !aligned16(b1) ||
       !aligned16(y) || !aligned16(se_partial) || !aligned16(w_dw))
@@ -286,11 +291,18 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
   const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
   p.Ho = (H + total_pad - k) / stride + 1;
   p.Wo = (W + total_pad - k) / stride + 1;
-  const int toh = stride == 1 ? 16 : 8;
+  const int toh = mbf_toh(k, stride, cin);
   p.tiles_x = (p.Wo + 15) / 16;
   p.tiles_y = (p.Ho + toh - 1) / toh;
   p.nchunks = mid / 16;
-  const long total = (long)p.tiles_x * p.tiles_y * B;
+  // few tiles (small planes): cut the chunk loop so that the launch still has ~8 workgroups per CU
+  const long tiles = (long)p.tiles_x * p.tiles_y * B;
+  int ng = (int)((2048 + tiles - 1) / tiles);
+  if (ng > p.nchunks) ng = p.nchunks;
+  if (ng < 1) ng = 1;
+  p.cpg = (p.nchunks + ng - 1) / ng;
+  p.ngroups = (p.nchunks + p.cpg - 1) / p.cpg;
+  const long total = tiles * p.ngroups;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "mbconv_front: grid too large");
   p.total_blocks = (int)total;
   hipStream_t st = (hipStream_t)stream;
@@ -304,14 +316,20 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds, st, p);
   };
-#define MBF_N(K_, S_)                                                                            \
-  if (nkk == 1) go(mbconv_front_kernel<TE, K_, S_, 1>, MbfGeom<K_, S_>::LDS_FLOATS);              \
-  else if (nkk == 2) go(mbconv_front_kernel<TE, K_, S_, 2>, MbfGeom<K_, S_>::LDS_FLOATS);         \
-  else go(mbconv_front_kernel<TE, K_, S_, 3>, MbfGeom<K_, S_>::LDS_FLOATS)
-  if (k == 3 && stride == 1) { MBF_N(3, 1); }
-  else if (k == 3 && stride == 2) { MBF_N(3, 2); }
-  else if (k == 5 && stride == 1) { MBF_N(5, 1); }
-  else { MBF_N(5, 2); }
+  // instantiated: the big tile for Cin <= 16 (one K piece in either storage type), the small tile for 1-3 pieces
+#define MBF_N(K_, S_, TOH_)                                                                                  \
+  if (nkk == 1) go(mbconv_front_kernel<TE, K_, S_, 1, TOH_>, MbfGeom<K_, S_, TOH_>::LDS_FLOATS);                \
+  else if (nkk == 2) go(mbconv_front_kernel<TE, K_, S_, 2, TOH_>, MbfGeom<K_, S_, TOH_>::LDS_FLOATS);           \
+  else go(mbconv_front_kernel<TE, K_, S_, 3, TOH_>, MbfGeom<K_, S_, TOH_>::LDS_FLOATS)
+#define MBF_T(K_, S_, BIG_, SMALL_)                                                                          \
+  if (toh == BIG_) { go(mbconv_front_kernel<TE, K_, S_, 1, BIG_>, MbfGeom<K_, S_, BIG_>::LDS_FLOATS); } else { MBF_N(K_, S_, SMALL_); }
+  if (k == 3 && stride == 1) { MBF_T(3, 1, 16, 8) }
+  else if (k == 3 && stride == 2) { MBF_T(3, 2, 8, 4) }
+  else if (k == 5 && stride == 1) { MBF_N(5, 1, 8); }
+  else if (toh == 8) { go(mbconv_front_kernel<TE, 5, 2, 1, 8>, MbfGeom<5, 2, 8>::LDS_FLOATS); }
+  else if (nkk == 1) { go(mbconv_front_kernel<TE, 5, 2, 1, 4>, MbfGeom<5, 2, 4>::LDS_FLOATS); }
+  else { go(mbconv_front_kernel<TE, 5, 2, 2, 4>, MbfGeom<5, 2, 4>::LDS_FLOATS); }
+#undef MBF_T
 #undef MBF_N
   if (rc) return rc;
   return check_launch("mbconv_front_kernel");

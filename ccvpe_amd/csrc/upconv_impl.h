@@ -493,293 +493,6 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
-// ---------------------------------------------------------------------------------------------
-// upconv, BOTH sources as halo tiles of the LOW-RES grid (round 3).
-//
-// For output parity (py,px) the skip taps are  skip[2*y1 + py + ky - 1, 2*x1 + px + kx - 1].  Write the skip in
-// space-to-depth form  S'[y, x, (ry, rx, c)] = skip[2y + ry, 2x + rx, c]  (a pure re-indexing of the same NHWC memory):
-//   py + ky - 1 = 2*dy + ry   with   dy = a + py - 1,  a in {0,1}   <=>   ky = 2a + py + ry - 1
-// so every skip tap is a tap (a, b) of the SAME 2x2 low-res neighbourhood {py-1, py} x {px-1, px} the folded deconv
-// taps use, applied to sub-image (ry, rx).  Sub-image (ry, rx) carries |A(ry)| x |B(rx)| taps (A = {a : 0 <= ky <= 2}):
-// 4 + 2 + 2 + 1 = the nine 3x3 taps.  The whole GEMM therefore runs on the conv3x3 machinery: per 64-byte channel
-// chunk of a source a (TH+1) x 17 halo of LOW-RES positions is staged ONCE in LDS and its 1-4 taps read their pixel
-// fragments from it at shifted addresses (upconv_halo_kernel gathered the skip per tap through registers: nine L2 reads
-// and nine VGPR -> LDS round trips per skip element, 0.7-1.4 vector-ALU instructions per MFMA against 0.10 in the
-// 3x3 kernel); the W panels of a stage (a PAIR of taps) arrive by LDS-DMA with scalar-base addressing, requested at the
-// start of the previous stage; the halo is double-buffered so a stage ends in exactly one barrier.
-// Same packed weights / shift table as the other two kernels.  Needs W1 >= 16 and Npad % BN == 0 (the DMA cannot guard rows).
-// ---------------------------------------------------------------------------------------------
-template <typename T, int MT, int NT, int WN>
-struct UpS2dGeom {
-  static constexpr int WM = 4 / WN;
-  static constexpr int BM = 16 * MT * WM;
-  static constexpr int BN = 16 * NT * WN;
-  static constexpr int TH = BM / 16;
-  static constexpr int HR = TH + 1, HC = 17, HPX = HR * HC;
-  static constexpr int HS_FLOATS = HPX * LDS_LD;            // one halo buffer
-  static constexpr int BS_FLOATS = 2 * 2 * BN * 16;         // [stage parity][tap of the pair][BN][64 bytes]
-  static constexpr int LDS_BYTES = (2 * HS_FLOATS + BS_FLOATS) * 4;
-};
-
-template <typename T, int MT, int NT, int WN>
-__global__ __launch_bounds__(256, 2) void upconv_s2d_kernel(const UpParams p) {
-  using G = UpS2dGeom<T, MT, NT, WN>;
-  constexpr int E = ElemTraits<T>::E;
-  constexpr int SK = 4 * E;                        // channels per chunk: 16 (fp32) or 32 (bf16)
-  constexpr int WM = G::WM, BM = G::BM, BN = G::BN, TH = G::TH, HC = G::HC, HPX = G::HPX;
-  constexpr int H_IT = (HPX * 4 + 255) / 256;
-  constexpr int NSLOT = (BN / 16 + 3) / 4;         // 16-row W groups per wave
-
-  extern __shared__ __attribute__((aligned(16))) float us_sm[];
-  float* Hs = us_sm;                               // [2][HPX][LDS_LD]
-  float* Bs = us_sm + 2 * G::HS_FLOATS;            // [2][2][BN][16]
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = sgpr(tid >> 6);
-  const int wm = wave / WN;
-  const int wn = wave % WN;
-
-  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
-  const int tn = tile % p.tiles_n;
-  const int par = (tile / p.tiles_n) & 3;
-  const int ts = tile / (p.tiles_n * 4);           // low-res spatial tile: x fastest, y, sample
-  const int tiles_x = (p.W1 + 15) / 16;
-  const int tiles_y = (p.H1 + TH - 1) / TH;
-  const int tx = ts % tiles_x;
-  const int ty = (ts / tiles_x) % tiles_y;
-  const int b = ts / (tiles_x * tiles_y);
-  const int py = par >> 1, px = par & 1;
-  const int y0 = ty * TH, x0 = tx * 16;
-  const int n0 = tn * BN;
-  const int H2 = 2 * p.H1, W2 = 2 * p.W1;
-
-  const char* src0 = reinterpret_cast<const char*>(p.src0);
-  const char* src1 = reinterpret_cast<const char*>(p.src1);
-  const T* wp = reinterpret_cast<const T*>(p.w) + (size_t)par * p.Npad * p.Kpad;
-  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
-
-  // ---- halo staging coordinates (fixed per thread): halo pixel (hy, hx) <-> low-res position (y0+py-1+hy, x0+px-1+hx) ----
-  int h_off[H_IT];          // LDS float offset inside a halo buffer, -1 if the slot is unused
-  unsigned h_b0[H_IT];      // byte offset of the low-res pixel row in src0
-  unsigned h_b1[H_IT];      // byte offset of skip pixel (2y, 2x) in src1
-  unsigned h_ok = 0;        // bit it: the position is inside the low-res image
-  int h_sub[H_IT];
-#pragma unroll
-  for (int it = 0; it < H_IT; ++it) {
-    const int idx = tid + 256 * it;
-    const int pxl = idx >> 2, sub = idx & 3;
-    h_sub[it] = sub;
-    h_off[it] = -1;
-    h_b0[it] = 0;
-    h_b1[it] = 0;
-    if (pxl < HPX) {
-      const int hy = pxl / HC, hx = pxl - hy * HC;
-      const int iy = y0 + py - 1 + hy, ix = x0 + px - 1 + hx;
-      h_off[it] = pxl * LDS_LD + sub * 4;
-      if ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1) {
-        h_ok |= 1u << it;
-        h_b0[it] = (unsigned)((b * p.H1 + iy) * p.W1 + ix) * (unsigned)ld0s * (unsigned)sizeof(T);
-        h_b1[it] = (unsigned)((b * H2 + 2 * iy) * W2 + 2 * ix) * (unsigned)ld1s * (unsigned)sizeof(T);
-      }
-    }
-  }
-
-  // ---- segment / tap arithmetic (all workgroup-uniform) ----------------------------------------------------------
-  // seg 0 = low-res source (4 taps); seg 1..4 = skip sub-image (ry, rx) = ((seg-1)>>1, (seg-1)&1)
-  const int nch0 = (p.c0 + SK - 1) / SK, nch1 = (p.c1 + SK - 1) / SK;
-  const int nseg = p.c1 > 0 ? 5 : 1;
-  struct Seg { int na, nb, a0, b0, q, qx; };
-  auto seg_info = [&](int seg) {
-    Seg s;
-    if (seg == 0) { s.na = 2; s.nb = 2; s.a0 = 0; s.b0 = 0; s.q = 0; s.qx = 0; return s; }
-    const int ry = (seg - 1) >> 1, rx = (seg - 1) & 1;
-    s.q = py + ry - 1; s.qx = px + rx - 1;         // ky = 2a + q, kx = 2b + qx must lie in 0..2
-    s.na = s.q == 0 ? 2 : 1; s.a0 = s.q < 0 ? 1 : 0;
-    s.nb = s.qx == 0 ? 2 : 1; s.b0 = s.qx < 0 ? 1 : 0;
-    return s;
-  };
-  // tap t of segment seg: (a, b) and the first K column of its weights
-  auto tap_of = [&](int seg, const Seg& s, int t, int& a, int& bcol, int& wcol) {
-    const int ta = t / s.nb, tb = t - ta * s.nb;
-    a = s.a0 + ta; bcol = s.b0 + tb;
-    wcol = seg == 0 ? (a * 2 + bcol) * p.c0 : 4 * p.c0 + ((2 * a + s.q) * 3 + (2 * bcol + s.qx)) * p.c1;
-  };
-
-  f32x4 h_reg[H_IT];
-  unsigned h_keep = 0;
-  auto load_halo = [&](int seg, int chunk) {        // raw loads from clamped addresses; masked at the LDS store (STAGING RULE)
-    const bool first = seg == 0;
-    const char* base = first ? src0 : src1;
-    const int cmax = first ? p.c0 : p.c1;
-    // skip sub-image (ry, rx): pixel (2y + ry, 2x + rx)
-    const unsigned sdelta = first ? 0u : (unsigned)((((seg - 1) >> 1) * W2 + ((seg - 1) & 1)) * ld1s) * (unsigned)sizeof(T);
-    h_keep = 0;
-#pragma unroll
-    for (int it = 0; it < H_IT; ++it) {
-      const int ch = chunk * SK + h_sub[it] * E;
-      const bool ok = ((h_ok >> it) & 1u) && ch < cmax;
-      const unsigned off = ok ? (first ? h_b0[it] : h_b1[it] + sdelta) + (unsigned)ch * (unsigned)sizeof(T) : 0u;
-      h_reg[it] = *reinterpret_cast<const f32x4*>(base + off);
-      h_keep |= ok ? (1u << it) : 0u;
-    }
-  };
-  auto store_halo = [&](int hbuf) {
-#pragma unroll
-    for (int it = 0; it < H_IT; ++it)
-      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(Hs + hbuf * G::HS_FLOATS + h_off[it]) = keep_if(h_reg[it], (h_keep >> it) & 1u);
-  };
-
-  // W panels by LDS-DMA: lane -> (row = lane>>2, swizzled 16-byte piece); stage-invariant per-lane offsets (see conv3x3_kernel)
-  unsigned wvoff[NSLOT];
-  {
-    const int rl = lane >> 2;
-    const int c = (lane & 3) ^ w_swz(rl);
-#pragma unroll
-    for (int q = 0; q < NSLOT; ++q) {
-      const int g = min(wave + 4 * q, BN / 16 - 1);
-      wvoff[q] = ((unsigned)(n0 + g * 16 + rl) * (unsigned)p.Kpad + (unsigned)(c * E)) * (unsigned)sizeof(T);
-    }
-  }
-  const unsigned bs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
-  auto load_w = [&](int seg, int chunk, int tg, int dbuf) {   // the (up to 2) taps 2*tg, 2*tg+1 of (seg, chunk) -> Bs[dbuf][0..1]
-    const Seg s = seg_info(seg);
-    const int nt = s.na * s.nb;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (2 * tg + t < nt) {
-        int a, bc, wcol;
-        tap_of(seg, s, 2 * tg + t, a, bc, wcol);
-        const char* sbase = reinterpret_cast<const char*>(wp) + ((size_t)wcol + (size_t)chunk * SK) * sizeof(T);
-#pragma unroll
-        for (int q = 0; q < NSLOT; ++q) {
-          const int g = wave + 4 * q;
-          if (g < BN / 16) {
-            const unsigned lds = __builtin_amdgcn_readfirstlane(bs_lds + (unsigned)(((dbuf * 2 + t) * BN + g * 16) * 16 * 4));
-            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(wvoff[q]), "s"(sbase)
-                         : "memory", "m0");
-          }
-        }
-      }
-    }
-  };
-
-  f32x4 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  const int frow = lane & 15;
-  const int fk = (lane >> 4) * 4;
-  const int bcol = ((lane >> 4) ^ w_swz(frow)) * 4;
-
-  // ---- prologue: halo + W of stage 0 ----------------------------------------------------------------------------
-  int seg = 0, chunk = 0, tg = 0, hbuf = 0, sidx = 0;
-  load_halo(0, 0);
-  load_w(0, 0, 0, 0);
-  store_halo(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  while (true) {
-    const Seg s = seg_info(seg);
-    const int nt = s.na * s.nb;
-    const int ngroups = (nt + 1) >> 1;
-    const int nch = seg == 0 ? nch0 : nch1;
-    // next stage
-    int nseg_ = seg, nchunk = chunk, ntg = tg + 1;
-    bool new_chunk = false;
-    if (ntg == ngroups) {
-      ntg = 0; new_chunk = true;
-      if (++nchunk == nch) { nchunk = 0; ++nseg_; }
-    }
-    const bool more = nseg_ < nseg;
-
-    int a0, b0, w0, a1 = 0, b1 = 0, w1 = 0;
-    tap_of(seg, s, 2 * tg, a0, b0, w0);
-    const bool two = 2 * tg + 1 < nt;
-    if (two) tap_of(seg, s, 2 * tg + 1, a1, b1, w1);
-    (void)w0; (void)w1;
-
-    f32x4 af[2][MT], bf[2][NT];
-    const float* hs = Hs + hbuf * G::HS_FLOATS;
-    auto read_frag = [&](int t, int a, int bc, f32x4* af_, f32x4* w_) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af_[i] = *reinterpret_cast<const f32x4*>(hs + (((wm * MT + i) + a) * HC + frow + bc) * LDS_LD + fk);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        w_[j] = *reinterpret_cast<const f32x4*>(&Bs[((((sidx & 1) * 2 + t) * BN) + (wn * NT + j) * 16 + frow) * 16 + bcol]);
-    };
-    read_frag(0, a0, b0, af[0], bf[0]);
-    if (two) read_frag(1, a1, b1, af[1], bf[1]);     // second tap's fragments: in flight under the first tap's MFMAs
-    // next stage's halo (when it opens a new chunk) and W panels: requested under this stage's matrix work
-    if (more && new_chunk) load_halo(nseg_, nchunk);
-    if (more) load_w(nseg_, nchunk, ntg, (sidx + 1) & 1);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (t == 1 && !two) break;
-      if (sizeof(T) == 4) {
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-          for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int j = 0; j < NT; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t][j][kk], af[t][i][kk], acc[i][j], 0, 0, 0);
-      } else {
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[t][j], af[t][i], acc[i][j]);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!more) break;
-    if (new_chunk) store_halo(hbuf ^ 1);             // the other buffer: its last readers finished before the previous barrier
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's share of the W panels has landed
-    __syncthreads();
-    if (new_chunk) hbuf ^= 1;
-    seg = nseg_; chunk = nchunk; tg = ntg; ++sidx;
-  }
-
-  // ---- epilogue: pixel (2y1+py, 2x1+px); shift picked by the pixel's border class --------------------------------
-  const int epix = lane & 15;
-  const int en = (lane >> 4) * 4;
-  IgemmParams ep{};
-  ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
-  const float one[4] = {1.f, 1.f, 1.f, 1.f};
-  const int x1 = x0 + epix;
-  auto epilogue = [&](auto act_tag) {
-  constexpr int ACT = decltype(act_tag)::value;
-#pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int y1 = y0 + wm * MT + i;
-    if (y1 >= p.H1 || x1 >= p.W1) continue;
-    const int Y = 2 * y1 + py, X = 2 * x1 + px;
-    const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
-    const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
-    const float* shp = p.shift9 + (size_t)(rc * 3 + cc) * p.N;
-    const size_t pix = (size_t)(b * H2 + Y) * W2 + X;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int n = n0 + (wn * NT + j) * 16 + en;
-      if (n >= p.N) continue;
-      float sh[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) sh[q] = (n + q < p.N) ? shp[n + q] : 0.f;
-      store4<T, ACT>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
-    }
-  }
-  };
-  CCVPE_ACT_DISPATCH(p.act, epilogue);
-}
-
-// CCVPE_UPCONV_S2D=0: keep the round-2 kernels (A/B runs)
-static const bool g_up_s2d = !(getenv("CCVPE_UPCONV_S2D") && getenv("CCVPE_UPCONV_S2D")[0] == '0');
-
 template <typename T, int MT, int NT, int WN>
 static int launch_up(const UpParams& p0, hipStream_t stream) {
   constexpr int WM = 4 / WN;
@@ -796,20 +509,6 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
   const long total = (long)p.tiles_m * p.tiles_n * 4;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "upconv: grid too large");
   p.tiles_total = (int)total;
-  // both sources below 4 GB (32-bit byte offsets in the halo loader) and full column tiles (the W DMA has no row guard)
-  const double bytes0 = (double)p.M * p.ld0 * sizeof(T), bytes1 = (double)p.M * 4.0 * p.ld1 * sizeof(T);
-  if (halo && g_up_s2d && p.Npad % BN == 0 && bytes0 < 4294967296.0 && bytes1 < 4294967296.0) {
-    using G = UpS2dGeom<T, MT, NT, WN>;
-    static bool attr_set = false;                 // one flag per instantiation
-    if (!attr_set && G::LDS_BYTES > 48 * 1024) {
-      hipError_t e = hipFuncSetAttribute((const void*)upconv_s2d_kernel<T, MT, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         G::LDS_BYTES);
-      if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "upconv: set smem attr: %s", hipGetErrorString(e));
-      attr_set = true;
-    }
-    hipLaunchKernelGGL((upconv_s2d_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
-    return check_launch("upconv_s2d_kernel");
-  }
   if (halo)
     hipLaunchKernelGGL((upconv_halo_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
   else

@@ -211,7 +211,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
         flops = algo_flops if algo_flops is not None else 2.0 * m * n * k_eff
         esz = 4.0 if dt == torch.float32 else 2.0
         nbytes = esz * (batch * h1 * w1 * c0 + m * c1 + m * n + 4 * n * k_eff)
-        kname = "upconv_s2d_kernel" if w1 >= 16 else "upconv_kernel"      # mirrors launch_up() in csrc/upconv_impl.h
+        kname = "upconv_halo_kernel" if w1 >= 16 else "upconv_kernel"     # mirrors launch_up() in csrc/upconv_impl.h
         name = igemm_tile(n).replace("igemm_f32_kernel<", "%s<%s," % (kname, "f32" if dt == torch.float32 else "bf16"))
         rec.end(name, "up3x3 M%d N%d Keff%d" % (m, n, k_eff), flops, nbytes, ev0)
     return dst

@@ -265,11 +265,9 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
         grads[conv + ".2.weight"] = dwb.permute(0, 3, 1, 2)
         grads[conv + ".2.bias"] = dbb
     else:
-        grads[conv + ".2.weight"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1)
-        grads[conv + ".2.bias"] = bw.bias_grad(dout)
+        grads[conv + ".2.weight"], grads[conv + ".2.bias"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1, want_bias=True)
         dy = bw.conv3x3_dgrad(dout, w_b, relu_out=y)                               # ReLU backward fused in the store
-    grads[conv + ".0.weight"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip)
-    grads[conv + ".0.bias"] = bw.bias_grad(dy)
+    grads[conv + ".0.weight"], grads[conv + ".0.bias"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip, want_bias=True)
     dcat2 = bw.conv3x3_dgrad(dy, _p(live, conv + ".0.weight"))                 # [B,2hw,2hw,c0+c1]
     if skip is not None:
         if skip_block in dfeats:
@@ -364,8 +362,8 @@ def backward_train(model, tape, gout, on_ready=None):
     w_lin = _p(live, "sat_feature_to_descriptors.1.weight")
     w4 = w_lin.view(w_lin.shape[0], 1280, 2, 2)
     svol = tape["svol"]
-    grads["sat_feature_to_descriptors.1.weight"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0).reshape(w_lin.shape)
-    grads["sat_feature_to_descriptors.1.bias"] = bw.bias_grad(dsdesc)
+    dw_lin, grads["sat_feature_to_descriptors.1.bias"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0, want_bias=True)
+    grads["sat_feature_to_descriptors.1.weight"] = dw_lin.reshape(w_lin.shape)
     dsvol = bw.conv2x2s2_dgrad(dsdesc, w4)
     if on_ready is not None:
         on_ready(grads)

@@ -287,6 +287,11 @@ int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, int kh, int k
 int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1, const float* dy,
                          int ldy, float* dw, float* scratch, int batch, int in_h, int in_w, int kh, int kw,
                          int stride, int pad, int n, void* stream);
+/* the same launch also returns the conv's BIAS gradient dbias[n] = sum_pixels dy[pixel][n]: the first column tile of every row
+ * tile adds up the dY pieces it stages anyway (one pass over dY instead of a ccvpe_colsum_f32 pass). */
+int ccvpe_conv_wgrad_bias_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1, const float* dy,
+                              int ldy, float* dw, float* dbias, float* scratch, int batch, int in_h, int in_w, int kh,
+                              int kw, int stride, int pad, int n, void* stream);
 int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------

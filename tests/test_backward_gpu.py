@@ -50,6 +50,9 @@ def test_conv_wgrad_and_dgrad_vs_autograd(bw, c0, c1, n, k, stride, pad, h, w):
         dyd = F.pad(dyd, (0, 4 - n % 4)).contiguous()
     close(bw.conv_wgrad(x0, dyd, n, k, k, stride, pad, x1), wt.grad, 2e-4, "wgrad")
     close(bw.bias_grad(dyd)[:n], bias.grad, 2e-4, "bias grad")
+    dw2, db2 = bw.conv_wgrad(x0, dyd, n, k, k, stride, pad, x1, want_bias=True)      # bias gradient from the same launch
+    close(dw2, wt.grad, 2e-4, "wgrad (+bias launch)")
+    close(db2, bias.grad, 2e-4, "bias grad fused into the weight-gradient launch")
     dyd = dyd[..., :n].contiguous() if n % 4 == 0 else None
     if dyd is None:
         return                                  # dgrad of the padded case is the plain 1x1 path tested above

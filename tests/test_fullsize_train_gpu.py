@@ -42,10 +42,13 @@ def test_conv_wgrad_at_benched_shapes(name, b, c0, c1, n, k, hw, tile, min_split
     xs = nhwc(x)
     x0 = xs[..., :c0].contiguous().cuda()
     x1 = xs[..., c0:].contiguous().cuda() if c1 else None
-    got = bw.conv_wgrad(x0, nhwc(dy).cuda(), n, k, k, 1, k // 2, x1).cpu().double()
+    got, gbias = bw.conv_wgrad(x0, nhwc(dy).cuda(), n, k, k, 1, k // 2, x1, want_bias=True)
+    got, gbias = got.cpu().double(), gbias.cpu().double()
     scale = want.abs().max().item()
     err = (got - want).abs().max().item()
     assert err <= 2e-4 * scale, "%s: max err %.3e vs scale %.3e" % (name, err, scale)
+    wb = dy.double().sum(dim=(0, 2, 3))
+    assert (gbias - wb).abs().max().item() <= 2e-4 * wb.abs().max().item(), "%s: fused bias gradient" % name
     again = bw.conv_wgrad(x0, nhwc(dy).cuda(), n, k, k, 1, k // 2, x1).cpu().double()
     assert torch.equal(got, again), "%s: two runs differ (a non-deterministic merge)" % name
 

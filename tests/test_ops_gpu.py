@@ -204,7 +204,7 @@ def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
     (64, 64, 32, 16, 32, 7, 6, False),        # ori branch: plain input
     (88, 81, 40, 16, 40, 6, 7, True),
     (648, 641, 320, 112, 320, 3, 4, True),
-    # w1 >= 16: the low-res-halo kernels (upconv_s2d_kernel; tiles + ragged borders in both directions, channel counts that
+    # w1 >= 16: the low-res-halo kernel (upconv_halo_kernel; tiles + ragged borders in both directions, channel counts that
     # do not fill the last 64-byte chunk of either source, 1- and 2-column tiles, every tile family of the decoder)
     (48, 41, 16, 0, 16, 17, 33, False),       # level 1 (no skip), <4,1,1>
     (88, 81, 40, 16, 40, 18, 16, False),      # level 2, <4,3,1>
