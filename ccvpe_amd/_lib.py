@@ -92,6 +92,9 @@ PROTOTYPES = {
     "ccvpe_colsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "ccvpe_bn_bwd_nblk": (c_int, [c_int]),
     "ccvpe_bn_act_bwd_f32": (c_int, [c_void_p] * 9 + [c_float, c_int] + [c_void_p] * 4 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_se_bn_bwd_reduce_f32": (c_int, [c_void_p] * 6 + [c_float, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "ccvpe_se_bn_bwd_apply_f32": (c_int, [c_void_p] * 8 + [c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                          c_void_p]),
     "ccvpe_se_dgate_f32": (c_int, [c_void_p] * 6 + [c_float, c_int, c_void_p] + [c_int] * 3 + [c_void_p]),
     "ccvpe_se_bwd_f32": (c_int, [c_void_p, c_int, c_float, c_void_p, c_int] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "ccvpe_dwconv_dgrad_f32": (c_int, [c_void_p] * 3 + [c_int] * 7 + [c_void_p]),

@@ -147,6 +147,35 @@ def se_dgate_partials(x, dv, mean, var, gamma, beta, eps, act):
     return part
 
 
+def se_bn_bwd_reduce(x, dv, mean, var, gamma, beta, eps, act):
+    """First pass of the BatchNorm + squeeze-excite backward: A [5, B, C] (ccvpe_se_bn_bwd_reduce_f32); A[0] is dgate."""
+    lib = _lib.load()
+    for t, nm in ((x, "x"), (dv, "dv"), (mean, "mean"), (var, "var"), (gamma, "gamma"), (beta, "beta")):
+        ops._chk(t, nm)
+    b, rps, c = _bc(x)
+    a = torch.empty((5, b, c), device=x.device, dtype=torch.float32)
+    scratch = torch.empty((b * lib.ccvpe_bn_bwd_nblk(rps) * 5 * c,), device=x.device, dtype=torch.float32)
+    check(lib.ccvpe_se_bn_bwd_reduce_f32(ops._ptr(x), ops._ptr(dv), ops._ptr(mean), ops._ptr(var), ops._ptr(gamma), ops._ptr(beta),
+                                         float(eps), act, ops._ptr(a), ops._ptr(scratch), b, rps, c, ops._stream()),
+          "ccvpe_se_bn_bwd_reduce_f32")
+    return a
+
+
+def se_bn_bwd_apply(x, dv, mean, var, gamma, beta, eps, act, gate, dmean, a):
+    """Second pass: dbeta / dgamma from A, gate and dmean, then dx.  Returns (dx, dgamma, dbeta)."""
+    lib = _lib.load()
+    for t, nm in ((gate, "gate"), (dmean, "dmean"), (a, "A")):
+        ops._chk(t, nm)
+    b, rps, c = _bc(x)
+    dx = torch.empty_like(x)
+    both = torch.empty((2, c), device=x.device, dtype=torch.float32)
+    dbeta, dgamma = both[0], both[1]
+    check(lib.ccvpe_se_bn_bwd_apply_f32(ops._ptr(x), ops._ptr(dv), ops._ptr(mean), ops._ptr(var), ops._ptr(gamma), ops._ptr(beta),
+                                        ops._ptr(gate), ops._ptr(dmean), float(eps), act, ops._ptr(a), ops._ptr(dx),
+                                        ops._ptr(dgamma), ops._ptr(dbeta), b, rps, c, ops._stream()), "ccvpe_se_bn_bwd_apply_f32")
+    return dx, dgamma, dbeta
+
+
 def se_bwd(se_partial, hw, dgate_partial, w1, b1, w2t, b2):
     """Returns (dmean [B,C] (already / HW), dw1 [Cs,C], db1, dw2 [C,Cs], db2)."""
     lib = _lib.load()

@@ -263,6 +263,138 @@ __global__ __launch_bounds__(256) void se_dgate_kernel(const BnBwdParams p, floa
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// BatchNorm-with-squeeze-excite backward in TWO passes over (x, dv) instead of three.
+// The SE gradient needs dgate[b,c] = sum_px dv*u BEFORE the BatchNorm reduction can run, because the reduction's g =
+// (dv*gate + dmean) * act'(z) contains dmean, which comes out of the SE backward.  But g is LINEAR in (gate, dmean), both
+// constant over the pixels of a (sample, channel):
+//     sum_px g        = gate * sum dv*a'      + dmean * sum a'
+//     sum_px g * xhat = gate * sum dv*a'*xhat + dmean * sum a'*xhat            (a' = act'(z))
+// so ONE pass accumulates the five per-(sample, channel) sums  A = (dv*u, dv*a', a', dv*a'*xhat, a'*xhat),  the SE backward
+// runs on A[0], and dbeta / dgamma are finished from A[1..4] with a [B,C]-sized kernel.  (se_dgate_kernel + bn_bwd_reduce
+// were two full passes over the depthwise-conv-sized tensors of all 32 MBConv blocks: 2.3 + 6.8 ms of the B = 64 step.)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_bn_bwd_reduce_kernel(const BnBwdParams p, float* __restrict__ part /*[B*nblk][5][C]*/) {
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [P][cgx][5] float4
+  const int b = blockIdx.y;
+  const int cg4 = p.C >> 2;
+  const int cgx = cg4 < 256 ? cg4 : 256;
+  const int P = 256 / cgx;
+  const int tid = threadIdx.x;
+  const int cgl = tid % cgx, pl = tid / cgx;
+  const int r0 = blockIdx.x * p.rows_per_block;
+  const int r1 = min(r0 + p.rows_per_block, p.rows_per_sample);
+  float* out = part + ((size_t)b * p.nblk + blockIdx.x) * 5 * p.C;
+  for (int cc = 0; cc < cg4; cc += cgx) {
+    const int cg = cc + cgl;
+    f32x4 s[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (pl < P && cg < cg4) {
+      const int c = cg * 4;
+      const f32x4 mu = *reinterpret_cast<const f32x4*>(p.mean + c);
+      const f32x4 vv = *reinterpret_cast<const f32x4*>(p.var + c);
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(p.gamma + c);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + c);
+      f32x4 istd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) istd[j] = 1.0f / sqrtf(vv[j] + p.eps);
+      const float* __restrict__ xb = p.x + ((size_t)b * p.rows_per_sample) * p.C + c;
+      const float* __restrict__ db_ = p.dv + ((size_t)b * p.rows_per_sample) * p.C + c;
+      auto one = [&](auto act_tag, f32x4 xv, f32x4 dv) {
+        constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float xh = (xv[j] - mu[j]) * istd[j];
+          const float z = xh * ga[j] + be[j];
+          float u, ap;
+          if (ACT == CCVPE_ACT_SWISH) {
+            const float sg = sigmoidf(z);
+            u = z * sg;
+            ap = sg * (1.0f + z * (1.0f - sg));
+          } else if (ACT == CCVPE_ACT_RELU) {
+            u = fmaxf(z, 0.f);
+            ap = z > 0.f ? 1.f : 0.f;
+          } else {
+            u = z;
+            ap = 1.f;
+          }
+          const float da = dv[j] * ap;
+          s[0][j] = fmaf(dv[j], u, s[0][j]);
+          s[1][j] += da;
+          s[2][j] += ap;
+          s[3][j] = fmaf(da, xh, s[3][j]);
+          s[4][j] = fmaf(ap, xh, s[4][j]);
+        }
+      };
+      auto rows = [&](auto act_tag) {
+        int r = r0 + pl;
+        for (; r + P < r1; r += 2 * P) {             // two rows per trip: four loads in flight
+          const f32x4 xa = *reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C);
+          const f32x4 da = *reinterpret_cast<const f32x4*>(db_ + (size_t)r * p.C);
+          const f32x4 xc = *reinterpret_cast<const f32x4*>(xb + (size_t)(r + P) * p.C);
+          const f32x4 dc = *reinterpret_cast<const f32x4*>(db_ + (size_t)(r + P) * p.C);
+          one(act_tag, xa, da);
+          one(act_tag, xc, dc);
+        }
+        if (r < r1) one(act_tag, *reinterpret_cast<const f32x4*>(xb + (size_t)r * p.C), *reinterpret_cast<const f32x4*>(db_ + (size_t)r * p.C));
+      };
+      CCVPE_BN_ACT_DISPATCH(p.act, rows);
+    }
+    f32x4* red4 = reinterpret_cast<f32x4*>(red);
+    if (pl < P) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) red4[(pl * cgx + cgl) * 5 + q] = s[q];
+    }
+    __syncthreads();
+    if (pl == 0 && cg < cg4) {
+#pragma unroll
+      for (int q = 0; q < 5; ++q) {
+        f32x4 t = red4[cgl * 5 + q];
+        for (int w = 1; w < P; ++w) t += red4[(w * cgx + cgl) * 5 + q];
+        *reinterpret_cast<f32x4*>(out + (size_t)q * p.C + cg * 4) = t;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// A[q][b][c] = sum over the sample's nblk partial rows (fixed order)
+__global__ __launch_bounds__(256) void se_bn_merge_kernel(const float* __restrict__ part, int nblk, int C, int B,
+                                                          float* __restrict__ A) {
+  const int e = blockIdx.x * 256 + threadIdx.x;      // q * C + c
+  const int b = blockIdx.y;
+  if (e >= 5 * C) return;
+  const float* src = part + (size_t)b * nblk * 5 * C + e;
+  float s0 = 0.f, s1 = 0.f;
+  int k = 0;
+  for (; k + 1 < nblk; k += 2) {
+    s0 += src[(size_t)k * 5 * C];
+    s1 += src[(size_t)(k + 1) * 5 * C];
+  }
+  if (k < nblk) s0 += src[(size_t)k * 5 * C];
+  const int q = e / C, c = e - q * C;
+  A[((size_t)q * B + b) * C + c] = s0 + s1;
+}
+
+// dbeta[c] = sum_b gate*A1 + dmean*A2 ; dgamma[c] = sum_b gate*A3 + dmean*A4   (batch order fixed)
+__global__ __launch_bounds__(256) void se_bn_finish_kernel(const float* __restrict__ A, const float* __restrict__ gate,
+                                                           const float* __restrict__ dmean, int B, int C,
+                                                           float* __restrict__ dbeta, float* __restrict__ dgamma) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const size_t plane = (size_t)B * C;
+  float sb = 0.f, sg = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const size_t i = (size_t)b * C + c;
+    const float g = gate[i], dm = dmean[i];
+    sb += g * A[plane + i] + dm * A[2 * plane + i];
+    sg += g * A[3 * plane + i] + dm * A[4 * plane + i];
+  }
+  dbeta[c] = sb;
+  dgamma[c] = sg;
+}
+
 // dx = dy where y > 0 else 0   (ReLU between the two convs of double_conv, models.py:45)
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ y, const float* __restrict__ dy,
                                                        float* __restrict__ dx, long n4) {
@@ -325,6 +457,39 @@ extern "C" int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float
   hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, st, p, dbeta, dgamma,
                      1.0f / ((float)batch * (float)rows_per_sample), dx);
   return check_launch("bn_act_bwd");
+}
+
+extern "C" int ccvpe_se_bn_bwd_reduce_f32(const float* x, const float* dv, const float* mean, const float* var,
+                                          const float* gamma, const float* beta, float eps, int act, float* A,
+                                          float* scratch, int batch, int rows_per_sample, int channels, void* stream) {
+  BnBwdParams p;
+  const int rc = fill_bn_params(p, x, dv, mean, var, gamma, beta, nullptr, nullptr, nullptr, eps, act, batch, rows_per_sample,
+                                channels);
+  if (rc) return rc;
+  if (!A || !scratch) return fail(CCVPE_EINVAL, "se_bn_bwd_reduce: null output");
+  const int cg4 = channels / 4, cgx = cg4 < 256 ? cg4 : 256, P = 256 / cgx;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_bn_bwd_reduce_kernel, dim3(p.nblk, batch), dim3(256), (size_t)P * cgx * 5 * 16, st, p, scratch);
+  hipLaunchKernelGGL(se_bn_merge_kernel, dim3((5 * channels + 255) / 256, batch), dim3(256), 0, st, scratch, p.nblk, channels,
+                     batch, A);
+  return check_launch("se_bn_bwd_reduce");
+}
+
+extern "C" int ccvpe_se_bn_bwd_apply_f32(const float* x, const float* dv, const float* mean, const float* var,
+                                         const float* gamma, const float* beta, const float* gate, const float* dmean,
+                                         float eps, int act, const float* A, float* dx, float* dgamma, float* dbeta,
+                                         int batch, int rows_per_sample, int channels, void* stream) {
+  BnBwdParams p;
+  const int rc = fill_bn_params(p, x, dv, mean, var, gamma, beta, gate, dmean, nullptr, eps, act, batch, rows_per_sample,
+                                channels);
+  if (rc) return rc;
+  if (!gate || !dmean || !A) return fail(CCVPE_EINVAL, "se_bn_bwd_apply: gate, dmean and A are required");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(se_bn_finish_kernel, dim3((channels + 255) / 256), dim3(256), 0, st, A, gate, dmean, batch, channels, dbeta,
+                     dgamma);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(p.nblk, batch), dim3(256), 0, st, p, dbeta, dgamma,
+                     1.0f / ((float)batch * (float)rows_per_sample), dx);
+  return check_launch("se_bn_bwd_apply");
 }
 
 extern "C" int ccvpe_se_dgate_f32(const float* x, const float* dv, const float* mean, const float* var,

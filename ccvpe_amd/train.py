@@ -23,6 +23,8 @@ from .synth import MODEL_SPECS
 
 BN_EPS = 1e-3
 SKIP_BLOCKS = (15, 10, 4, 2, 0)
+# train mode: ground and aerial encoder (forward AND backward) on two HIP streams; CCVPE_TRAIN_TWO_STREAMS=0 for A/B runs
+TWO_STREAMS = __import__("os").environ.get("CCVPE_TRAIN_TWO_STREAMS", "1") != "0"
 
 
 def _round_up(v, m):
@@ -124,14 +126,24 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     model._nbt_pending = []
     model._last_drop_masks = {}
 
-    gfeat, _, gt = encoder_forward(model, pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks, rec)
-    _, gh, gw, _ = gfeat.shape
-    if gh != spec["grd_h"]:
-        raise ValueError("ground feature height %d != %d expected by the descriptor heads" % (gh, spec["grd_h"]))
-    y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw, shift=pk.gd_bias,
-                        ldd=_round_up(pk.gd_n, 4))
-    gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
+    # The two encoders are independent until the first matching block, and in train mode they are long chains of small
+    # HBM- / latency-bound launches (BatchNorm statistics and apply passes, depthwise convs, SE): the ground encoder + descriptor
+    # heads run on the model's side stream next to the aerial encoder, as in the eval forward (fork / join by events).
+    main = torch.cuda.current_stream()
+    side = model._side_stream() if TWO_STREAMS else main
+    side.wait_stream(main)
+    with torch.cuda.stream(side):
+        gfeat, _, gt = encoder_forward(model, pk.grd, live, "grd_efficientnet", grd, circular, False, drop_masks, rec)
+        _, gh, gw, _ = gfeat.shape
+        if gh != spec["grd_h"]:
+            raise ValueError("ground feature height %d != %d expected by the descriptor heads" % (gh, spec["grd_h"]))
+        y1 = ops.conv_igemm(gfeat, 1280, pk.gd_w, pk.gd_n, batch=batch, in_h=gh, in_w=gw, shift=pk.gd_bias,
+                            ldd=_round_up(pk.gd_n, 4))
+        gdesc = ops.ground_descriptor(y1, pk.gd_wh, pk.gd_bh, spec["cd"])
     svol, sfeats, st = encoder_forward(model, pk.sat, live, "sat_efficientnet", sat, False, True, drop_masks, rec)
+    main.wait_stream(side)
+    if side is not main:
+        gdesc.record_stream(main)                 # (read by the matching kernels on the main stream)
     model._stats_epoch = getattr(model, "_stats_epoch", 0) + 1      # the folded (eval) pack is stale now
     torch._foreach_add_(model._nbt_pending, 1)                      # num_batches_tracked += 1 for all 98 BatchNorms
     model._nbt_pending = []
@@ -223,13 +235,16 @@ def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
         dv = bw.conv1x1_dgrad(dp, _p(live, bp + "._project_conv.weight"))
         # squeeze-excite
         g1, b1 = _p(live, bp + "._bn1.weight"), _p(live, bp + "._bn1.bias")
-        dgp = bw.se_dgate_partials(s["u_raw"], dv, s["m1"], s["v1"], g1, b1, BN_EPS, ops.ACT_SWISH)
+        # BN1 + SE backward in two passes over (u_raw, dv): five per-(sample, channel) sums first (A[0] = the gate gradient),
+        # the small SE backward on them, then dbeta / dgamma finished from the sums and dx written (csrc/train_bwd.hip)
+        sums = bw.se_bn_bwd_reduce(s["u_raw"], dv, s["m1"], s["v1"], g1, b1, BN_EPS, ops.ACT_SWISH)
         ho, wo = s["u_raw"].shape[1], s["u_raw"].shape[2]
-        dmean, dw1, db1, dw2, db2 = bw.se_bwd(s["part"], ho * wo, dgp, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
+        dmean, dw1, db1, dw2, db2 = bw.se_bwd(s["part"], ho * wo, sums[0].unsqueeze(1), blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
         grads[bp + "._se_reduce.weight"], grads[bp + "._se_reduce.bias"] = dw1, db1
         grads[bp + "._se_expand.weight"], grads[bp + "._se_expand.bias"] = dw2, db2
         # depthwise conv + bn1
-        du = _bn_bwd(live, bp + "._bn1", grads, s["u_raw"], dv, s["m1"], s["v1"], ops.ACT_SWISH, gate=s["gate"], dmean=dmean)
+        du, dg1, db1n = bw.se_bn_bwd_apply(s["u_raw"], dv, s["m1"], s["v1"], g1, b1, BN_EPS, ops.ACT_SWISH, s["gate"], dmean, sums)
+        grads[bp + "._bn1.weight"], grads[bp + "._bn1.bias"] = dg1, db1n
         grads[bp + "._depthwise_conv.weight"] = bw.dwconv_wgrad(s["t"], du, blk.k, blk.s, circular).t()
         dt = bw.dwconv_dgrad(du, blk.w_dw, h, w, blk.k, blk.s, circular)
         # expand conv + bn0
@@ -367,32 +382,43 @@ def backward_train(model, tape, gout, on_ready=None):
     dsvol = bw.conv2x2s2_dgrad(dsdesc, w4)
     if on_ready is not None:
         on_ready(grads)
+
+    # ---- the two encoders' backward passes are independent: ground descriptors + ground encoder on the side stream, aerial
+    # encoder on the main stream (both are chains of small HBM- / latency-bound launches).  Their gradients are collected in
+    # separate dicts so that on_ready never sees a gradient whose kernels are still queued on the other stream.
+    main = torch.cuda.current_stream()
+    side = model._side_stream() if TWO_STREAMS else main
+    side.wait_stream(main)
+    g_grd = {}
+    with torch.cuda.stream(side):
+        # ---- ground descriptors (models.py:57-97,153-165) ---------------------------------------------------------
+        y1, gfeat = tape["y1"], tape["gfeat"]
+        dy1, dwh, dbh = bw.ground_descriptor_bwd(y1, pk.gd_wh, spec["cd"], dgdesc)
+        n = pk.gd_n
+        dwg = bw.conv_wgrad(gfeat, dy1, n, 1, 1, 1, 0).reshape(n, 1280)
+        dbg = bw.bias_grad(dy1)
+        off = 0
+        for l in range(1, 7):
+            p = "grd_feature_to_descriptor%d" % l
+            cd = spec["cd"][l - 1]
+            g_grd[p + ".0.weight"] = dwg[off:off + cd].reshape(live[p + ".0.weight"].shape)
+            g_grd[p + ".0.bias"] = dbg[off:off + cd]
+            g_grd[p + ".2.weight"] = dwh[l - 1].reshape(live[p + ".2.weight"].shape)
+            g_grd[p + ".2.bias"] = dbh[l - 1:l].reshape(live[p + ".2.bias"].shape)
+            off += cd
+        b, gh, gw, ld = dy1.shape
+        # dy1's pad columns (n..ld) are zero; the K dimension of the dgrad GEMM is padded to ld with zero weights
+        wcat = torch.cat([_p(live, "grd_feature_to_descriptor%d.0.weight" % l) for l in range(1, 7)], 0)
+        wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
+        wpad[:n] = wcat
+        dgfeat = ops.conv_igemm(dy1, ld, bw._pack_conv(wpad.permute(1, 0, 2, 3)), 1280, batch=b, in_h=gh, in_w=gw)
+        encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], g_grd)
     encoder_backward(pk.sat, live, "sat_efficientnet", tape["sat"], dsvol, dfeats, False, grads)
     if on_ready is not None:
         on_ready(grads)
-
-    # ---- ground descriptors (models.py:57-97,153-165) ---------------------------------------------------------
-    y1, gfeat = tape["y1"], tape["gfeat"]
-    dy1, dwh, dbh = bw.ground_descriptor_bwd(y1, pk.gd_wh, spec["cd"], dgdesc)
-    n = pk.gd_n
-    dwg = bw.conv_wgrad(gfeat, dy1, n, 1, 1, 1, 0).reshape(n, 1280)
-    dbg = bw.bias_grad(dy1)
-    off = 0
-    for l in range(1, 7):
-        p = "grd_feature_to_descriptor%d" % l
-        cd = spec["cd"][l - 1]
-        grads[p + ".0.weight"] = dwg[off:off + cd].reshape(live[p + ".0.weight"].shape)
-        grads[p + ".0.bias"] = dbg[off:off + cd]
-        grads[p + ".2.weight"] = dwh[l - 1].reshape(live[p + ".2.weight"].shape)
-        grads[p + ".2.bias"] = dbh[l - 1:l].reshape(live[p + ".2.bias"].shape)
-        off += cd
-    b, gh, gw, ld = dy1.shape
-    # dy1's pad columns (n..ld) are zero; the K dimension of the dgrad GEMM is padded to ld with zero weights
-    wcat = torch.cat([_p(live, "grd_feature_to_descriptor%d.0.weight" % l) for l in range(1, 7)], 0)
-    wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
-    wpad[:n] = wcat
-    dgfeat = ops.conv_igemm(dy1, ld, bw._pack_conv(wpad.permute(1, 0, 2, 3)), 1280, batch=b, in_h=gh, in_w=gw)
-    encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], grads)
+    main.wait_stream(side)                 # join: the ground gradients are complete on the main stream's timeline from here
+    side.wait_stream(main)                 # ... and later side-stream work cannot overtake the main stream's readers
+    grads.update(g_grd)
     if on_ready is not None:
         on_ready(grads)
     return grads

@@ -314,6 +314,17 @@ int ccvpe_bn_act_bwd_f32(const float* x, const float* dv, const float* mean, con
                          const float* beta, const float* gate, const float* dmean, const float* dc_scale, float eps,
                          int act, float* dx, float* dgamma, float* dbeta, float* scratch, int batch,
                          int rows_per_sample, int channels, void* stream);
+/* BatchNorm + squeeze-excite backward in two passes over (x, dv) instead of three (csrc/train_bwd.hip): the reduce pass
+ * returns A [5][batch][channels] = per-(sample, channel) sums of (dv*u, dv*a', a', dv*a'*xhat, a'*xhat); A[0] is the SE gate
+ * gradient (feed it to ccvpe_se_bwd_f32 as a one-row partial), and the apply call finishes dbeta / dgamma from A, gate and
+ * dmean before writing dx.  scratch: batch * ccvpe_bn_bwd_nblk(rows_per_sample) * 5 * channels floats. */
+int ccvpe_se_bn_bwd_reduce_f32(const float* x, const float* dv, const float* mean, const float* var, const float* gamma,
+                               const float* beta, float eps, int act, float* A, float* scratch, int batch,
+                               int rows_per_sample, int channels, void* stream);
+int ccvpe_se_bn_bwd_apply_f32(const float* x, const float* dv, const float* mean, const float* var, const float* gamma,
+                              const float* beta, const float* gate, const float* dmean, float eps, int act, const float* A,
+                              float* dx, float* dgamma, float* dbeta, int batch, int rows_per_sample, int channels,
+                              void* stream);
 int ccvpe_se_dgate_f32(const float* x, const float* dv, const float* mean, const float* var, const float* gamma,
                        const float* beta, float eps, int act, float* part, int batch, int rows_per_sample,
                        int channels, void* stream);

@@ -21,7 +21,7 @@ def nhwc(t):
 
 
 def close(got, want, tol, what):
-    got, want = got.detach().cpu().double(), want.detach().double()
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
     assert got.shape == want.shape, (what, got.shape, want.shape)
     scale = want.abs().max().item() + 1e-30
     err = (got - want).abs().max().item()
@@ -173,6 +173,26 @@ def test_se_bwd_vs_autograd(bw, c, cs, hw):
     close(db1, b1.grad, 2e-4, "db1")
     close(dw2, w2.grad, 2e-4, "dw2")
     close(db2, b2.grad, 2e-4, "db2")
+
+
+@pytest.mark.parametrize("b,rows,c", [(3, 20 * 24, 96), (2, 33 * 17, 240), (5, 7 * 9, 1152)])
+def test_se_bn_bwd_two_pass_equals_three_pass(bw, b, rows, c):
+    """BatchNorm + squeeze-excite backward: the two-pass form (five per-(sample, channel) sums, then apply: what the training
+    step runs) against the three-pass form (se_dgate partials + bn_act_bwd) it replaces — same dgate, dx, dgamma, dbeta."""
+    from ccvpe_amd import ops
+    x = (synth.normal((b, rows, c), 950 + c) * 1.3 + 0.2).cuda()
+    dv = synth.normal((b, rows, c), 951).cuda()
+    mean, var = x.mean(dim=(0, 1)).contiguous(), x.var(dim=(0, 1), unbiased=False).contiguous()
+    gamma, beta = synth.uniform((c,), 952, 0.5, 1.5).cuda(), synth.normal((c,), 953, 0.3).cuda()
+    gate, dmean = synth.uniform((b, c), 954, 0.1, 0.9).cuda(), (synth.normal((b, c), 955) / rows).cuda()
+    dgp = bw.se_dgate_partials(x, dv, mean, var, gamma, beta, 1e-3, ops.ACT_SWISH)
+    dx0, dg0, db0 = bw.bn_act_bwd(x, dv, mean, var, gamma, beta, 1e-3, ops.ACT_SWISH, gate=gate, dmean=dmean)
+    sums = bw.se_bn_bwd_reduce(x, dv, mean, var, gamma, beta, 1e-3, ops.ACT_SWISH)
+    dx1, dg1, db1 = bw.se_bn_bwd_apply(x, dv, mean, var, gamma, beta, 1e-3, ops.ACT_SWISH, gate, dmean, sums)
+    close(sums[0], dgp.sum(1), 2e-5, "dgate")
+    close(dg1, dg0, 5e-5, "dgamma")
+    close(db1, db0, 5e-5, "dbeta")
+    close(dx1, dx0, 5e-5, "dx")
 
 
 def test_relu_bwd(bw):
