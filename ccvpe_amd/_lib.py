@@ -87,6 +87,8 @@ PROTOTYPES = {
     "ccvpe_conv_wgrad_scratch_floats": (c_int, [c_int] * 9),
     "ccvpe_conv_wgrad_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                      c_void_p] + [c_int] * 8 + [c_void_p]),
+    "ccvpe_conv_wgrad_gated_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int,
+                                           c_int, c_void_p]),
     "ccvpe_conv_wgrad_bias_f32": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p,
                                           c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
     "ccvpe_colsum_f32": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -56,6 +56,30 @@ def conv_wgrad(x0, dy, n, kh, kw, stride, pad, x1=None, c0=None, c1=None, want_b
     return (dw, dbias) if want_bias else dw
 
 
+def conv1x1_wgrad_gated(u, gate, dy, n):
+    """Weight gradient [n, C, 1, 1] of a 1x1 conv whose input is u[b, px, c] * gate[b, c] (the SE product in front of the MBConv
+    projection) without materialising that product (ccvpe_conv_wgrad_gated_f32)."""
+    lib = _lib.load()
+    for t, nm in ((u, "u"), (gate, "gate"), (dy, "dy")):
+        ops._chk(t, nm)
+    b, h, w, c = u.shape
+    nfl = lib.ccvpe_conv_wgrad_scratch_floats(b, h, w, 1, 1, 1, 0, c, n)
+    if nfl <= 0:
+        raise _lib.CcvpeError("ccvpe_conv_wgrad_scratch_floats rejected the shape")
+    scratch = torch.empty((nfl,), device=u.device, dtype=torch.float32)
+    dw = torch.empty((n, 1, c), device=u.device, dtype=torch.float32)
+    rec = ops._recorder
+    ev0 = rec.begin() if rec is not None else None
+    check(lib.ccvpe_conv_wgrad_gated_f32(ops._ptr(u), c, c, ops._ptr(gate), ops._ptr(dy), dy.shape[-1], ops._ptr(dw),
+                                         ops._ptr(scratch), b, h, w, n, ops._stream()), "ccvpe_conv_wgrad_gated_f32")
+    if rec is not None:
+        m = b * h * w
+        tile = lib.ccvpe_conv_wgrad_tile(n, c)
+        rec.end("conv_wgrad_kernel<%d,%d>" % (tile >> 16, tile & 0xffff), "1x1 gated M%d N%d C%d" % (m, n, c),
+                2.0 * m * n * c, 4.0 * (m * c + m * n + n * c), ev0)
+    return dw.reshape(n, 1, 1, c).permute(0, 3, 1, 2)
+
+
 def deconv_wgrad(x, dy_hi):
     """d(ConvTranspose2d k2 s2)/d(weight) [Cin,Cout,2,2]: x [B,H,W,Cin] forward input, dy_hi [B,2H,2W,Cout]."""
     cin = x.shape[-1]

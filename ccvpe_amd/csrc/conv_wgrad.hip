@@ -29,6 +29,7 @@ struct WgradParams {
   int S, pix_per_split;
   int tiles_n, tiles_c;
   float* bias_part;     // optional [S][N]: column sums of dY (the conv's bias gradient) from the tiles with tc == 0, else nullptr
+  const float* gate;    // GATED kernels (1x1 convs only): x is multiplied by gate[sample][channel] while it is staged
   int ablate;           // diagnostics build only (-DCCVPE_ABLATE): 1 = no global loads, 2 = no LDS stores, 4 = no fragment reads
 };
 
@@ -40,7 +41,10 @@ constexpr int WG_BP = 32;   // pixels per stage
 // (16 FLOP per byte staged) is bound by L2 -> LDS bandwidth: every dY panel is re-read by each column tile and vice versa.
 // The tile columns index (tap, input channel) jointly: col = tap*Ctot + c, so narrow layers (Ctot = 16..48) fill the
 // tile with several taps instead of zero columns.
-template <int TN, int TC>
+// GATED: the conv's input is u * gate[b, c] (the squeeze-excite product in front of the MBConv projection,
+// efficientnet_pytorch/model.py:118-121): the gate is applied to the X pieces as they are written to LDS, so the training
+// step no longer materialises the gated tensor (gate_mul_kernel: one read + one write of every depthwise-conv output).
+template <int TN, int TC, bool GATED = false>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr bool SQ = TN == 64 || TN == 128;          // 2 x 2 waves of (TN/2) x (TC/2); else 4 waves of TN x (TC/4)
   constexpr int NI = (SQ ? TN / 2 : TN) / 16;         // 16-row MFMA tiles per wave along n
@@ -77,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   // staging: thread -> pixel row tid >> 3 (0..31), float4 pieces at tile column (tid & 7) * 4 + 32 * q
   const int prow = tid >> 3;
   const int pc = (tid & 7) * 4;
+  int pch[XP];                                       // (GATED) channel of each X piece
   int pky[XP], pkx[XP], pld[XP];                     // per X piece: tap offsets, pixel stride of its source (stage-invariant)
   const float* pbase[XP];                            // ... and the source row base at its input channel (src0 or src1)
   bool pok[XP];
@@ -91,12 +96,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     const bool first = c < p.c0;
     pbase[q] = first ? p.src0 + c : p.src1 + (c - p.c0);
     pld[q] = first ? p.ld0 : p.ld1;
+    pch[q] = c;
   }
   // Staged pieces are kept RAW in registers across the stage's matrix work, with their validity as lane masks; the masks
   // are applied when the pieces go to LDS (store_stage).  Applying them at the load (`x = in ? t : 0`) made every stage
   // wait for its own prefetch before the first MFMA: vmcnt(3..0) right after the loads.
   typedef int i32x4 __attribute__((ext_vector_type(4)));
   f32x4 yr[YP], xr[XP];
+  f32x4 gr[GATED ? XP : 1];                          // gate values of the staged X pieces
   int ykeep = 0, xkeep[XP];
   // bias gradient = column sums of dY: the first column tile of every row tile adds up the dY pieces it stages anyway
   // (one pass over dY instead of a second kernel reading it again: ccvpe_colsum_f32 was 3.3 ms of the B = 64 training step)
@@ -147,6 +154,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       const bool in = ok && pok[q] && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
       const int pix = in ? (cb * p.H + iy) * p.W + ix : 0;        // 32-bit: the launcher checks pixels * pitch < 2^31 floats
       xr[q] = *reinterpret_cast<const f32x4*>(pbase[q] + (size_t)(unsigned)(pix * pld[q]));
+      if constexpr (GATED) gr[q] = *reinterpret_cast<const f32x4*>(p.gate + (size_t)(in ? cb : 0) * ctot + pch[q]);
       xkeep[q] = in ? -1 : 0;
     }
   };
@@ -168,7 +176,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
       }
     } else {
       const int q = k - YP;
-      *reinterpret_cast<i32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, xr[q]) & xkeep[q];
+      f32x4 xv = xr[q];
+      if constexpr (GATED) xv *= gr[q];
+      *reinterpret_cast<i32x4*>(&Xs[(buf * WG_BP + prow) * XLD + pc + 32 * q]) = __builtin_bit_cast(i32x4, xv) & xkeep[q];
     }
   };
   auto load_stage = [&](int /*m0*/) {
@@ -440,7 +450,7 @@ extern "C" int ccvpe_conv_wgrad_scratch_floats(int batch, int in_h, int in_w, in
 
 static int conv_wgrad_impl(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
                            const float* dy, int ldy, float* dw, float* dbias, float* scratch, int batch, int in_h,
-                           int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
+                           int in_w, int kh, int kw, int stride, int pad, int n, void* stream, const float* gate = nullptr) {
   if (c0 <= 0 || c0 % 4 || c1 < 0 || c1 % 4 || ld0 % 4 || (c1 && ld1 % 4)) return fail(CCVPE_EINVAL, "conv_wgrad: channels/ld %% 4");
   if (c1 > 0 && !src1) return fail(CCVPE_EINVAL, "conv_wgrad: c1>0 but src1 null");
   if (!aligned16(src0) || (src1 && !aligned16(src1)) || !aligned16(dy) || ldy % 4) return fail(CCVPE_EINVAL, "conv_wgrad: alignment");
@@ -470,6 +480,9 @@ static int conv_wgrad_impl(const float* src0, int c0, int ld0, const float* src1
   p.S = wgrad_splits(p.M, p.tiles_n * p.tiles_c, p.taps, big);
   p.pix_per_split = ((p.M + p.S - 1) / p.S + WG_BP - 1) / WG_BP * WG_BP;
   p.bias_part = dbias ? scratch + (size_t)p.S * n * p.taps * ctot : nullptr;
+  p.gate = gate;
+  if (gate && (kh != 1 || kw != 1 || stride != 1 || pad != 0 || c1 != 0 || big || !aligned16(gate)))
+    return fail(CCVPE_EINVAL, "conv_wgrad: the gated form is for 1x1 single-source convs with fewer than 128 output channels");
   hipStream_t st = (hipStream_t)stream;
   const long blocks = (long)p.tiles_n * p.tiles_c * p.S;
   const size_t lds = sizeof(float) * 2 * WG_BP * ((size_t)(tn + 4) + (tcw + 4));
@@ -481,6 +494,12 @@ static int conv_wgrad_impl(const float* src0, int c0, int ld0, const float* src1
       attr_set = true;
     }
     hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+  } else if (gate) {
+    if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, 64, true>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, true>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else if (tn == 48) hipLaunchKernelGGL((conv_wgrad_kernel<48, 64, true>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else if (tn == 80) hipLaunchKernelGGL((conv_wgrad_kernel<80, 64, true>), dim3((unsigned)blocks), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, true>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   } else if (tn == 16) hipLaunchKernelGGL((conv_wgrad_kernel<16, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   else if (tn == 32) hipLaunchKernelGGL((conv_wgrad_kernel<32, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
   else if (tn == 48) hipLaunchKernelGGL((conv_wgrad_kernel<48, 64>), dim3((unsigned)blocks), dim3(256), lds, st, p);
@@ -497,6 +516,11 @@ extern "C" int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const fl
                                     int in_w, int kh, int kw, int stride, int pad, int n, void* stream) {
   return conv_wgrad_impl(src0, c0, ld0, src1, c1, ld1, dy, ldy, dw, nullptr, scratch, batch, in_h, in_w, kh, kw, stride, pad, n,
                          stream);
+}
+extern "C" int ccvpe_conv_wgrad_gated_f32(const float* x, int c, int ld, const float* gate, const float* dy, int ldy, float* dw,
+                                          float* scratch, int batch, int in_h, int in_w, int n, void* stream) {
+  if (!gate) return fail(CCVPE_EINVAL, "conv_wgrad_gated: gate is NULL");
+  return conv_wgrad_impl(x, c, ld, nullptr, 0, 0, dy, ldy, dw, nullptr, scratch, batch, in_h, in_w, 1, 1, 1, 0, n, stream, gate);
 }
 extern "C" int ccvpe_conv_wgrad_bias_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1,
                                          const float* dy, int ldy, float* dw, float* dbias, float* scratch, int batch,

@@ -375,14 +375,20 @@ class _CVMBase(nn.Module):
         parameter itself and ccvpe_amd.optim.Adam are detected automatically (_weights_key)."""
         self._pack_cache = None
         self._pack_key = None
+        object.__setattr__(self, "_flat_tensors", None)
         return self
 
     def _weights_key(self):
+        """(storage, version) of every parameter / buffer: what the packed weights were derived from.  The module tree is
+        walked ONCE (0.86 ms per forward otherwise: 7 % of a B = 8 forward); `to()` / `load_state_dict` swap or rewrite the
+        tensors, which the per-tensor (data_ptr, _version) pairs of the cached list catch — a parameter OBJECT that is replaced
+        (`module.weight = nn.Parameter(...)`) needs invalidate()."""
         from . import _lib
-        key = [_lib.weights_epoch]
-        for t in list(self.parameters()) + list(self.buffers()):
-            key.append((t.data_ptr(), t._version))
-        return tuple(key)
+        flat = getattr(self, "_flat_tensors", None)
+        if flat is None:
+            flat = list(self.parameters()) + list(self.buffers())
+            object.__setattr__(self, "_flat_tensors", flat)
+        return (_lib.weights_epoch,) + tuple((t.data_ptr(), t._version) for t in flat)
 
     def _packed(self):
         # running statistics are updated in place by the HIP kernels (no torch version bump): the eval pack (BN folded

@@ -64,12 +64,11 @@ def encoder_forward(model, e, live, prefix, img, circular, multiscale, drop_mask
         (u, part), m1, v1 = _bn(model, live, bp + "._bn1", u_raw, ops.ACT_SWISH, want_se=True)
         ho, wo = u.shape[1], u.shape[2]
         gate = ops.se_gate(part, ho * wo, blk.se_w1, blk.se_b1, blk.se_w2, blk.se_b2)
-        if rec:      # the projection's weight gradient needs the gated tensor itself
-            vg = bw.gate_mul(u, gate)
-            p_raw = ops.conv_igemm(vg, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo)
-            s.update(t=t, u_raw=u_raw, m1=m1, v1=v1, part=part, gate=gate, vg=vg)
-        else:
-            p_raw = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate)
+        # the SE gate is applied inside the projection GEMM's operand load (as in eval) and, in the backward, inside the weight
+        # gradient's staging (bw.conv1x1_wgrad_gated): the gated tensor u * gate is never materialised
+        p_raw = ops.conv_igemm(u, blk.mid, blk.w_proj, blk.cout, batch=b, in_h=ho, in_w=wo, gate=gate)
+        if rec:
+            s.update(t=t, u_raw=u_raw, m1=m1, v1=v1, part=part, gate=gate, u=u)
         dc = None
         rate = model.drop_connect_rate * float(i) / len(e.blocks)               # model.py:293-295
         if blk.skip and rate:
@@ -231,7 +230,7 @@ def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
         h, w = s["hw"]
         # project conv + bn2 (+ residual, drop_connect)
         dp = _bn_bwd(live, bp + "._bn2", grads, s["p_raw"], dx, s["m2"], s["v2"], ops.ACT_NONE, dc_scale=s["dc"])
-        grads[bp + "._project_conv.weight"] = bw.conv_wgrad(s["vg"], dp, blk.cout, 1, 1, 1, 0)
+        grads[bp + "._project_conv.weight"] = bw.conv1x1_wgrad_gated(s["u"], s["gate"], dp, blk.cout)
         dv = bw.conv1x1_dgrad(dp, _p(live, bp + "._project_conv.weight"))
         # squeeze-excite
         g1, b1 = _p(live, bp + "._bn1.weight"), _p(live, bp + "._bn1.bias")

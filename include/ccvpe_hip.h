@@ -292,6 +292,10 @@ int ccvpe_conv_wgrad_f32(const float* src0, int c0, int ld0, const float* src1, 
 int ccvpe_conv_wgrad_bias_f32(const float* src0, int c0, int ld0, const float* src1, int c1, int ld1, const float* dy,
                               int ldy, float* dw, float* dbias, float* scratch, int batch, int in_h, int in_w, int kh,
                               int kw, int stride, int pad, int n, void* stream);
+/* 1x1 conv whose input is the squeeze-excite product x[b, px, c] * gate[b, c] (MBConv projection, model.py:118-121;
+ * fewer than 128 output channels): the gate is applied while x is staged, the gated tensor is never materialised. */
+int ccvpe_conv_wgrad_gated_f32(const float* x, int c, int ld, const float* gate, const float* dy, int ldy, float* dw,
+                               float* scratch, int batch, int in_h, int in_w, int n, void* stream);
 int ccvpe_colsum_f32(const float* x, int rows, int channels, int ld, float* out, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------

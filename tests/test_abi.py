@@ -147,7 +147,9 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.ccvpe_softmax_rows_f32(256, 256, 0, 8, None) == EINVAL
     assert lib.ccvpe_mbconv_front_nblk(8, 8, 16, 96, 4, 1) == EINVAL
     assert lib.ccvpe_mbconv_front_nblk(16, 16, 192, 1152, 3, 1) == 0        # valid but unfused shape
-    assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 1) == 4          # 64 output rows / 16 per band
+    assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 1) == 32         # squeeze-partial rows = 8 x 16 output tiles: 8 x 4
+    assert lib.ccvpe_mbconv_front_nblk(256, 256, 16, 96, 3, 2) == 128       # block 1: 128 x 128 outputs in 8 x 16 tiles
+    assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 2) == 0          # k5 s2 with Cin > 32: not instantiated -> unfused
 
 
 def test_planning_entry_points_without_a_gpu():

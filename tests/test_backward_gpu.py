@@ -195,6 +195,22 @@ def test_se_bn_bwd_two_pass_equals_three_pass(bw, b, rows, c):
     close(dx1, dx0, 5e-5, "dx")
 
 
+@pytest.mark.parametrize("c,n,h,w", [(96, 16, 19, 23), (144, 24, 12, 30), (240, 40, 9, 11), (480, 80, 8, 8), (672, 112, 6, 7),
+                                     (1152, 192, 5, 4), (1152, 320, 4, 4)])
+def test_gated_1x1_wgrad_equals_wgrad_of_the_materialised_product(bw, c, n, h, w):
+    """MBConv projection: weight gradient with the SE gate applied while x is staged == weight gradient of u * gate (every
+    row-tile family the projection layers use)."""
+    b = 3
+    u = synth.normal((b, h, w, c), 960 + c).cuda()
+    gate = synth.uniform((b, c), 961, 0.05, 0.95).cuda()
+    dy = synth.normal((b, h, w, n), 962).cuda()
+    want = bw.conv_wgrad(bw.gate_mul(u, gate), dy, n, 1, 1, 1, 0)
+    got = bw.conv1x1_wgrad_gated(u, gate, dy, n)
+    close(got, want, 1e-5, "gated 1x1 wgrad")
+    ref = torch.einsum("bhwn,bhwc->nc", dy.double().cpu(), (u * gate.view(b, 1, 1, c)).double().cpu())
+    close(got.reshape(n, c), ref, 2e-4, "gated 1x1 wgrad vs float64")
+
+
 def test_relu_bwd(bw):
     y = torch.relu(synth.normal((2, 5, 6, 16), 930))
     dy = synth.normal((2, 5, 6, 16), 931)
