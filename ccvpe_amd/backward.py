@@ -100,23 +100,26 @@ def bias_grad(dy, channels=None):
     return out
 
 
-def conv1x1_dgrad(dy, w):
-    """w [N,C,1,1] -> dx [B,H,W,C]."""
+def conv1x1_dgrad(dy, w, wp=None):
+    """w [N,C,1,1] -> dx [B,H,W,C].  wp: the weight already in the backward layout (models._pack_backward)."""
     b, h, wd, n = dy.shape
     c = w.shape[1]
-    return ops.conv_igemm(dy, n, _pack_conv(w.permute(1, 0, 2, 3)), c, batch=b, in_h=h, in_w=wd)
+    if wp is None:
+        wp = _pack_conv(w.permute(1, 0, 2, 3))
+    return ops.conv_igemm(dy, n, wp, c, batch=b, in_h=h, in_w=wd)
 
 
-def conv3x3_dgrad(dy, w, relu_out=None):
+def conv3x3_dgrad(dy, w, relu_out=None, wp=None):
     """w [N,C,3,3] (stride 1, pad 1) -> dx [B,H,W,C] (split it along C for a two-source forward).
     relu_out [B,H,W,C]: the convolution's input was this ReLU output; return the gradient in FRONT of the ReLU
     (dx where relu_out > 0, else 0) from the same launch instead of a relu_bwd pass over dx."""
     b, h, wd, n = dy.shape
     c = w.shape[1]
-    wt = w.flip(2, 3).permute(1, 0, 2, 3).contiguous()
+    if wp is None:
+        wp = _pack_conv(w.flip(2, 3).permute(1, 0, 2, 3).contiguous())
     if relu_out is None:
-        return ops.conv_igemm(dy, n, _pack_conv(wt), c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1)
-    return ops.conv_igemm(dy, n, _pack_conv(wt), c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1, residual=relu_out,
+        return ops.conv_igemm(dy, n, wp, c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1)
+    return ops.conv_igemm(dy, n, wp, c, batch=b, in_h=h, in_w=wd, kh=3, kw=3, pad=1, residual=relu_out,
                           act=ops.ACT_RELU_MASK)
 
 
@@ -127,11 +130,12 @@ def deconv_dgrad(dy_hi, w):
     return ops.conv_igemm(dy_hi, cout, _pack_conv(w), cin, batch=b, in_h=h2, in_w=w2, kh=2, kw=2, stride=2)
 
 
-def conv2x2s2_dgrad(dy, w):
+def conv2x2s2_dgrad(dy, w, wp=None):
     """Forward conv 2x2 stride 2 with w [N,C,2,2]; dy [B,H/2,W/2,N] -> dx [B,H,W,C]."""
     b, h, wd, n = dy.shape
     c = w.shape[1]
-    wp, _ = _pack_deconv(w, w.new_zeros((c,)), [(0, 0, n)], n)
+    if wp is None:
+        wp, _ = _pack_deconv(w, w.new_zeros((c,)), [(0, 0, n)], n)
     return ops.conv_igemm(dy, n, wp, 4 * c, batch=b, in_h=h, in_w=wd, out_mode=ops.OUT_DECONV2X)
 
 
@@ -222,12 +226,14 @@ def se_bwd(se_partial, hw, dgate_partial, w1, b1, w2t, b2):
     return dmean, dw1, db1, dw2, db2
 
 
-def dwconv_dgrad(dy, w, in_h, in_w, k, stride, circular):
+def dwconv_dgrad(dy, w, in_h, in_w, k, stride, circular, w_flipped=None):
     """w: packed depthwise weights [k*k, C] or [k, k, C].  Stride 1 is the forward depthwise kernel with the taps
     reversed (symmetric SAME padding, zero or circular): the register-sliding strip kernel instead of a gather."""
     if stride == 1:
         c = dy.shape[-1]
-        return ops.dwconv_raw(dy, w.reshape(k * k, c).flip(0).contiguous(), k, 1, circular)
+        if w_flipped is None:
+            w_flipped = w.reshape(k * k, c).flip(0).contiguous()
+        return ops.dwconv_raw(dy, w_flipped, k, 1, circular)
     lib = _lib.load()
     ops._chk(dy, "dy")
     ops._chk(w, "w")

@@ -144,7 +144,14 @@ _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image fo
 # Decoder levels (index j = 0..5 <-> level 6..1) whose ConvTranspose2d is folded into the following 3x3
 # conv (csrc/conv_igemm.hip: upconv kernels).  Measured at B=64 fp32 (ms/step): none 46.8, levels 6-3 42.6,
 # 6-2 41.95, all six 41.7 -> all levels by default (CCVPE_FOLD_LEVELS overrides, e.g. "" to disable).
-OVERLAP_DECODERS = __import__("os").environ.get("CCVPE_OVERLAP_DECODERS", "0") == "1"
+# orientation decoder on the side stream next to the localisation decoder: "auto" (default) = in bf16 storage only, where the
+# decoder kernels are short and far from the MFMA roof (C2, B = 32: 8.48 -> 7.80 ms; C1 model bf16 13.18 -> 13.05); in fp32
+# both decoders are MFMA-bound (35.59 -> 35.34 ms) and stay serial so that per-kernel timings are those of a kernel alone
+_OVERLAP_ENV = __import__("os").environ.get("CCVPE_OVERLAP_DECODERS", "auto")
+
+
+def _overlap_decoders(precision):
+    return _OVERLAP_ENV == "1" or (_OVERLAP_ENV == "auto" and precision == "bf16")
 FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
 # Below this many low-res pixels (batch * h * w) the folded GEMM has too few output tiles to fill the chip and walks
 # K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
@@ -191,6 +198,59 @@ def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
                     v += w3d[:, :, ky, kx] @ bd.double()
             shift9[rc * 3 + cc] = v
     return out.to(dtype).contiguous(), shift9.float().contiguous()
+
+
+def _pack_backward(sd, kind, pk):
+    """Train mode: the weights in the layouts the BACKWARD GEMMs read (ccvpe_amd/backward.py: 1x1 -> W^T; 3x3 -> taps flipped,
+    in / out swapped; ConvTranspose2d <-> conv 2x2 stride 2; stride-1 depthwise -> taps reversed), keyed by parameter name.
+    Built together with the forward pack, i.e. inside the ONE hipGraph that replays the per-step re-pack: the backward used to
+    re-lay them out with ~250 eager torch launches in the middle of its kernel stream."""
+    spec = MODEL_SPECS[kind]
+    n_rot = spec["n_rot"]
+    bwd = {}
+    for enc in ("grd_efficientnet", "sat_efficientnet"):
+        for i, (k, s_, ex, cin, cout) in enumerate(B0_BLOCKS):
+            bp = "%s._blocks.%d" % (enc, i)
+            if ex != 1:
+                bwd[bp + "._expand_conv.weight"] = _pack_conv(sd[bp + "._expand_conv.weight"].permute(1, 0, 2, 3))
+            bwd[bp + "._project_conv.weight"] = _pack_conv(sd[bp + "._project_conv.weight"].permute(1, 0, 2, 3))
+            if s_ == 1:
+                mid = cin * ex
+                w_dw = sd[bp + "._depthwise_conv.weight"].reshape(mid, k * k).t()            # [k*k, C] as the forward packs it
+                bwd[bp + "._depthwise_conv.weight"] = w_dw.flip(0).contiguous()
+        bwd[enc + "._conv_head.weight"] = _pack_conv(sd[enc + "._conv_head.weight"].permute(1, 0, 2, 3))
+    for j in range(6):
+        lvl = 6 - j
+        for branch, lv in (("", pk.loc[j]), ("_ori", pk.ori[j])):
+            conv, deconv = "conv%d%s" % (lvl, branch), "deconv%d%s" % (lvl, branch)
+            if lvl != 1:
+                bwd[conv + ".2.weight"] = _pack_conv(sd[conv + ".2.weight"].flip(2, 3).permute(1, 0, 2, 3))
+            bwd[conv + ".0.weight"] = _pack_conv(sd[conv + ".0.weight"].flip(2, 3).permute(1, 0, 2, 3))
+            # ConvTranspose2d weight [Cin_ref, Cout, 2, 2] -> rows in this implementation's input-channel order, as a conv 2x2 s2
+            w_ref = sd[deconv + ".weight"]
+            if branch == "":
+                c = lv.c
+                k_rows, cmap = lv.ldo, [(0, 1, c), (c, 0, 1)]
+            elif j == 0:
+                c6 = spec["ori"][0][0] - n_rot
+                k_rows, cmap = lv.k, [(0, n_rot, c6), (c6 + 1, 0, n_rot)]
+            else:
+                k_rows, cmap = lv.k, [(0, 0, spec["ori"][j][0])]
+            w_ours = w_ref.new_zeros((k_rows,) + tuple(w_ref.shape[1:]))
+            for d0, s0, n in cmap:
+                w_ours[d0:d0 + n] = w_ref[s0:s0 + n]
+            bwd[deconv + ".weight"] = _pack_conv(w_ours)
+    # aerial descriptor Linear == conv 2x2 s2: its input gradient is the pixel-shuffle GEMM
+    w = sd["sat_feature_to_descriptors.1.weight"]
+    w4 = w.view(w.shape[0], 1280, 2, 2)
+    bwd["sat_feature_to_descriptors.1.weight"] = _pack_deconv(w4, w4.new_zeros((1280,)), [(0, 0, w.shape[0])], w.shape[0])[0]
+    # six ground-descriptor 1x1 convs as one GEMM over the padded column count of the fused forward output
+    wcat = torch.cat([sd["grd_feature_to_descriptor%d.0.weight" % l] for l in range(1, 7)], 0)
+    ld = _round_up(pk.gd_n, 4)
+    wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
+    wpad[:pk.gd_n] = wcat
+    bwd["grd_feature_to_descriptor.0.weight"] = _pack_conv(wpad.permute(1, 0, 2, 3))
+    return bwd
 
 
 def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True, f32_tail=0):
@@ -283,6 +343,7 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True, f32_tail=0):
             ov.w_b = sd["conv1_ori.2.weight"].permute(0, 2, 3, 1).contiguous()  # [2][3][3][16]
         ov.b_b = sd["conv%d_ori.2.bias" % lvl].contiguous()
         pk.ori.append(ov)
+    pk.bwd = _pack_backward(sd, kind, pk) if (not fold and base_dtype == torch.float32) else None
     return pk
 
 
@@ -442,12 +503,15 @@ class _CVMBase(nn.Module):
         self._pack_key = key
         return self._pack_cache
 
-    def _side_stream(self):
+    def _side_stream(self, which=1):
+        """Extra HIP streams of this model: 1 = the ground encoder (eval and train), 2 = the decoders' weight gradients in
+        the training backward."""
         dev = next(self.parameters()).device
-        st = getattr(self, "_side", None)
+        streams = self.__dict__.setdefault("_side_streams", {})
+        st = streams.get(which)
         if st is None or st.device != dev:
             st = torch.cuda.Stream(device=dev)
-            self._side = st
+            streams[which] = st
         return st
 
     def _ori_decoder(self, pk, cat6, sfeats, batch):
@@ -535,6 +599,7 @@ class _CVMBase(nn.Module):
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
                                    in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
 
+            overlap = _overlap_decoders(self.precision)
             loc_shifts = self._loc_shifts()
             scores_out = []
             x = sdesc
@@ -571,7 +636,7 @@ class _CVMBase(nn.Module):
                     # runs on the side stream concurrently with the localisation decoder (measured: only
                     # 39.29 -> 39.09 ms, both are MFMA-bound; off by default so that per-kernel timings
                     # of the dominant GEMMs are not blurred by a co-running kernel)
-                    if OVERLAP_DECODERS:
+                    if overlap:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
                             x_ori = self._ori_decoder(pk, cat6, sfeats, batch)
@@ -595,7 +660,7 @@ class _CVMBase(nn.Module):
             logits = logits_map.reshape(batch, -1)                                   # models.py:319
             heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)             # models.py:320
 
-            if OVERLAP_DECODERS:
+            if overlap:
                 main.wait_stream(side)          # join the orientation decoder
                 x_ori.record_stream(main)
             else:

@@ -25,6 +25,10 @@ BN_EPS = 1e-3
 SKIP_BLOCKS = (15, 10, 4, 2, 0)
 # train mode: ground and aerial encoder (forward AND backward) on two HIP streams; CCVPE_TRAIN_TWO_STREAMS=0 for A/B runs
 TWO_STREAMS = __import__("os").environ.get("CCVPE_TRAIN_TWO_STREAMS", "1") != "0"
+# the decoders' weight gradients deferred to a third stream that runs beside the encoders' backward; =0 for A/B runs
+DEFER_WGRAD = __import__("os").environ.get("CCVPE_TRAIN_DEFER_WGRAD", "1") != "0"
+# (running the critical chain on HIGH-priority streams so that the deferred weight gradients only fill idle capacity measured
+# slower: 192.6 vs 173.3 ms per step — removed)
 
 
 def _round_up(v, m):
@@ -216,12 +220,14 @@ def _bn_bwd(live, name, grads, x_raw, dv, mean, var, act, **kw):
     return dx
 
 
-def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
-    """dfeat: gradient w.r.t. the 1280-channel output; dfeats {block index: gradient w.r.t. that block's output}."""
+def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads, bwd=None):
+    """dfeat: gradient w.r.t. the 1280-channel output; dfeats {block index: gradient w.r.t. that block's output}.
+    bwd: {parameter name: weight in the backward layout} from the train pack (models._pack_backward)."""
+    bwd = bwd or {}
     x_last, h_raw, m, v = tape["head"]
     dh = _bn_bwd(live, prefix + "._bn1", grads, h_raw, dfeat, m, v, ops.ACT_SWISH)
     grads[prefix + "._conv_head.weight"] = bw.conv_wgrad(x_last, dh, 1280, 1, 1, 1, 0)
-    dx = bw.conv1x1_dgrad(dh, _p(live, prefix + "._conv_head.weight"))
+    dx = bw.conv1x1_dgrad(dh, _p(live, prefix + "._conv_head.weight"), wp=bwd.get(prefix + "._conv_head.weight"))
     for i in reversed(range(len(e.blocks))):
         blk, s = e.blocks[i], tape["blocks"][i]
         bp = "%s._blocks.%d" % (prefix, i)
@@ -231,7 +237,7 @@ def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
         # project conv + bn2 (+ residual, drop_connect)
         dp = _bn_bwd(live, bp + "._bn2", grads, s["p_raw"], dx, s["m2"], s["v2"], ops.ACT_NONE, dc_scale=s["dc"])
         grads[bp + "._project_conv.weight"] = bw.conv1x1_wgrad_gated(s["u"], s["gate"], dp, blk.cout)
-        dv = bw.conv1x1_dgrad(dp, _p(live, bp + "._project_conv.weight"))
+        dv = bw.conv1x1_dgrad(dp, _p(live, bp + "._project_conv.weight"), wp=bwd.get(bp + "._project_conv.weight"))
         # squeeze-excite
         g1, b1 = _p(live, bp + "._bn1.weight"), _p(live, bp + "._bn1.bias")
         # BN1 + SE backward in two passes over (u_raw, dv): five per-(sample, channel) sums first (A[0] = the gate gradient),
@@ -245,12 +251,12 @@ def encoder_backward(e, live, prefix, tape, dfeat, dfeats, circular, grads):
         du, dg1, db1n = bw.se_bn_bwd_apply(s["u_raw"], dv, s["m1"], s["v1"], g1, b1, BN_EPS, ops.ACT_SWISH, s["gate"], dmean, sums)
         grads[bp + "._bn1.weight"], grads[bp + "._bn1.bias"] = dg1, db1n
         grads[bp + "._depthwise_conv.weight"] = bw.dwconv_wgrad(s["t"], du, blk.k, blk.s, circular).t()
-        dt = bw.dwconv_dgrad(du, blk.w_dw, h, w, blk.k, blk.s, circular)
+        dt = bw.dwconv_dgrad(du, blk.w_dw, h, w, blk.k, blk.s, circular, w_flipped=bwd.get(bp + "._depthwise_conv.weight"))
         # expand conv + bn0
         if blk.expand:
             de = _bn_bwd(live, bp + "._bn0", grads, s["e_raw"], dt, s["m0"], s["v0"], ops.ACT_SWISH)
             grads[bp + "._expand_conv.weight"] = bw.conv_wgrad(s["x_in"], de, blk.mid, 1, 1, 1, 0)
-            dxin = bw.conv1x1_dgrad(de, _p(live, bp + "._expand_conv.weight"))
+            dxin = bw.conv1x1_dgrad(de, _p(live, bp + "._expand_conv.weight"), wp=bwd.get(bp + "._expand_conv.weight"))
         else:
             dxin = dt
         if blk.skip:
@@ -268,10 +274,14 @@ def _scatter_rows(dst, src, col_map):
     return dst
 
 
-def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, skip_block, grads):
+def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, skip_block, grads, bwd=None, defer=None):
     """names = (deconv, conv); dout: gradient w.r.t. the level's output (NHWC, or NCHW head output when last).
     Returns the gradient w.r.t. the level's input `cat` [B,hw,hw,k] in this implementation's column order."""
     deconv, conv = names
+    bwd = bwd or {}
+    if defer is None:                  # weight gradients right here (tests of a single level)
+        def defer(fn):
+            fn()
     y, up, skip, cat, k = t["y"], t["up"], t["skip"], t["cat"], t["k"]
     w_b = _p(live, conv + ".2.weight")
     if last:
@@ -279,10 +289,15 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
         grads[conv + ".2.weight"] = dwb.permute(0, 3, 1, 2)
         grads[conv + ".2.bias"] = dbb
     else:
-        grads[conv + ".2.weight"], grads[conv + ".2.bias"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1, want_bias=True)
-        dy = bw.conv3x3_dgrad(dout, w_b, relu_out=y)                               # ReLU backward fused in the store
-    grads[conv + ".0.weight"], grads[conv + ".0.bias"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip, want_bias=True)
-    dcat2 = bw.conv3x3_dgrad(dy, _p(live, conv + ".0.weight"))                 # [B,2hw,2hw,c0+c1]
+        def wg2(y=y, dout=dout):
+            grads[conv + ".2.weight"], grads[conv + ".2.bias"] = bw.conv_wgrad(y, dout, lv.n_b, 3, 3, 1, 1, want_bias=True)
+        defer(wg2)
+        dy = bw.conv3x3_dgrad(dout, w_b, relu_out=y, wp=bwd.get(conv + ".2.weight"))   # ReLU backward fused in the store
+
+    def wg0(dy=dy):
+        grads[conv + ".0.weight"], grads[conv + ".0.bias"] = bw.conv_wgrad(up, dy, lv.n_a, 3, 3, 1, 1, x1=skip, want_bias=True)
+    defer(wg0)
+    dcat2 = bw.conv3x3_dgrad(dy, _p(live, conv + ".0.weight"), wp=bwd.get(conv + ".0.weight"))   # [B,2hw,2hw,c0+c1]
     if skip is not None:
         if skip_block in dfeats:
             bw.add_cols(dcat2, lv.c0, lv.c1, dfeats[skip_block])
@@ -292,15 +307,20 @@ def _decoder_level_backward(live, lv, t, dout, last, names, col_map, dfeats, ski
     # ConvTranspose2d(k2,s2): weight [Cin,Cout,2,2] (Cin in reference order), bias [Cout]
     w_ref = _p(live, deconv + ".weight")
     cout = w_ref.shape[1]
-    grads[deconv + ".bias"] = bw.bias_grad(dcat2, cout)
-    dw_ours = bw.conv_wgrad(dcat2, cat, k, 2, 2, 2, 0, c0=cout)                 # [k, Cout, 2, 2], our row order
-    grads[deconv + ".weight"] = _scatter_rows(torch.empty_like(w_ref), dw_ours, col_map)
-    w_ours = w_ref.new_zeros((k,) + tuple(w_ref.shape[1:]))
-    for d0, s0, n in col_map:
-        w_ours[d0:d0 + n] = w_ref[s0:s0 + n]
+
+    def wgd(dcat2=dcat2):
+        grads[deconv + ".bias"] = bw.bias_grad(dcat2, cout)
+        dw_ours = bw.conv_wgrad(dcat2, cat, k, 2, 2, 2, 0, c0=cout)             # [k, Cout, 2, 2], our row order
+        grads[deconv + ".weight"] = _scatter_rows(torch.empty_like(w_ref), dw_ours, col_map)
+    defer(wgd)
+    wp = bwd.get(deconv + ".weight")
+    if wp is None:
+        w_ours = w_ref.new_zeros((k,) + tuple(w_ref.shape[1:]))
+        for d0, s0, n in col_map:
+            w_ours[d0:d0 + n] = w_ref[s0:s0 + n]
+        wp = bw._pack_conv(w_ours)
     b, h2 = dcat2.shape[0], dcat2.shape[1]
-    return ops.conv_igemm(dcat2, cout, bw._pack_conv(w_ours), k, batch=b, in_h=h2, in_w=h2, kh=2, kw=2, stride=2,
-                          ld0=dcat2.shape[-1])
+    return ops.conv_igemm(dcat2, cout, wp, k, batch=b, in_h=h2, in_w=h2, kh=2, kw=2, stride=2, ld0=dcat2.shape[-1])
 
 
 def backward_train(model, tape, gout, on_ready=None):
@@ -312,6 +332,7 @@ def backward_train(model, tape, gout, on_ready=None):
     spec = MODEL_SPECS[model.kind]
     n_rot = spec["n_rot"]
     pk, live = tape["pk"], tape["live"]          # the forward's packed weights / parameter table (nothing changed since)
+    bwd = getattr(pk, "bwd", None) or {}         # backward-layout weights, built inside the per-step re-pack graph
     grads = {}
     dfeats = {}
     g_logits, g_heat, g_ori = gout[0], gout[1], gout[2]
@@ -340,6 +361,13 @@ def backward_train(model, tape, gout, on_ready=None):
     else:
         dori = torch.zeros((batch, 2) + tuple(heatmap.shape[2:]), device=dev, dtype=torch.float32)
 
+    # The decoders' WEIGHT gradients (MFMA-bound, ~20 % of the step) are off the critical path: nothing in the backward
+    # reads them.  They are collected here and launched on a third stream when the encoders' backward starts — a phase of
+    # HBM- / latency-bound kernels (BatchNorm, depthwise, SE) that leaves the matrix cores idle — instead of sitting between
+    # the input-gradient GEMMs of the decoder chain.
+    deferred = []
+    defer = deferred.append if DEFER_WGRAD else None
+
     # ---- orientation decoder, level 1 -> 6 ----------------------------------------------------------------
     d = dori
     for j in reversed(range(6)):
@@ -351,7 +379,7 @@ def backward_train(model, tape, gout, on_ready=None):
         else:
             cmap = [(0, 0, spec["ori"][j][0])]
         d = _decoder_level_backward(live, ov, tape["ori"][j], d, j == 5, ("deconv%d_ori" % lvl, "conv%d_ori" % lvl), cmap,
-                                    dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads)
+                                    dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads, bwd, defer)
     dcat6_ori = d
 
     # ---- localisation decoder + matching, level 1 -> 6 -------------------------------------------------
@@ -362,7 +390,7 @@ def backward_train(model, tape, gout, on_ready=None):
         lv = pk.loc[j]
         c = lv.c
         dcat = _decoder_level_backward(live, lv, tape["loc"][j], d, j == 5, ("deconv%d" % lvl, "conv%d" % lvl),
-                                       [(0, 1, c), (c, 0, 1)], dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads)
+                                       [(0, 1, c), (c, 0, 1)], dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads, bwd, defer)
         if j == 0:
             bw.add_cols(dcat6_ori, 0, lv.ldo, dcat)
         mt = tape["match"][j]
@@ -376,16 +404,29 @@ def backward_train(model, tape, gout, on_ready=None):
     w_lin = _p(live, "sat_feature_to_descriptors.1.weight")
     w4 = w_lin.view(w_lin.shape[0], 1280, 2, 2)
     svol = tape["svol"]
-    dw_lin, grads["sat_feature_to_descriptors.1.bias"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0, want_bias=True)
-    grads["sat_feature_to_descriptors.1.weight"] = dw_lin.reshape(w_lin.shape)
-    dsvol = bw.conv2x2s2_dgrad(dsdesc, w4)
-    if on_ready is not None:
+    def wg_lin(dsdesc=dsdesc):
+        dw_lin, grads["sat_feature_to_descriptors.1.bias"] = bw.conv_wgrad(svol, dsdesc, pk.sd_n, 2, 2, 2, 0, want_bias=True)
+        grads["sat_feature_to_descriptors.1.weight"] = dw_lin.reshape(w_lin.shape)
+    (defer or (lambda fn: fn()))(wg_lin)
+    dsvol = bw.conv2x2s2_dgrad(dsdesc, w4, wp=bwd.get("sat_feature_to_descriptors.1.weight"))
+    main = torch.cuda.current_stream()
+    wst = model._side_stream(2) if deferred else main
+    if deferred:
+        wst.wait_stream(main)
+        g_dec = grads
+        with torch.cuda.stream(wst):
+            for fn in deferred:
+                fn()
+        # (the closures keep the decoder's gradient tensors — allocated on the main stream, read on this one — alive until
+        # the join below: freed earlier, the allocator would hand their blocks to the encoders' backward while these kernels
+        # are still queued)
+        grads = {}                         # the encoders' gradients are collected apart until the weight-gradient stream joins
+    elif on_ready is not None:
         on_ready(grads)
 
     # ---- the two encoders' backward passes are independent: ground descriptors + ground encoder on the side stream, aerial
     # encoder on the main stream (both are chains of small HBM- / latency-bound launches).  Their gradients are collected in
     # separate dicts so that on_ready never sees a gradient whose kernels are still queued on the other stream.
-    main = torch.cuda.current_stream()
     side = model._side_stream() if TWO_STREAMS else main
     side.wait_stream(main)
     g_grd = {}
@@ -407,14 +448,27 @@ def backward_train(model, tape, gout, on_ready=None):
             off += cd
         b, gh, gw, ld = dy1.shape
         # dy1's pad columns (n..ld) are zero; the K dimension of the dgrad GEMM is padded to ld with zero weights
-        wcat = torch.cat([_p(live, "grd_feature_to_descriptor%d.0.weight" % l) for l in range(1, 7)], 0)
-        wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
-        wpad[:n] = wcat
-        dgfeat = ops.conv_igemm(dy1, ld, bw._pack_conv(wpad.permute(1, 0, 2, 3)), 1280, batch=b, in_h=gh, in_w=gw)
-        encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], g_grd)
-    encoder_backward(pk.sat, live, "sat_efficientnet", tape["sat"], dsvol, dfeats, False, grads)
+        wgd = bwd.get("grd_feature_to_descriptor.0.weight")
+        if wgd is None:
+            wcat = torch.cat([_p(live, "grd_feature_to_descriptor%d.0.weight" % l) for l in range(1, 7)], 0)
+            wpad = wcat.new_zeros((ld,) + tuple(wcat.shape[1:]))
+            wpad[:n] = wcat
+            wgd = bw._pack_conv(wpad.permute(1, 0, 2, 3))
+        dgfeat = ops.conv_igemm(dy1, ld, wgd, 1280, batch=b, in_h=gh, in_w=gw)
+        encoder_backward(pk.grd, live, "grd_efficientnet", tape["grd"], dgfeat, {}, tape["circular"], g_grd, bwd)
+    encoder_backward(pk.sat, live, "sat_efficientnet", tape["sat"], dsvol, dfeats, False, grads, bwd)
     if on_ready is not None:
-        on_ready(grads)
+        on_ready(grads)                    # (aerial encoder: gradient group 1)
+    if wst is not main:
+        main.wait_stream(wst)              # join the decoders' weight gradients (group 0)
+        wst.wait_stream(main)
+        deferred = None
+        for t in g_dec.values():
+            if t is not None and t.is_cuda:
+                t.record_stream(main)      # allocated on the weight-gradient stream, consumed on the main stream
+        grads.update(g_dec)
+        if on_ready is not None:
+            on_ready(grads)
     main.wait_stream(side)                 # join: the ground gradients are complete on the main stream's timeline from here
     side.wait_stream(main)                 # ... and later side-stream work cannot overtake the main stream's readers
     grads.update(g_grd)

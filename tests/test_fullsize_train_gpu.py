@@ -119,3 +119,44 @@ def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_s
 # printed by the test.
 PERM_MEDIAN_RTOL = 3e-4
 PERM_WORST_RTOL = 3e-2
+
+
+def test_stream_overlap_does_not_change_a_single_bit(synth_sd):
+    """The training step overlaps work on three HIP streams (the two encoders forward and backward; the decoders' weight
+    gradients beside the encoders' backward).  Stream overlap may only change WHEN a kernel runs: loss, every gradient and the
+    BatchNorm running statistics must be bit-identical to the single-stream schedule — a cross-stream race (a tensor freed
+    while another stream still reads it, a missing join) shows up here as a differing bit."""
+    from ccvpe_amd import models, train
+    batch = 16
+    grd, sat = synth.synthetic_pair(batch, "vigor", 4321)
+    grd, sat = grd.cuda(), sat.cuda()
+    u = synth.uniform((batch, 3), 77)
+    center, angle = ((u[:, :2] - 0.5) * 384.0).cuda(), (u[:, 2] * 359.99).cuda()
+    keys = [("%s_efficientnet" % e, i) for e in ("grd", "sat") for i in range(16)]
+    masks = {k: (synth.uniform((batch,), 7100 + j) > 0.1).float().cuda() for j, k in enumerate(keys)}
+
+    def run(two, defer):
+        old = train.TWO_STREAMS, train.DEFER_WGRAD
+        train.TWO_STREAMS, train.DEFER_WGRAD = two, defer
+        try:
+            net = models.CVM_VIGOR("cuda", True)
+            net.load_state_dict(synth_sd("vigor", 0), strict=True)
+            net = net.to("cuda:0").train()
+            out = []
+            for _ in range(2):                      # the second step also covers stream-pool reuse across steps
+                out.append(_step(net, grd, sat, masks, center, angle))
+            stats = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
+            return out, stats
+        finally:
+            train.TWO_STREAMS, train.DEFER_WGRAD = old
+
+    ref, ref_stats = run(False, False)
+    for two, defer in ((True, False), (True, True)):
+        got, stats = run(two, defer)
+        for (l0, g0), (l1, g1) in zip(ref, got):
+            assert l0 == l1, (two, defer, l0, l1)
+            assert set(g0) == set(g1)
+            for n in g0:
+                assert torch.equal(g0[n], g1[n]), "gradient of %s changes with the stream schedule (two=%s defer=%s)" % (n, two, defer)
+        for k in ref_stats:
+            assert torch.equal(ref_stats[k], stats[k]), k
