@@ -1,0 +1,65 @@
+"""SURVEY.md 8(f)-4, device half: ccvpe_amd.datasets.DeviceBatches — decoded uint8 images + three scalars per sample in,
+normalised / rolled / cropped fp32 batches and the training ground truth out, all as kernels on the MI355X — against the
+oracle's PIL-exact transform and ground-truth restatement (both pinned to the reference's dataset class in
+tests/test_oracle_vs_reference.py / tests/test_datasets.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from ccvpe_amd import datasets as DS
+from oracle import ccvpe_oracle as O
+from test_datasets import GOLDEN, make_vigor_tree
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("fov,jpeg", [(360, True), (180, False)])
+def test_device_batches_match_the_oracle_pipeline(tmp_path, fov, jpeg):
+    make_vigor_tree(str(tmp_path), jpeg=jpeg)
+    orient = np.load(os.path.join(GOLDEN, "samearea_orientation_test_head256.npy"))
+    ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=True, ori_noise=180, random_orientation=orient)
+    seen = []
+    for batch in DS.DeviceBatches(ds, 5, device="cuda", workers=3, fov=fov):
+        b = len(batch.indices)
+        keep = int(fov / 360 * 640)
+        assert tuple(batch.grd.shape) == (b, 3, 320, keep) and tuple(batch.sat.shape) == (b, 3, 512, 512)
+        for j, i in enumerate(batch.indices):
+            s = ds.sample(i)
+            want_g = O.preprocess_reference(s["grd_u8"], (320, 640), roll=s["roll"])[:, :, :keep]
+            assert torch.equal(batch.grd[j].cpu(), want_g), "ground image of sample %d" % i
+            assert torch.equal(batch.sat[j].cpu(), O.preprocess_reference(s["sat_u8"], (512, 512)))
+            g, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 20)
+            assert (batch.gt[j].cpu() - g[0]).abs().max() < 1e-6 and (batch.gt_ori[j].cpu() - ori[0]).abs().max() < 1e-6
+            assert (batch.gt_flat[j].cpu() - flat[0]).abs().max() < 1e-9
+            for a, w in zip(batch.labels, labs):
+                assert (a[j].cpu() - w[0]).abs().max() < 1e-6
+            assert batch.cities[j] == ds.city_of[i] and abs(float(batch.angle_deg[j]) - s["angle_deg"]) < 1e-3
+        seen += batch.indices
+    assert seen == list(range(12))
+
+
+def test_device_batches_shards_and_model_forward(tmp_path, synth_sd):
+    """Two ranks' shards are disjoint and complete, and a batch goes straight into the model."""
+    from ccvpe_amd import models
+    make_vigor_tree(str(tmp_path))
+    ds = DS.VIGORPairs(str(tmp_path), split="crossarea", train=False, ori_noise=180,
+                       random_orientation=os.path.join(GOLDEN, "crossarea_orientation_test_head256.npy"))
+    got = [sum((b.indices for b in DS.DeviceBatches(ds, 2, device="cuda", rank=r, world=2, targets=False)), []) for r in range(2)]
+    assert sorted(got[0] + got[1]) == list(range(6)) and not set(got[0]) & set(got[1])
+    net = models.CVM_VIGOR_ori_prior("cuda", 180, True)
+    net.load_state_dict(synth_sd("vigor", 0), strict=True)
+    net = net.to("cuda:0").eval()
+    batch = next(iter(DS.DeviceBatches(ds, 2, device="cuda", targets=False)))
+    out = net(batch.grd, batch.sat)
+    assert tuple(out[0].shape) == (2, 512 * 512) and torch.isfinite(out[0]).all()
+
+
+def test_unreadable_aerial_tile_raises_in_the_consumer(tmp_path):
+    make_vigor_tree(str(tmp_path))
+    ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=True)
+    os.remove(ds.sat_paths[ds.labels[3, 0]])
+    with pytest.raises((OSError, FileNotFoundError)):
+        for _ in DS.DeviceBatches(ds, 4, device="cuda"):
+            pass

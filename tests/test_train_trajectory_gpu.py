@@ -1,4 +1,4 @@
-"""A whole optimisation TRAJECTORY, not one gradient: 6 training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
+"""A whole optimisation TRAJECTORY, not one gradient: 4 training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
 ground truth, train-mode forward with running-statistic updates, the reference's loss mix train_VIGOR.py:137-146, the HIP
 backward through the gradient arena, the one-launch Adam) against the CPU oracle driven by autograd + torch.optim.Adam on
 the same weights, pairs, drop_connect draws and targets.  Per-step gradients agree to ~1 % per tensor (golden_util
@@ -13,7 +13,7 @@ from oracle import ccvpe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-STEPS = 6      # (10 in round 2: 150 s of CPU oracle steps; 6 keeps the GPU suite inside its time box)
+STEPS = 4      # (10 in round 2: 150 s of CPU oracle steps; 4 keeps the GPU suite inside its 900 s time box)
 LR = 1e-4                      # train_VIGOR.py:104
 
 
