@@ -409,6 +409,7 @@ def main():
 
     from ccvpe_amd import models, ops, synth, _lib
     _lib.load()                                             # fails loudly if the HIP library is missing
+    torch.manual_seed(1234 + rank)                          # drop_connect draws of the training legs: the same in every run
 
     kind = args.model if args.model in ("kitti", "oxford") else "vigor"
     sd = synth.synthetic_state_dict(kind, 0)                # identical on every rank
@@ -524,6 +525,30 @@ def main():
         legs = {}
         want = set(args.legs.split(","))
         del fwd
+        # (4) BASELINE.json's metric string names "(fwd+bwd) VIGOR bs=64": the full training step of CVM_VIGOR (N_rot = 20)
+        #     at batch 64 per GPU: ground truth, train-mode forward, losses, backward, (all-reduce,) Adam
+        try:
+            del net                                 # (first among the side legs: right after the fp32 headline, before the
+            torch.cuda.empty_cache()                # bf16 legs and the B = 256 graph have churned the allocator)
+            if "train" not in want:
+                raise KeyError("skipped")
+            net3 = models.CVM_VIGOR(dev, True)
+            net3.load_state_dict(sd, strict=True)
+            net3 = net3.to(dev)
+            # 3 warm-up steps: the 2nd captures the re-pack hipGraph, and the caching allocator's pools of the three streams of
+            # the training step stop growing by the 3rd
+            ent, _ = train_entry(net3, "vigor", grd, sat, dev, args.batch, 5, 3, rank, world, 20, record,
+                                 tag="fwd_bwd_vigor_b64")
+            if rank == 0:
+                if world == 1 and not args.no_cpu_baseline:
+                    ent["cpu_baseline"] = cpu_baseline_train(sd, "vigor")
+                legs["fwd_bwd_vigor_b64"] = ent
+            del net3
+        except KeyError:
+            pass
+        except Exception as ex:
+            if rank == 0:
+                legs["fwd_bwd_vigor_b64"] = {"error": repr(ex)}
         # (1) BASELINE configs[2] "C2": CVM_VIGOR, N_rot = 20, batch 32, bf16 storage; (2) the C1 model in bf16 at batch 64
         #     (the north-star's ">= 10 000 pairs/s forward at batch 64" is a bf16 goal: fp32 MFMA ceiling is 2.8 k);
         # (3) configs[4] "C4": ori_prior(180), FoV 180 ground input, bf16, hipGraph replay at batch 256
@@ -558,30 +583,6 @@ def main():
             except Exception as ex:      # the headline must not depend on a side measurement; the error is driver-visible
                 if rank == 0:
                     legs[tag] = {"error": repr(ex)}
-        # (4) BASELINE.json's metric string names "(fwd+bwd) VIGOR bs=64": the full training step of CVM_VIGOR (N_rot = 20)
-        #     at batch 64 per GPU: ground truth, train-mode forward, losses, backward, (all-reduce,) Adam
-        try:
-            del net
-            torch.cuda.empty_cache()
-            if "train" not in want:
-                raise KeyError("skipped")
-            net3 = models.CVM_VIGOR(dev, True)
-            net3.load_state_dict(sd, strict=True)
-            net3 = net3.to(dev)
-            # 3 warm-up steps: the 2nd captures the re-pack hipGraph, and the caching allocator's pools of the three streams of
-            # the training step stop growing by the 3rd
-            ent, _ = train_entry(net3, "vigor", grd, sat, dev, args.batch, 5, 3, rank, world, 20, record,
-                                 tag="fwd_bwd_vigor_b64")
-            if rank == 0:
-                if world == 1 and not args.no_cpu_baseline:
-                    ent["cpu_baseline"] = cpu_baseline_train(sd, "vigor")
-                legs["fwd_bwd_vigor_b64"] = ent
-            del net3
-        except KeyError:
-            pass
-        except Exception as ex:
-            if rank == 0:
-                legs["fwd_bwd_vigor_b64"] = {"error": repr(ex)}
         # (5) under a process group (N > 1): BASELINE configs[3] "C3" — CVM_KITTI data-parallel training step, batch 64 per
         #     GPU, gradients averaged by RCCL all-reduce over xGMI.  This is the ONLY leg with a data-path collective: if it
         #     fails the line is still printed (with the error) and the process exits non-zero.

@@ -28,7 +28,8 @@ TWO_STREAMS = __import__("os").environ.get("CCVPE_TRAIN_TWO_STREAMS", "1") != "0
 # the decoders' weight gradients deferred to a third stream that runs beside the encoders' backward; =0 for A/B runs
 DEFER_WGRAD = __import__("os").environ.get("CCVPE_TRAIN_DEFER_WGRAD", "1") != "0"
 # (running the critical chain on HIGH-priority streams so that the deferred weight gradients only fill idle capacity measured
-# slower: 192.6 vs 173.3 ms per step — removed)
+# slower: 192.6 vs 173.3 ms per step — removed; so did confining them to half / a quarter of the CUs with
+# hipExtStreamCreateWithCUMask: 188.9 / 186.9 vs 175.1 ms)
 
 
 def _round_up(v, m):

@@ -31,10 +31,11 @@ def test_device_batches_match_the_oracle_pipeline(tmp_path, fov, jpeg):
             assert torch.equal(batch.grd[j].cpu(), want_g), "ground image of sample %d" % i
             assert torch.equal(batch.sat[j].cpu(), O.preprocess_reference(s["sat_u8"], (512, 512)))
             g, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 20)
-            assert (batch.gt[j].cpu() - g[0]).abs().max() < 1e-6 and (batch.gt_ori[j].cpu() - ori[0]).abs().max() < 1e-6
-            assert (batch.gt_flat[j].cpu() - flat[0]).abs().max() < 1e-9
+            # (the device takes the angle as fp32: the orientation-bin weights (angle % 18) / 18 carry ~1e-6 of that)
+            assert (batch.gt[j].cpu() - g[0]).abs().max() < 1e-5 and (batch.gt_ori[j].cpu() - ori[0]).abs().max() < 1e-5
+            assert (batch.gt_flat[j].cpu() - flat[0]).abs().max() < 2e-6 * float(flat[0].max())      # (normalised to sum 1: peak ~1e-2)
             for a, w in zip(batch.labels, labs):
-                assert (a[j].cpu() - w[0]).abs().max() < 1e-6
+                assert (a[j].cpu() - w[0]).abs().max() < 1e-5
             assert batch.cities[j] == ds.city_of[i] and abs(float(batch.angle_deg[j]) - s["angle_deg"]) < 1e-3
         seen += batch.indices
     assert seen == list(range(12))
