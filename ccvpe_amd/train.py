@@ -27,6 +27,8 @@ SKIP_BLOCKS = (15, 10, 4, 2, 0)
 TWO_STREAMS = __import__("os").environ.get("CCVPE_TRAIN_TWO_STREAMS", "1") != "0"
 # the decoders' weight gradients deferred to a third stream that runs beside the encoders' backward; =0 for A/B runs
 DEFER_WGRAD = __import__("os").environ.get("CCVPE_TRAIN_DEFER_WGRAD", "1") != "0"
+# localisation and orientation decoders on two streams (forward and backward); CCVPE_TRAIN_DECODER_STREAMS=0 for A/B runs
+DECODER_STREAMS = TWO_STREAMS and __import__("os").environ.get("CCVPE_TRAIN_DECODER_STREAMS", "1") != "0"
 # (running the critical chain on HIGH-priority streams so that the deferred weight gradients only fill idle capacity measured
 # slower: 192.6 vs 173.3 ms per step — removed; so did confining them to half / a quarter of the CUs with
 # hipExtStreamCreateWithCUMask: 188.9 / 186.9 vs 175.1 ms)
@@ -184,6 +186,12 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
         goff += L
         if j == 0:
             cat6 = cat
+            if DECODER_STREAMS:
+                # the orientation decoder needs only cat6 + the skips: it runs on the side stream beside the localisation
+                # decoder (whose narrow high-resolution levels leave matrix-core time the other's wide levels can use)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    xo = _ori_decoder_forward(pk, cat6, sfeats, batch, rec, tape)
         scores_out.append(sc)
         skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
         x, t = _decoder_level(lv, cat, lv.ldo, lv.c + 1, skip, batch, hw, j == 5, 1, rec)
@@ -193,6 +201,18 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
     logits = logits_map.reshape(batch, -1)                                        # models.py:319
     heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)                  # models.py:320
 
+    if DECODER_STREAMS:
+        main.wait_stream(side)
+        if side is not main:
+            xo.record_stream(main)
+    else:
+        xo = _ori_decoder_forward(pk, cat6, sfeats, batch, rec, tape)
+    if rec:
+        tape["heatmap"] = heatmap
+    return (logits, heatmap, xo) + tuple(scores_out), tape
+
+
+def _ori_decoder_forward(pk, cat6, sfeats, batch, rec, tape):
     xo = cat6
     for j in range(6):
         ov = pk.ori[j]
@@ -201,9 +221,7 @@ def forward_train(model, grd, sat, drop_masks=None, rec=False):
         xo, t = _decoder_level(ov, xo, ov.k, ov.k_algo, skip, batch, hw, j == 5, 2, rec)
         if rec:
             tape["ori"].append(t)
-    if rec:
-        tape["heatmap"] = heatmap
-    return (logits, heatmap, xo) + tuple(scores_out), tape
+    return xo
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -369,19 +387,26 @@ def backward_train(model, tape, gout, on_ready=None):
     deferred = []
     defer = deferred.append if DEFER_WGRAD else None
 
-    # ---- orientation decoder, level 1 -> 6 ----------------------------------------------------------------
-    d = dori
-    for j in reversed(range(6)):
-        lvl = 6 - j
-        ov = pk.ori[j]
-        if j == 0:
-            c6 = spec["ori"][0][0] - n_rot
-            cmap = [(0, n_rot, c6), (c6 + 1, 0, n_rot)]
-        else:
-            cmap = [(0, 0, spec["ori"][j][0])]
-        d = _decoder_level_backward(live, ov, tape["ori"][j], d, j == 5, ("deconv%d_ori" % lvl, "conv%d_ori" % lvl), cmap,
-                                    dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads, bwd, defer)
-    dcat6_ori = d
+    # ---- orientation decoder, level 1 -> 6: on the side stream beside the localisation decoder + matching (its skip
+    # gradients go to a dict of its own and are added to the localisation decoder's afterwards: two streams must not
+    # read-modify-write one tensor) ------------------------------------------------------------------------------------
+    main0 = torch.cuda.current_stream()
+    dside = model._side_stream() if DECODER_STREAMS else main0
+    dfeats_ori = {} if DECODER_STREAMS else dfeats
+    dside.wait_stream(main0)
+    with torch.cuda.stream(dside):
+        d = dori
+        for j in reversed(range(6)):
+            lvl = 6 - j
+            ov = pk.ori[j]
+            if j == 0:
+                c6 = spec["ori"][0][0] - n_rot
+                cmap = [(0, n_rot, c6), (c6 + 1, 0, n_rot)]
+            else:
+                cmap = [(0, 0, spec["ori"][j][0])]
+            d = _decoder_level_backward(live, ov, tape["ori"][j], d, j == 5, ("deconv%d_ori" % lvl, "conv%d_ori" % lvl), cmap,
+                                        dfeats_ori, SKIP_BLOCKS[j] if j < 5 else None, grads, bwd, defer)
+        dcat6_ori = d
 
     # ---- localisation decoder + matching, level 1 -> 6 -------------------------------------------------
     dgdesc = torch.zeros_like(tape["gdesc"])
@@ -393,6 +418,14 @@ def backward_train(model, tape, gout, on_ready=None):
         dcat = _decoder_level_backward(live, lv, tape["loc"][j], d, j == 5, ("deconv%d" % lvl, "conv%d" % lvl),
                                        [(0, 1, c), (c, 0, 1)], dfeats, SKIP_BLOCKS[j] if j < 5 else None, grads, bwd, defer)
         if j == 0:
+            if DECODER_STREAMS:                # join the orientation decoder's backward
+                main0.wait_stream(dside)
+                dside.wait_stream(main0)
+                for blk, t in dfeats_ori.items():
+                    if blk in dfeats:
+                        bw.add_cols(t, 0, t.shape[-1], dfeats[blk])
+                    else:
+                        dfeats[blk] = t
             bw.add_cols(dcat6_ori, 0, lv.ldo, dcat)
         mt = tape["match"][j]
         g = tape["gdesc"][:, mt["goff"]:mt["goff"] + mt["L"]]

@@ -122,8 +122,8 @@ PERM_WORST_RTOL = 3e-2
 
 
 def test_stream_overlap_does_not_change_a_single_bit(synth_sd):
-    """The training step overlaps work on three HIP streams (the two encoders forward and backward; the decoders' weight
-    gradients beside the encoders' backward).  Stream overlap may only change WHEN a kernel runs: loss, every gradient and the
+    """The training step overlaps work on three HIP streams (the two encoders and the two decoders, forward and backward; the
+    decoders' weight gradients beside the encoders' backward).  Stream overlap may only change WHEN a kernel runs: loss, every gradient and the
     BatchNorm running statistics must be bit-identical to the single-stream schedule — a cross-stream race (a tensor freed
     while another stream still reads it, a missing join) shows up here as a differing bit."""
     from ccvpe_amd import models, train
@@ -136,8 +136,8 @@ def test_stream_overlap_does_not_change_a_single_bit(synth_sd):
     masks = {k: (synth.uniform((batch,), 7100 + j) > 0.1).float().cuda() for j, k in enumerate(keys)}
 
     def run(two, defer):
-        old = train.TWO_STREAMS, train.DEFER_WGRAD
-        train.TWO_STREAMS, train.DEFER_WGRAD = two, defer
+        old = train.TWO_STREAMS, train.DEFER_WGRAD, train.DECODER_STREAMS
+        train.TWO_STREAMS, train.DEFER_WGRAD, train.DECODER_STREAMS = two, defer, two
         try:
             net = models.CVM_VIGOR("cuda", True)
             net.load_state_dict(synth_sd("vigor", 0), strict=True)
@@ -148,7 +148,7 @@ def test_stream_overlap_does_not_change_a_single_bit(synth_sd):
             stats = {k: v.clone() for k, v in net.state_dict().items() if "running_" in k}
             return out, stats
         finally:
-            train.TWO_STREAMS, train.DEFER_WGRAD = old
+            train.TWO_STREAMS, train.DEFER_WGRAD, train.DECODER_STREAMS = old
 
     ref, ref_stats = run(False, False)
     for two, defer in ((True, False), (True, True)):
