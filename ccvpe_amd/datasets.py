@@ -114,19 +114,19 @@ class VIGORPairs(object):
         from PIL import Image
         try:
             with Image.open(self.grd_paths[idx]) as im:
-                grd = np.asarray(im.convert("RGB"))
+                grd = np.array(im.convert("RGB"))             # owning, writable: torch.from_numpy needs that
         except (OSError, ValueError):                                  # unreadable panorama -> blank image (datasets.py:103-105)
             grd = np.zeros((grd_hw[0], grd_hw[1], 3), dtype=np.uint8)
         rot = self.rotation_fraction(idx)
         k, drow, dcol = self.positive(idx)
         with Image.open(self.sat_paths[self.labels[idx, k]]) as im:
-            sat = np.asarray(im.convert("RGB"))
+            sat = np.array(im.convert("RGB"))
         h_raw, w_raw = sat.shape[0], sat.shape[1]
         row = np.round(drow / h_raw * sat_hw[0])
         col = np.round(dcol / w_raw * sat_hw[1])
         # torch.round (half to even) of rotation * width, like datasets.py:121
         roll = int(torch.round(torch.as_tensor(rot) * grd_hw[1]).int().item())
-        return dict(grd_u8=np.ascontiguousarray(grd), sat_u8=np.ascontiguousarray(sat), roll=roll, angle_deg=rot * 360.0,
+        return dict(grd_u8=grd, sat_u8=sat, roll=roll, angle_deg=rot * 360.0,
                     center=(float(col), float(-row)), city=self.city_of[idx], index=int(idx))
 
 
