@@ -159,6 +159,9 @@ FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEV
 FOLD_MIN_PIXELS = 4096
 # train mode: replay the per-step weight re-pack as one hipGraph (see _CVMBase._packed); CCVPE_PACK_GRAPH=0 keeps it eager
 PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
+# eval forward: CCVPE_EVAL_TWO_STREAMS=0 runs the ground encoder on the main stream too (for per-kernel profiles in which no
+# two kernels share the chip; the default overlaps the two encoders)
+EVAL_TWO_STREAMS = __import__("os").environ.get("CCVPE_EVAL_TWO_STREAMS", "1") != "0"
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
@@ -582,7 +585,7 @@ class _CVMBase(nn.Module):
             # CU), so the ground encoder + descriptor heads run on a second HIP stream and overlap with
             # the aerial encoder (fork/join by events: also legal inside hipGraph capture).
             main = torch.cuda.current_stream()
-            side = self._side_stream()
+            side = self._side_stream() if EVAL_TWO_STREAMS else main
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 gfeat, _ = _run_encoder(pk.grd, grd, circular, False, pk.dtype)
