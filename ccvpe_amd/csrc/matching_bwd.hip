@@ -8,8 +8,13 @@
 //     dg[k]  = sum_p sum_i a_i x[c : (c+off_i) mod C == k]  -  g[k]/G^2 * sum_p sum_i ds_i s_i
 // Same mapping as the forward (lane = pixel, 32-channel tiles transposed through LDS, wave-uniform LDS
 // broadcasts of the tables).  dg is a reduction over pixels: every (channel, shift) term is summed across
-// the workgroup's pixels through a small LDS GEMM (G[i][c] = sum_px a_i x_c) and folded into one LDS vector; the workgroup writes
-// one partial row [L+1] and a finishing kernel reduces the rows in fixed order (deterministic).
+// the workgroup's pixels by a small MFMA GEMM out of LDS (G[i][c] = sum_px a_i x_c: M = shifts, N = the 16 channels of the staged
+// tile, K = pixels, one 64-pixel K range per wave) and folded into one LDS vector; the workgroup writes one partial row [L+1] and a
+// finishing kernel reduces the rows in fixed order (deterministic).
+// LDS pitches: every [row][pixel] array has pitch TPB + 4 floats (pitch mod 64 banks = 4): the transposing tile writes, the
+// per-lane column reads AND the MFMA operand reads (lane -> row l%16, pixel l/16: bank 4*row + pixel) are all conflict-free.
+// (Pitch TPB for the a_i table put the 4 shifts a wave reads together on ONE bank: the old per-thread G loop spent most of the
+// kernel in 4-way conflicts — 2.7 ms for the 256 x 256 level of a B = 64 step.)
 #include "common.h"
 
 namespace ccvpe {
@@ -30,16 +35,19 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
                                                         int ldo, float* __restrict__ dx, int lddx,
                                                         float* __restrict__ part, int nblk, int hw, int C, int nslice) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  constexpr int MT = (NPAD + 15) / 16;  // 16-shift MFMA tiles
   const int TPB = blockDim.x;
-  const int XLD = TPB + 1;
+  // (opaque to the optimiser on purpose: with the pitch KNOWN to be a multiple of 4 the compiler rewrote the channel loops below
+  // into wide vector form and spilled — 256 VGPR + 256 AGPR + 2.9 KB of scratch per lane, the pathology `#pragma unroll 1` guards)
+  const int XLD = __builtin_amdgcn_readfirstlane(TPB + 4);
   const int NW = TPB >> 6;
   float* gg = sm;                       // [2C]
   float* ww = gg + 2 * C;               // [2C]
   float* xs = ww + 2 * C;               // [MBK][XLD]
   float* dd = xs + MBK * XLD;           // [MBK][XLD]
-  float* as = dd + MBK * XLD;           // [n_shifts][TPB]  a_i of every pixel of the workgroup
-  float* Gs = as + n_shifts * TPB;      // [n_shifts][MBK]  G[i][c] = sum_px a_i(px) x(px, c) of the current tile
-  float* dgw = Gs + n_shifts * MBK;     // [L+1]
+  float* as = dd + MBK * XLD;           // [n_shifts][XLD]  a_i of every pixel of the workgroup
+  float* Gs = as + n_shifts * XLD;      // [4 waves][16 MT][MBK]  per-wave G[i][c] = sum_px a_i(px) x(px, c) of the current tile
+  float* dgw = Gs + 4 * 16 * MT * MBK;  // [L+1]
   float* red = dgw + (L + 1);           // [4]
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -142,7 +150,7 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
 #pragma unroll
   for (int i = 0; i < NPAD; ++i) {
     bqsum += bq[i];
-    if (i < n_shifts) as[i * TPB + tid] = a[i];
+    if (i < n_shifts) as[i * XLD + tid] = a[i];
   }
   const float xn = sqrtf(tot);
   const float k1 = 1.0f / fmaxf(xn, 1e-12f);
@@ -204,28 +212,48 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
       }
       dd[cc * XLD + tid] = acc;
     }
-    // dg: G[i][c] = sum over the workgroup's pixels of a_i(px) * x(px, c) — every thread owns a few (i, c) entries and
-    // walks the pixels in LDS (independent FMAs; a first version summed every (c, i) term across the wave with a
-    // butterfly and spent 5 ms per launch on dependent ds_bpermute chains)
-    for (int e = tid; e < n_shifts * ck; e += TPB) {
-      const int i = e / ck, cc = e - i * ck;
-      const float* ap = as + i * TPB;
-      const float* xp = xs + cc * XLD;
-      float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f;
-      for (int px = 0; px < TPB; px += 4) {
-        g0 = fmaf(ap[px], xp[px], g0);
-        g1 = fmaf(ap[px + 1], xp[px + 1], g1);
-        g2 = fmaf(ap[px + 2], xp[px + 2], g2);
-        g3 = fmaf(ap[px + 3], xp[px + 3], g3);
+    // dg: G[i][c] = sum over the workgroup's pixels of a_i(px) * x(px, c): v_mfma_f32_16x16x4_f32 with A[m = shift][k = pixel] from
+    // the a_i table and B[k = pixel][n = channel] from the transposed x tile (rows >= ck of the tile and pixels >= hw are zeros,
+    // a_i = 0 for invalid pixels); wave wv owns pixels [64 wv, 64 wv + 64) and leaves its partial in Gs[wv].  (The first version
+    // summed every (c, i) term across the wave with a butterfly: 5 ms per launch on dependent ds_bpermute chains; the second
+    // gave every thread a few (i, c) entries and walked the pixels in LDS: two LDS reads per FMA, 4-way conflicts.)
+    {
+      const int fm = lane & 15, fk = lane >> 4;
+      f32x4 gacc[MT][2];                 // even / odd K steps: two independent accumulation chains per tile
+#pragma unroll
+      for (int t = 0; t < MT; ++t) gacc[t][0] = gacc[t][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const float* xrow = xs + fm * XLD + wv * 64 + fk;
+      const float* arow[MT];
+      bool aok[MT];
+#pragma unroll
+      for (int t = 0; t < MT; ++t) {
+        const int i = 16 * t + fm;
+        aok[t] = i < n_shifts;
+        arow[t] = as + (aok[t] ? i : 0) * XLD + wv * 64 + fk;
       }
-      Gs[i * MBK + cc] = (g0 + g1) + (g2 + g3);
+#pragma unroll 2
+      for (int ks = 0; ks < 16; ks += 2) {
+        const float bv0 = xrow[4 * ks], bv1 = xrow[4 * ks + 4];
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+          const float a0 = arow[t][4 * ks], a1 = arow[t][4 * ks + 4];
+          gacc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok[t] ? a0 : 0.f, bv0, gacc[t][0], 0, 0, 0);
+          gacc[t][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(aok[t] ? a1 : 0.f, bv1, gacc[t][1], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) Gs[((wv * MT + t) * 16 + 4 * fk + j) * MBK + fm] = gacc[t][0][j] + gacc[t][1][j];
     }
     __syncthreads();
     if (tid < ck) {                    // one wave, lock-step: for a fixed shift the ck channels hit distinct dg entries
       for (int i = 0; i < n_shifts; ++i) {
         const int k = c0 + tid + mo.off[i];
         const int kk = k >= C ? k - C : k;
-        if (kk < L) dgw[kk] += Gs[i * MBK + tid];
+        float gsum = Gs[i * MBK + tid];
+        for (int w = 1; w < NW; ++w) gsum += Gs[(w * MT * 16 + i) * MBK + tid];
+        if (kk < L) dgw[kk] += gsum;
       }
     }
     for (int idx = tid; idx < TPB * F4; idx += TPB) {
@@ -305,7 +333,8 @@ static int launch_match_bwd(const float* x, int ldx, const float* g, int ldg, in
   const int tpb = match_bwd_tpb(hw);
   const int nblk = (hw + tpb - 1) / tpb;
   const int nslice = match_bwd_slices(hw, B, C);
-  const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 1) + (size_t)n_shifts * (tpb + MBK) + (L + 1) + 4);
+  const size_t smem = sizeof(float) * ((size_t)4 * C + (size_t)2 * MBK * (tpb + 4) + (size_t)n_shifts * (tpb + 4) +
+                                       (size_t)4 * 16 * ((NPAD + 15) / 16) * MBK + (L + 1) + 4);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level_bwd: C=%d needs %zu B of LDS", C, smem);
   auto kern = match_bwd_kernel<NPAD>;
   if (smem > 64 * 1024) {

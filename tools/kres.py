@@ -11,6 +11,8 @@ filt = [a for a in sys.argv[2:] if not a.startswith("-")]
 defs = [a for a in sys.argv[2:] if a.startswith("-")]
 cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Rpass-analysis=kernel-resource-usage",
        "-c", os.path.basename(src), "-o", "/tmp/kres_%d.o" % os.getpid()] + defs
+if os.path.basename(src).startswith("matching"):       # same per-file flag as csrc/Makefile ($(NOSLP))
+    cmd.insert(1, "-fno-slp-vectorize")
 res = subprocess.run(cmd, cwd=os.path.dirname(os.path.abspath(src)), capture_output=True, text=True)
 cur = None
 rows = []
