@@ -153,7 +153,7 @@ struct IgemmParams {
   int ablate;        // diagnostics builds only (-DCCVPE_ABLATE): read nowhere in the product build
 };
 
-constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad)
+constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad); see DESIGN section 4 "LDS bank conflicts" for the measured pitch-24 variant
 
 // XCD-aware tile order: consecutive workgroup ids round-robin over the 8 XCDs, so give each XCD a
 // contiguous run of tiles (n fastest): the N-tiles that re-read one A panel, and spatially

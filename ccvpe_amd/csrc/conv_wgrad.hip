@@ -35,6 +35,12 @@ struct WgradParams {
 
 constexpr int WG_T = 64;    // tile: 64 output channels x 64 input channels
 constexpr int WG_BP = 32;   // pixels per stage
+// Row pitch of a staged [pixel][column] panel.  Square tiles read fragments as 32 consecutive floats of one row per half-wave
+// (conflict-free for any pitch).  The 16x16x4 tiles read (column = lane & 15, pixel = lane >> 4) with ds_read_b32, whose bank is
+// (address / 4) mod 32 and whose lane groups are the two 32-lane halves: two pixel rows share a group, so the pitch must be
+// 16 mod 32 for their 16-float runs to land on different banks.  (Pitch width + 4 — 68, 84, ... — made every fragment read
+// a 2-way conflict: SQ_LDS_BANK_CONFLICT = 40 % of the LDS-active cycles with the LDS arrays busy 46-64 % of these kernels.)
+constexpr int wgrad_pitch(int width, bool square) { return square ? width + 4 : (width + 15) / 32 * 32 + 16; }
 
 // TN x TC = output channels x columns per tile.  TN = 16 / 32 for the decoder's last levels (N = 16..32 and millions of
 // pixels: a 64-row tile would spend 4-16x the MFMA work on padding); 128 x 128 for the wide layers, where a 64 x 64 tile
@@ -51,7 +57,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   constexpr int NJ = (SQ ? TC / 2 : TC / 4) / 16;     // 16-col MFMA tiles per wave along columns
   constexpr int YP = (TN + 31) / 32;                  // float4 pieces per thread per stage (dY): columns (tid&7)*4 + 32*q
   constexpr int XP = TC / 32;                         // float4 pieces per thread per stage (X)
-  constexpr int YLD = TN + 4, XLD = TC + 4;
+  constexpr int YLD = wgrad_pitch(TN, SQ), XLD = wgrad_pitch(TC, SQ);
   extern __shared__ __attribute__((aligned(16))) float wsm[];
   float* Ys = wsm;                                    // [2][WG_BP][YLD]   dY [pixel][n]
   float* Xs = wsm + 2 * WG_BP * YLD;                  // [2][WG_BP][XLD]   X  [pixel][col]
@@ -485,7 +491,8 @@ static int conv_wgrad_impl(const float* src0, int c0, int ld0, const float* src1
     return fail(CCVPE_EINVAL, "conv_wgrad: the gated form is for 1x1 single-source convs with fewer than 128 output channels");
   hipStream_t st = (hipStream_t)stream;
   const long blocks = (long)p.tiles_n * p.tiles_c * p.S;
-  const size_t lds = sizeof(float) * 2 * WG_BP * ((size_t)(tn + 4) + (tcw + 4));
+  const bool sq = tn == 64 || big;
+  const size_t lds = sizeof(float) * 2 * WG_BP * ((size_t)wgrad_pitch(tn, sq) + wgrad_pitch(tcw, sq));
   if (big) {
     static bool attr_set = false;
     if (!attr_set) {
