@@ -51,6 +51,8 @@ PROTOTYPES = {
     "ccvpe_last_error": (ctypes.c_char_p, []),
     "ccvpe_abi_version": (c_int, []),
     "ccvpe_multi_copy_f32": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p]),
+    "ccvpe_gather_repack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "ccvpe_gather_repack_chunk": (c_int, []),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),

@@ -206,7 +206,37 @@ __global__ __launch_bounds__(256) void multi_copy_kernel(const MultiCopyArgs a) 
   const int n = a.n[t];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += MC_CHUNKS * 256) d[i] = s[i];
 }
+
+// One-launch weight re-pack (ccvpe_amd/repack.py).  Every packed weight of the training step is a pure re-layout of live
+// parameters (permutes, flips, channel re-orders, zero padding, concatenations): element j of a packed tensor is either 0 or
+// element idx[j] - 1 of ONE source tensor.  A chunk is <= RP_CHUNK consecutive packed elements that read the same source.
+constexpr int RP_CHUNK = 4096;
+__global__ __launch_bounds__(256) void gather_repack_kernel(float* const* __restrict__ dsts, const float* const* __restrict__ srcs,
+                                                            const long long* __restrict__ idx_off, const int* __restrict__ counts,
+                                                            const int* __restrict__ idx) {
+  const int c = blockIdx.x;
+  float* __restrict__ d = dsts[c];
+  const float* __restrict__ s = srcs[c];
+  const int* __restrict__ ix = idx + idx_off[c];
+  const int n = counts[c];
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int k = ix[i];
+    d[i] = k > 0 ? s[k - 1] : 0.f;
+  }
+}
 }  // namespace ccvpe
+
+extern "C" int ccvpe_gather_repack_f32(void* const* dsts, const void* const* srcs, const long long* idx_off, const int* counts,
+                                       const int* idx, int n_chunks, void* stream) {
+  if (n_chunks < 0 || (n_chunks > 0 && (!dsts || !srcs || !idx_off || !counts || !idx)))
+    return fail(CCVPE_EINVAL, "gather_repack: bad arguments");
+  if (n_chunks == 0) return CCVPE_OK;
+  hipLaunchKernelGGL(ccvpe::gather_repack_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream,
+                     reinterpret_cast<float* const*>(dsts), reinterpret_cast<const float* const*>(srcs), idx_off, counts, idx);
+  return check_launch("gather_repack_kernel");
+}
+
+extern "C" int ccvpe_gather_repack_chunk(void) { return ccvpe::RP_CHUNK; }
 
 extern "C" int ccvpe_multi_copy_f32(const void* const* srcs, void* const* dsts, const int* counts, int n, void* stream) {
   if (n < 0 || (n > 0 && (!srcs || !dsts || !counts))) return fail(CCVPE_EINVAL, "multi_copy: bad arguments");

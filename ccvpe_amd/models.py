@@ -159,6 +159,8 @@ FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEV
 FOLD_MIN_PIXELS = 4096
 # train mode: replay the per-step weight re-pack as one hipGraph (see _CVMBase._packed); CCVPE_PACK_GRAPH=0 keeps it eager
 PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
+# train mode, fp32: the per-step re-pack as ONE gather launch (ccvpe_amd/repack.py); CCVPE_PACK_GATHER=0 keeps the graph replay
+PACK_GATHER = __import__("os").environ.get("CCVPE_PACK_GATHER", "1") != "0"
 # eval forward: CCVPE_EVAL_TWO_STREAMS=0 runs the ground encoder on the main stream too (for per-kernel profiles in which no
 # two kernels share the chip; the default overlaps the two encoders)
 EVAL_TWO_STREAMS = __import__("os").environ.get("CCVPE_EVAL_TWO_STREAMS", "1") != "0"
@@ -468,12 +470,27 @@ class _CVMBase(nn.Module):
         n_tail = MODEL_SPECS[self.kind]["n_rot"]
         dtype = torch.float32 if self.precision == "fp32" else torch.bfloat16
 
-        def pack():
+        def pack(src=sd):
             with torch.no_grad():
                 # train mode runs the decoders unfused (ccvpe_amd/train.py): skip the fp64 fold of deconv into conv
-                return _pack_model(sd, self.kind, n_tail, dtype, fold=not self.training, f32_tail=self.fp32_tail_levels)
+                return _pack_model(src, self.kind, n_tail, dtype, fold=not self.training, f32_tail=self.fp32_tail_levels)
 
-        if self.training and PACK_GRAPH:
+        if self.training and PACK_GATHER and dtype == torch.float32 and not getattr(self, "_pack_plan_failed", False):
+            # The train-mode pack is pure data movement, so it is ONE gather launch per step (repack.py: the plan is derived by
+            # running the pack code on index-carrying tensors and verified bit for bit against an eager pack when it is built).
+            from . import repack
+            where = tuple(t.data_ptr() for t in list(self.parameters()) + list(self.buffers()))
+            gp = getattr(self, "_pack_plan", None)
+            if gp is not None and gp[0] == where:
+                self._pack_cache = gp[1].run()
+            else:
+                plan = repack.build(sd, pack)
+                if plan is None:
+                    self._pack_plan, self._pack_plan_failed = None, True
+                    return self._packed()
+                self._pack_plan = (where, plan)
+                self._pack_cache = plan.pk
+        elif self.training and PACK_GRAPH:
             # Every optimizer step changes every weight, so a training step re-packs all of them: ~280 tiny torch launches
             # (permute / pad / copy), 8.8 ms of wall time of which 1.9 ms is kernel time.  The launches read the live
             # parameters in place and never change shape, so from the second pack on (the first one runs eagerly and

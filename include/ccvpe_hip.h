@@ -215,6 +215,13 @@ int ccvpe_softmax_rows_f32(const float* logits, float* out, int rows, int n, voi
 /* n device-to-device copies of fp32 vectors (counts[i] floats from srcs[i] to dsts[i]) in ceil(n / 96) launches; the three
  * arrays are HOST arrays, read before the call returns.  Gradients -> slots of the flat all-reduce arena (harness.py). */
 int ccvpe_multi_copy_f32(const void* const* srcs, void* const* dsts, const int* counts, int n, void* stream);
+/* Train-mode weight re-pack in ONE launch (train_VIGOR.py:146-150: optimizer.step() rewrites every weight, so every step
+ * re-lays all of them out for the forward and backward GEMMs).  n_chunks chunks; chunk c writes counts[c] (<=
+ * ccvpe_gather_repack_chunk()) floats to dsts[c]: element i = idx[idx_off[c] + i] > 0 ? srcs[c][idx[idx_off[c] + i] - 1] : 0.
+ * All five arrays are DEVICE arrays (built once per parameter placement by ccvpe_amd/repack.py). */
+int ccvpe_gather_repack_f32(void* const* dsts, const void* const* srcs, const long long* idx_off, const int* counts,
+                            const int* idx, int n_chunks, void* stream);
+int ccvpe_gather_repack_chunk(void);
 int ccvpe_cast_bf16_f32(const void* src, float* dst, long n_elems, void* stream);
 
 /* -------------------------------------------------------------------------------------------

@@ -1,0 +1,31 @@
+"""The one-launch train-mode re-pack on the device: after the weights change, the gathered pack equals a fresh eager pack bit for
+bit (forward AND backward layouts), and the model really uses the gather path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gather_repack_tracks_weight_updates_bit_for_bit():
+    from ccvpe_amd import models, repack
+    torch.manual_seed(11)
+    net = models.CVM_VIGOR("cuda", True).to("cuda:0").train()
+    pk0 = net._packed()
+    assert getattr(net, "_pack_plan", None) is not None and not getattr(net, "_pack_plan_failed", False)
+    plan = net._pack_plan[1]
+    assert plan.n_chunks > 10000 and plan.n_elems > 100e6 and plan.n_alias > 0
+    n_tail = models.MODEL_SPECS[net.kind]["n_rot"]
+    for step in range(2):
+        with torch.no_grad():
+            for p in net.parameters():
+                p.add_(0.01 * torch.randn_like(p))             # in place: bumps the version counter like an optimizer step
+        pk = net._packed()
+        assert pk is pk0                                       # same tensors, re-derived in place
+        sd = {k: v.detach() for k, v in net.state_dict().items()}
+        with torch.no_grad():
+            ref = models._pack_model(sd, net.kind, n_tail, torch.float32, fold=False)
+        leaves, want = list(repack.walk(pk)), list(repack.walk(ref))
+        assert [p for p, _ in leaves] == [p for p, _ in want]
+        for (path, a), (_, b) in zip(leaves, want):
+            assert torch.equal(a, b), path
+    torch.cuda.synchronize()
