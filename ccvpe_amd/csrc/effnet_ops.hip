@@ -359,13 +359,46 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
                                                       float* __restrict__ gate, int C, int Cs) {
-  extern __shared__ float sm[];  // mean[C] | z[Cs] | red[256]
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[C^4] | z[Cs^4] | red[256][4]
   float* mean = sm;
-  float* z = sm + C;
-  float* red = z + Cs;
+  float* z = sm + ((C + 3) & ~3);
+  float* red = z + ((Cs + 3) & ~3);       // 16-byte aligned: the row-lane sums are float4
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
-  // partial rows are summed by R thread-rows in parallel (fixed assignment => deterministic)
+  // The nblk partial rows are summed by R row lanes in parallel (fixed assignment => deterministic).  A thread owns FOUR
+  // channels (one 16-byte load per row) when C % 4 == 0, so a narrow early block (C = 32 ... 240 with 50-128 partial rows)
+  // has 256 / (C/4) = 4 ... 32 row lanes and each walks a few rows with four loads in flight; with one channel per thread
+  // C = 96 left two row lanes walking 64 rows each — ~16 dependent L2 round trips, 50 us for a [64, 128, 96] tensor.
+  if ((C & 3) == 0 && nblk > 1) {
+    const int C4 = C >> 2;
+    const int cw = C4 < 256 ? C4 : 256;
+    const int R = 256 / cw;
+    f32x4* red4 = reinterpret_cast<f32x4*>(red);
+    for (int c0 = 0; c0 < C4; c0 += cw) {
+      const int cl = tid % cw, rr = tid / cw;
+      const int c4 = c0 + cl;
+      f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+      if (rr < R && c4 < C4) {
+        const f32x4* p = reinterpret_cast<const f32x4*>(part + (size_t)b * nblk * C) + c4;
+        int q = rr;
+        for (; q + 3 * R < nblk; q += 4 * R) {     // 4 independent loads in flight
+          s0 += p[(size_t)q * C4];
+          s1 += p[(size_t)(q + R) * C4];
+          s2 += p[(size_t)(q + 2 * R) * C4];
+          s3 += p[(size_t)(q + 3 * R) * C4];
+        }
+        for (; q < nblk; q += R) s0 += p[(size_t)q * C4];
+      }
+      red4[tid] = (s0 + s1) + (s2 + s3);
+      __syncthreads();
+      if (rr == 0 && c4 < C4) {
+        f32x4 t = red4[cl];
+        for (int j = 1; j < R; ++j) t += red4[j * cw + cl];
+        *reinterpret_cast<f32x4*>(mean + 4 * c4) = t * inv_hw;
+      }
+      __syncthreads();
+    }
+  } else {
   const int cw = C < 256 ? C : 256;
   const int R = 256 / cw;
   for (int c0 = 0; c0 < C; c0 += cw) {
@@ -391,6 +424,7 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
       mean[c] = t * inv_hw;
     }
     __syncthreads();
+  }
   }
   const int lane = tid & 63, wave = tid >> 6;
   // FC1: 4 outputs per pass and wave (independent accumulators: the loads of 4 weight rows are in
@@ -527,7 +561,7 @@ extern "C" int ccvpe_dwconv_bf16(const void* x, const float* w, const float* sca
 extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, const float* w1, const float* b1,
                                  const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
   if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
-  const size_t smem = (size_t)(C + Cs + 256) * sizeof(float);
+  const size_t smem = (size_t)(((C + 3) & ~3) + ((Cs + 3) & ~3) + 1024) * sizeof(float);
   hipLaunchKernelGGL(se_gate_kernel, dim3((C + SE_SLICE - 1) / SE_SLICE, B), dim3(256), smem, (hipStream_t)stream, part,
                      nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs);
   return check_launch("se_gate_kernel");

@@ -725,6 +725,67 @@ extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw
 // ---------------------------------------------------------------------------------------------
 namespace ccvpe {
 
+// out[c] = scale * sum_k rows[k][c] for one sample's [nrows][C] partial rows (C % 4 == 0): a thread owns four channels, the
+// 256 / (C/4) row lanes walk the rows with four 16-byte loads in flight and are combined through LDS in lane order (fixed
+// assignment: deterministic).  One channel per thread walked all rows serially: ~16 dependent L2 round trips for the early
+// MBConv blocks (50-128 partial rows), most of this kernel's 54 us.
+__device__ __forceinline__ void se_sum_rows(const float* __restrict__ rows, int nrows, int C, float scale, float* __restrict__ out,
+                                            f32x4* __restrict__ red4, int tid) {
+  const int C4 = C >> 2;
+  const int cw = C4 < 256 ? C4 : 256;
+  const int R = 256 / cw;
+  for (int c0 = 0; c0 < C4; c0 += cw) {
+    const int cl = tid % cw, rr = tid / cw;
+    const int c4 = c0 + cl;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (rr < R && c4 < C4) {
+      const f32x4* p = reinterpret_cast<const f32x4*>(rows) + c4;
+      int q = rr;
+      for (; q + 3 * R < nrows; q += 4 * R) {
+        s0 += p[(size_t)q * C4];
+        s1 += p[(size_t)(q + R) * C4];
+        s2 += p[(size_t)(q + 2 * R) * C4];
+        s3 += p[(size_t)(q + 3 * R) * C4];
+      }
+      for (; q < nrows; q += R) s0 += p[(size_t)q * C4];
+    }
+    red4[tid] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rr == 0 && c4 < C4) {
+      f32x4 t = red4[cl];
+      for (int j = 1; j < R; ++j) t += red4[j * cw + cl];
+      *reinterpret_cast<f32x4*>(out + 4 * c4) = t * scale;
+    }
+    __syncthreads();
+  }
+}
+
+// y[s] = sum_c W[s][c] v[c] for s < Cs (W row-major [Cs][C], v in LDS): four rows per pass and wave with independent accumulators
+// (their loads are in flight together), lanes stride over c.  The result of row s is handed to `fin(s, sum)` on lane 0.
+template <typename Fin>
+__device__ __forceinline__ void se_matvec_rows(const float* __restrict__ W, const float* __restrict__ v, int C, int Cs, int lane,
+                                               int wv, Fin fin) {
+  for (int j0 = wv * 4; j0 < Cs; j0 += 16) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    const int j1 = min(j0 + 1, Cs - 1), j2 = min(j0 + 2, Cs - 1), j3 = min(j0 + 3, Cs - 1);
+#pragma unroll 6
+    for (int c = lane; c < C; c += 64) {
+      const float m = v[c];
+      s0 = fmaf(W[(size_t)j0 * C + c], m, s0);
+      s1 = fmaf(W[(size_t)j1 * C + c], m, s1);
+      s2 = fmaf(W[(size_t)j2 * C + c], m, s2);
+      s3 = fmaf(W[(size_t)j3 * C + c], m, s3);
+    }
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    if (lane == 0) {
+      fin(j0, s0);
+      if (j0 + 1 < Cs) fin(j0 + 1, s1);
+      if (j0 + 2 < Cs) fin(j0 + 2, s2);
+      if (j0 + 3 < Cs) fin(j0 + 3, s3);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restrict__ se_partial, int nblk, float inv_hw,
                                                             const float* __restrict__ dg_partial, int ndg,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
@@ -732,57 +793,42 @@ __global__ __launch_bounds__(256) void se_bwd_sample_kernel(const float* __restr
                                                             float* __restrict__ dz2_o, float* __restrict__ dz1_o,
                                                             float* __restrict__ a_o, float* __restrict__ m_o,
                                                             float* __restrict__ dmean_o, int C, int Cs) {
-  extern __shared__ float sm[];
-  float* m = sm;            // [C]
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int Cs4 = (Cs + 3) & ~3;
+  float* m = sm;            // [C]      (C % 4 == 0: checked by the launcher)
   float* dz2 = m + C;       // [C]
-  float* z1 = dz2 + C;      // [Cs]
-  float* a = z1 + Cs;       // [Cs]
-  float* dz1 = a + Cs;      // [Cs]
+  float* dgs = dz2 + C;     // [C]      sum of the dgate partial rows
+  float* z1 = dgs + C;      // [Cs^4]
+  float* a = z1 + Cs4;      // [Cs^4]
+  float* dz1 = a + Cs4;     // [Cs^4]
+  f32x4* red4 = reinterpret_cast<f32x4*>(dz1 + Cs4);   // [256]
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  for (int c = tid; c < C; c += 256) {
-    float s = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < nblk; ++k) s += se_partial[((size_t)b * nblk + k) * C + c];
-    m[c] = s * inv_hw;
-    m_o[(size_t)b * C + c] = s * inv_hw;
-  }
-  __syncthreads();
-  for (int s = wv; s < Cs; s += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w1[(size_t)s * C + c], m[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float z = acc + b1[s];
-      z1[s] = z;
-      a[s] = swishf(z);
-      a_o[(size_t)b * Cs + s] = a[s];
-    }
-  }
+  se_sum_rows(se_partial + (size_t)b * nblk * C, nblk, C, inv_hw, m, red4, tid);
+  se_sum_rows(dg_partial + (size_t)b * ndg * C, ndg, C, 1.0f, dgs, red4, tid);
+  for (int c = tid; c < C; c += 256) m_o[(size_t)b * C + c] = m[c];
+  se_matvec_rows(w1, m, C, Cs, lane, wv, [&](int s, float acc) {
+    const float z = acc + b1[s];
+    z1[s] = z;
+    a[s] = swishf(z);
+    a_o[(size_t)b * Cs + s] = a[s];
+  });
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float z = b2[c];
 #pragma unroll 8
     for (int s = 0; s < Cs; ++s) z = fmaf(w2t[(size_t)s * C + c], a[s], z);
     const float g = sigmoidf(z);
-    float dg = 0.f;
-#pragma unroll 8
-    for (int k = 0; k < ndg; ++k) dg += dg_partial[((size_t)b * ndg + k) * C + c];
-    const float d = dg * g * (1.0f - g);
+    const float d = dgs[c] * g * (1.0f - g);
     dz2[c] = d;
     dz2_o[(size_t)b * C + c] = d;
   }
   __syncthreads();
-  for (int s = wv; s < Cs; s += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc = fmaf(w2t[(size_t)s * C + c], dz2[c], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      const float z = z1[s], sg = sigmoidf(z);
-      const float d = acc * sg * (1.0f + z * (1.0f - sg));
-      dz1[s] = d;
-      dz1_o[(size_t)b * Cs + s] = d;
-    }
-  }
+  se_matvec_rows(w2t, dz2, C, Cs, lane, wv, [&](int s, float acc) {
+    const float z = z1[s], sg = sigmoidf(z);
+    const float d = acc * sg * (1.0f + z * (1.0f - sg));
+    dz1[s] = d;
+    dz1_o[(size_t)b * Cs + s] = d;
+  });
   __syncthreads();
   for (int c = tid; c < C; c += 256) {
     float dm = 0.f;
@@ -842,12 +888,14 @@ extern "C" int ccvpe_se_bwd_f32(const float* se_partial, int nblk, float inv_hw,
                                 float* dw1, float* db1, float* dw2, float* db2, float* scratch, int batch, int channels,
                                 int squeezed, void* stream) {
   if (batch <= 0 || channels <= 0 || squeezed <= 0 || nblk <= 0 || ndg <= 0) return fail(CCVPE_EINVAL, "se_bwd: bad shape");
+  if (channels % 4 || !aligned16(se_partial) || !aligned16(dgate_partial))
+    return fail(CCVPE_EINVAL, "se_bwd: channels %% 4 == 0 and 16-byte aligned partial rows required");
   hipStream_t st = (hipStream_t)stream;
   float* dz2 = scratch;                              // [B][C]
   float* m = dz2 + (size_t)batch * channels;         // [B][C]
   float* dz1 = m + (size_t)batch * channels;         // [B][Cs]
   float* a = dz1 + (size_t)batch * squeezed;         // [B][Cs]
-  const size_t lds = (size_t)(2 * channels + 3 * squeezed) * sizeof(float);
+  const size_t lds = (size_t)(3 * channels + 3 * ((squeezed + 3) & ~3) + 1024) * sizeof(float);
   hipLaunchKernelGGL(se_bwd_sample_kernel, dim3(batch), dim3(256), lds, st, se_partial, nblk, inv_hw, dgate_partial, ndg, w1,
                      b1, w2t, b2, dz2, dz1, a, m, dmean, channels, squeezed);
   hipLaunchKernelGGL(se_bwd_weights_kernel, dim3((channels * squeezed + 255) / 256), dim3(256), 0, st, dz2, dz1, a, m, dw1,
