@@ -1,4 +1,4 @@
-"""VIGOR input side of the path: dataset indexing, JPEG decoding, iteration — feeding the
+"""VIGOR and KITTI input side of the path: dataset indexing, image decoding, iteration — feeding the
 device pipeline (ccvpe_amd/preprocess.py: PIL-exact resize + normalise + panorama roll + FoV crop; ccvpe_amd/targets.py:
 ground truth from three scalars per sample).
 
@@ -13,6 +13,15 @@ uint8 images (3-6 MB per pair) plus three scalars per sample to the device, wher
     pairs = VIGORPairs(root, split="samearea", train=False, ori_noise=180, random_orientation="samearea_orientation_test.npy")
     for batch in DeviceBatches(pairs, batch_size=64, device="cuda", rank=rank, world=world):
         out = net(batch.grd, batch.sat)                     # batch.gt, batch.gt_flat, batch.gt_ori, batch.labels for training
+
+KITTI (datasets.py:354-640, train_KITTI.py:46-100): `KITTIPairs(root, file, ...)` reads the split file, the OXTS heading and
+the two images of a sample and performs the aerial image's geometric alignment — rotate to the vehicle heading, shift to the
+camera, the random (training) or listed (test files) shift and rotation, centre crop — with the same PIL calls as the reference
+(PIL's affine resampling is host work either way; the result is the 512 x 512 uint8 crop).  Resize + normalise of both images
+and the 1 + 16 + 2 channel ground truth then run on the device exactly as for VIGOR:
+
+    pairs = KITTIPairs(root, "train_files.txt", shift_range_lat=20, shift_range_lon=20, rotation_range=10)
+    for batch in DeviceBatches(pairs, 64, grd_hw=(256, 1024), n_bins=16, rank=rank, world=world): ...
 
 Sharding: DeviceBatches gives rank r the contiguous shard harness.shard_indices(len, world, r) of the index list (after the
 optional seeded shuffle, identical on every rank): no sample is seen twice, no collective is needed.
@@ -130,6 +139,94 @@ class VIGORPairs(object):
                     center=(float(col), float(-row)), city=self.city_of[idx], index=int(idx))
 
 
+# ---- KITTI (datasets.py:354-372: constants of the reference's loader) ---------------------------------------------------
+KITTI_LAT, KITTI_ZOOM = 49.015, 18
+KITTI_CAMERA_SHIFT = (1.08, 0.26)          # metres: GPS antenna -> left colour camera (datasets.py:366)
+KITTI_CROP = 512
+
+
+def kitti_meter_per_pixel(lat=KITTI_LAT, zoom=KITTI_ZOOM, scale=1.0):
+    """Ground resolution of the aerial maps (datasets.py:368-372: web-mercator resolution at `lat`, maps fetched at scale 2)."""
+    return 156543.03392 * np.cos(lat * np.pi / 180.0) / (2 ** zoom) / 2.0 / scale
+
+
+class KITTIPairs(object):
+    """Host-side index of a KITTI split file + per-sample decode and aerial alignment (datasets.py:374-503 `SatGrdDataset`,
+    :506-640 `SatGrdDatasetTest`).  A line of a TRAINING file is `<day>/<drive>/<frame>.png`; a line of a TEST file carries the
+    sample's fixed perturbation: `<name> <shift_x> <shift_y> <theta>` (test=True).  Training perturbations are three uniform
+    draws in [-1, 1) per sample — from numpy's global generator when rng is None (so `np.random.seed(s)` reproduces the
+    reference's sequence sample by sample), else from `rng` (a numpy Generator / RandomState; draws are serialised by a lock)."""
+
+    def __init__(self, root, file, shift_range_lat=20.0, shift_range_lon=20.0, rotation_range=10.0, test=False, rng=None):
+        self.root, self.test = root, bool(test)
+        self.meter_per_pixel = kitti_meter_per_pixel()
+        self.shift_px_lat = shift_range_lat / self.meter_per_pixel
+        self.shift_px_lon = shift_range_lon / self.meter_per_pixel
+        self.rotation_range = float(rotation_range)
+        with open(file) as f:
+            self.lines = [ln[:-1] for ln in f.readlines()]                    # datasets.py:399 (drops the line's last character)
+        self._rng, self._rng_lock = rng, threading.Lock()
+
+    def __len__(self):
+        return len(self.lines)
+
+    def paths(self, name):
+        """(aerial map, OXTS record, left colour image) of `<day>/<drive>/<frame>.png` (datasets.py:410-435)."""
+        drive, frame = name[:38], name[38:]
+        base = os.path.join(self.root, "raw_data", drive)
+        return (os.path.join(self.root, "satmap", name),
+                os.path.join(base, "oxts/data", frame.lower().replace(".png", ".txt")),
+                os.path.join(base, "image_02/data", frame.lower()))
+
+    def perturbation(self, idx):
+        """(shift_x, shift_y) in units of the shift range (right / up positive, along / across the heading) and the rotation in
+        degrees (counter-clockwise; 0 = the vehicle heads east in the aerial image)."""
+        if self.test:
+            _, sx, sy, th = self.lines[idx].split(" ")
+            return -float(sx), -float(sy), float(th) * self.rotation_range          # datasets.py:585-595
+        with self._rng_lock:
+            u = np.random.uniform if self._rng is None else self._rng.uniform
+            sx, sy, r = u(-1, 1), u(-1, 1), u(-1, 1)                                # datasets.py:452-453,463 (this order)
+        return float(sx), float(sy), float(r) * self.rotation_range
+
+    def sample(self, idx, sat_hw=(512, 512), grd_hw=(256, 1024)):
+        """Decode + align sample idx.  Returns the dict DeviceBatches consumes: grd_u8 (the left camera image as decoded),
+        sat_u8 (the aligned, perturbed 512 x 512 aerial crop), roll = 0, angle_deg (orientation ground truth in [0, 360]),
+        center = (x_offset, y_offset) of the Gaussian (datasets.py:475-476), city = the drive, index."""
+        from PIL import Image
+        name = self.lines[idx].split(" ")[0] if self.test else self.lines[idx]
+        sat_path, oxts_path, grd_path = self.paths(name)
+        with Image.open(sat_path, "r") as im:
+            sat = im.convert("RGB")
+        with open(oxts_path) as f:
+            heading = float(f.readline().split(" ")[5])
+        with Image.open(grd_path, "r") as im:
+            grd = np.array(im.convert("RGB"))
+        sx, sy, ori = self.perturbation(idx)
+        mpp = self.meter_per_pixel
+        sat = sat.rotate(-heading / np.pi * 180)                                    # east = the vehicle heading
+        sat = sat.transform(sat.size, Image.AFFINE, (1, 0, KITTI_CAMERA_SHIFT[0] / mpp, 0, 1, KITTI_CAMERA_SHIFT[1] / mpp),
+                            resample=Image.BILINEAR)
+        sat = sat.transform(sat.size, Image.AFFINE, (1, 0, sx * self.shift_px_lon, 0, 1, -sy * self.shift_px_lat),
+                            resample=Image.BILINEAR)
+        sat = sat.rotate(ori)
+        w, h = sat.size
+        if w < KITTI_CROP or h < KITTI_CROP:
+            raise ValueError("%s: aerial map %dx%d is smaller than the %d crop" % (sat_path, w, h, KITTI_CROP))
+        left, top = int(round((w - KITTI_CROP) / 2.0)), int(round((h - KITTI_CROP) / 2.0))     # torchvision center_crop
+        sat = np.array(sat.crop((left, top, left + KITTI_CROP, top + KITTI_CROP)))
+        c, s_ = np.cos(ori / 180 * np.pi), np.sin(ori / 180 * np.pi)
+        x_off = int(sx * self.shift_px_lon * c - sy * self.shift_px_lat * s_)       # int(): truncation, as the reference
+        y_off = int(-sy * self.shift_px_lat * c - sx * self.shift_px_lon * s_)
+        angle = 90 - ori
+        if angle < 0:
+            angle += 360
+        elif angle > 360:
+            angle -= 360
+        return dict(grd_u8=grd, sat_u8=sat, roll=0, angle_deg=float(angle), center=(float(x_off), float(y_off)),
+                    city=name[:38], index=int(idx))
+
+
 class Batch(object):
     """One device batch: grd [B,3,h,w_fov], sat [B,3,H,W] (normalised fp32), angle_deg [B], center [B,2], cities, indices and —
     with targets — gt [B,1,H,W], gt_flat [B,H*W], gt_ori [B,2,H,W], labels (six max-pooled orientation-binned maps)."""
@@ -137,7 +234,7 @@ class Batch(object):
 
 
 class DeviceBatches(object):
-    """Iterates a VIGORPairs index in device batches.  Decoding runs `workers` samples ahead on a thread pool; resize,
+    """Iterates a VIGORPairs / KITTIPairs index in device batches (KITTI: grd_hw=(256, 1024), n_bins=16).  Decoding runs `workers` samples ahead on a thread pool; resize,
     normalisation, roll, FoV crop and the ground truth are kernels on `device` (no CPU fallback: preprocess raises without
     the HIP library).  fov < 360 keeps the first fov/360 of the rolled panorama's columns (train_VIGOR.py:177-178)."""
 

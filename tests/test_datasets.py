@@ -159,3 +159,92 @@ def test_device_batches_shard_without_overlap(tmp_path):
     assert sorted(allidx.tolist()) == list(range(12)) and [len(p) for p in parts] == [4, 4, 4]
     assert not np.array_equal(np.concatenate(parts), np.arange(12))            # shuffled, identically on every rank
     assert len(DS.DeviceBatches(ds, 5, device="cpu")) == 3 and len(DS.DeviceBatches(ds, 5, device="cpu", drop_last=True)) == 2
+
+
+# ---- KITTI ------------------------------------------------------------------------------------------------------------
+KITTI_DRIVES = ("2011_09_26/2011_09_26_drive_0001_sync/", "2011_09_30/2011_09_30_drive_0028_sync/")
+
+
+def make_kitti_tree(root, per_drive=2, sat_size=640, grd_hw=(94, 310), seed=5):
+    """A tiny dataset directory in the KITTI layout of the reference's loader (satmap/, raw_data/<drive>/oxts/data,
+    raw_data/<drive>/image_02/data) + a training file and a test file.  Returns (train file, test file, names)."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    names = []
+    for d in KITTI_DRIVES:
+        assert len(d) == 38
+        os.makedirs(os.path.join(root, "satmap", d))
+        os.makedirs(os.path.join(root, "raw_data", d, "oxts/data"))
+        os.makedirs(os.path.join(root, "raw_data", d, "image_02/data"))
+        for k in range(per_drive):
+            frame = "%010d.png" % (k * 7)
+            Image.fromarray((rng.rand(sat_size, sat_size, 3) * 255).astype(np.uint8), "RGB").save(os.path.join(root, "satmap", d, frame))
+            Image.fromarray((rng.rand(grd_hw[0], grd_hw[1], 3) * 255).astype(np.uint8), "RGB").save(
+                os.path.join(root, "raw_data", d, "image_02/data", frame))
+            with open(os.path.join(root, "raw_data", d, "oxts/data", frame.replace(".png", ".txt")), "w") as f:
+                f.write("49.01 8.43 112.0 0.02 0.01 %.6f 1.0 2.0\n" % rng.uniform(-3.1, 3.1))
+            names.append(d + frame)
+    train_file, test_file = os.path.join(root, "train_files.txt"), os.path.join(root, "test1_files.txt")
+    with open(train_file, "w") as f:
+        f.write("".join(n + "\n" for n in names))
+    with open(test_file, "w") as f:
+        f.write("".join("%s %.4f %.4f %.4f\n" % (n, rng.uniform(-1, 1), rng.uniform(-1, 1), rng.uniform(-1, 1)) for n in names))
+    return train_file, test_file, names
+
+
+def test_kitti_index_paths_and_listed_perturbations(tmp_path):
+    train_file, test_file, names = make_kitti_tree(str(tmp_path))
+    tr = DS.KITTIPairs(str(tmp_path), train_file)
+    te = DS.KITTIPairs(str(tmp_path), test_file, rotation_range=10, test=True)
+    assert len(tr) == len(te) == 4 and tr.lines == names
+    sat, oxts, grd = tr.paths(names[2])
+    assert sat == os.path.join(str(tmp_path), "satmap", names[2]) and oxts.endswith("oxts/data/0000000000.txt")
+    assert grd == os.path.join(str(tmp_path), "raw_data", KITTI_DRIVES[1], "image_02/data", "0000000000.png")
+    _, sx, sy, th = te.lines[1].split(" ")
+    assert te.perturbation(1) == (-float(sx), -float(sy), float(th) * 10)
+    assert abs(tr.meter_per_pixel - 0.19582850865) < 1e-9 and abs(tr.shift_px_lat - 20 / tr.meter_per_pixel) < 1e-12
+    s = te.sample(1)
+    assert s["sat_u8"].shape == (512, 512, 3) and s["grd_u8"].shape == (94, 310, 3) and s["roll"] == 0
+    assert 0.0 <= s["angle_deg"] <= 360.0 and s["city"] == KITTI_DRIVES[0]
+    # seeded generator instead of numpy's global one: reproducible draws
+    a = DS.KITTIPairs(str(tmp_path), train_file, rng=np.random.default_rng(3)).perturbation(0)
+    b = DS.KITTIPairs(str(tmp_path), train_file, rng=np.random.default_rng(3)).perturbation(0)
+    assert a == b and all(-1 <= v <= 1 for v in a[:2]) and abs(a[2]) <= 10
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference not present")
+def test_kitti_sample_matches_the_reference_datasets_live(tmp_path):
+    """The reference's own SatGrdDataset / SatGrdDatasetTest on the same directory: the aligned + perturbed aerial crop, the camera
+    image, the orientation angle and — through the oracle's ground-truth restatement with 16 bins — gt, gt_with_ori (max-pooled)
+    and the orientation map.  torchvision is not installed in this image: the reference's one use of it here,
+    `TF.center_crop` on a PIL image, is supplied with torchvision 0.x's published rule (top/left = int(round((size - crop) / 2)))."""
+    import torch.nn.functional as F
+    train_file, test_file, names = make_kitti_tree(str(tmp_path))
+    D = import_reference_datasets()
+
+    def center_crop(img, size):
+        w, h = img.size
+        left, top = int(round((w - size) / 2.0)), int(round((h - size) / 2.0))
+        return img.crop((left, top, left + size, top + size))
+    D.TF.center_crop = center_crop
+
+    def to_u8(im):
+        return torch.from_numpy(np.array(im)).permute(2, 0, 1)
+    for test in (False, True):
+        cls = D.SatGrdDatasetTest if test else D.SatGrdDataset
+        ref = cls(str(tmp_path), test_file if test else train_file, transform=(to_u8, to_u8), shift_range_lat=20, shift_range_lon=20,
+                  rotation_range=(10 if test else 180))
+        ours = DS.KITTIPairs(str(tmp_path), test_file if test else train_file, 20, 20, 10 if test else 180, test=test)
+        assert len(ours) == len(ref)
+        for i in range(len(ours)):
+            np.random.seed(100 + i)
+            sat, grd, gt, gt_with_ori, orientation, angle = ref[i]
+            np.random.seed(100 + i)
+            s = ours.sample(i)
+            assert abs(s["angle_deg"] - angle) < 1e-9
+            assert np.array_equal(s["sat_u8"], sat.permute(1, 2, 0).numpy())
+            assert np.array_equal(s["grd_u8"].astype(np.float32), grd.permute(1, 2, 0).numpy().astype(np.float32))
+            g, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 16)
+            assert torch.equal(g[0], gt) and torch.equal(ori[0], orientation)
+            for k, lab in zip((64, 32, 16, 8, 4, 2), labs):
+                assert torch.equal(lab[0], F.max_pool2d(gt_with_ori[None], k, stride=k)[0])

@@ -64,3 +64,34 @@ def test_unreadable_aerial_tile_raises_in_the_consumer(tmp_path):
     with pytest.raises((OSError, FileNotFoundError)):
         for _ in DS.DeviceBatches(ds, 4, device="cuda"):
             pass
+
+
+def test_kitti_device_batches_match_the_oracle_pipeline_and_feed_the_model(tmp_path, synth_sd):
+    """KITTIPairs (listed test perturbations: deterministic) -> DeviceBatches with the KITTI geometry (256 x 1024 camera image,
+    16 orientation bins) against the oracle's transform / ground-truth restatement; a batch goes straight into CVM_KITTI."""
+    from ccvpe_amd import models
+    from test_datasets import make_kitti_tree
+    train_file, test_file, names = make_kitti_tree(str(tmp_path))
+    ds = DS.KITTIPairs(str(tmp_path), test_file, 20, 20, 10, test=True)
+    seen = []
+    last = None
+    for batch in DS.DeviceBatches(ds, 3, device="cuda", workers=2, grd_hw=(256, 1024), n_bins=16):
+        b = len(batch.indices)
+        assert tuple(batch.grd.shape) == (b, 3, 256, 1024) and tuple(batch.sat.shape) == (b, 3, 512, 512)
+        assert tuple(batch.labels[0].shape) == (b, 16, 8, 8)
+        for j, i in enumerate(batch.indices):
+            s = ds.sample(i)
+            assert torch.equal(batch.grd[j].cpu(), O.preprocess_reference(s["grd_u8"], (256, 1024)))
+            assert torch.equal(batch.sat[j].cpu(), O.preprocess_reference(s["sat_u8"], (512, 512)))
+            g, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 16)
+            assert (batch.gt[j].cpu() - g[0]).abs().max() < 1e-5 and (batch.gt_ori[j].cpu() - ori[0]).abs().max() < 1e-5
+            for a, w in zip(batch.labels, labs):
+                assert (a[j].cpu() - w[0]).abs().max() < 1e-5
+        seen += batch.indices
+        last = batch
+    assert seen == list(range(4))
+    net = models.CVM_KITTI("cuda")
+    net.load_state_dict(synth_sd("kitti", 0), strict=True)
+    net = net.to("cuda:0").eval()
+    out = net(last.grd, last.sat)
+    assert tuple(out[0].shape) == (1, 512 * 512) and torch.isfinite(out[0]).all()
