@@ -123,6 +123,7 @@ PROTOTYPES = {
     "ccvpe_orientation_loss_bwd_f32": (c_int, [c_void_p] * 5 + [c_int, c_int, c_void_p]),
     "ccvpe_train_targets_nblk": (c_int, [c_int, c_int]),
     "ccvpe_train_targets_f32": (c_int, [c_void_p, c_void_p, c_int, c_float] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
+    "ccvpe_train_targets_ordered_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float] + [c_void_p] * 10 + [c_int] * 3 + [c_void_p]),
     "ccvpe_adam_chunk_elems": (c_int, []),
     "ccvpe_adam_hyper_floats": (c_int, []),
     "ccvpe_adam_step_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p]),

@@ -60,7 +60,7 @@ struct PyramidPtrs {
 };
 
 __global__ __launch_bounds__(256) void targets_pyramid_kernel(const float* __restrict__ center, const float* __restrict__ angle,
-                                                              float inv2s2, int n_bins, float bin_width,
+                                                              float inv2s2, int n_bins, float bin_width, int ascending,
                                                               const PyramidPtrs out, int H, int W) {
   const int b = blockIdx.y, l = blockIdx.z;
   const int k = 64 >> l;
@@ -84,8 +84,10 @@ __global__ __launch_bounds__(256) void targets_pyramid_kernel(const float* __res
   int index = (int)floor(ang / (double)bin_width);
   index = min(max(index, 0), n_bins - 1);
   const float ratio = (float)((ang - (double)index * (double)bin_width) / (double)bin_width);
-  const int b0 = index == 0 ? 0 : n_bins - index;
-  const int b1 = index == 0 ? n_bins - 1 : n_bins - index - 1;
+  // VIGOR / KITTI count the bins DOWN from the angle (datasets.py:156-161, :489-494); the Oxford RobotCar loader counts them UP
+  // (datasets.py:340-347: bins index and index + 1, wrapping n-1 -> 0)
+  const int b0 = ascending ? index : (index == 0 ? 0 : n_bins - index);
+  const int b1 = ascending ? (index == n_bins - 1 ? 0 : index + 1) : (index == 0 ? n_bins - 1 : n_bins - index - 1);
   float* o = out.lab[l] + (size_t)b * n_bins * hl * wl + cell;
   for (int q = 0; q < n_bins; ++q) {
     float w = 0.f;
@@ -155,9 +157,10 @@ using namespace ccvpe;
 
 extern "C" int ccvpe_train_targets_nblk(int h, int w) { return (h * w + TG_PIX - 1) / TG_PIX; }
 
-extern "C" int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
-                                       float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
-                                       float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream) {
+extern "C" int ccvpe_train_targets_ordered_f32(const float* center_xy, const float* angle_deg, int n_bins, int ascending, float sigma,
+                                               float* gt, float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3,
+                                               float* lab4, float* lab5, float* lab6, float* scratch, int batch, int h, int w,
+                                               void* stream) {
   if (batch <= 0 || h < 64 || w < 64 || h % 64 || w % 64) return fail(CCVPE_EINVAL, "train_targets: h, w must be multiples of 64");
   if (n_bins < 2 || sigma <= 0.f) return fail(CCVPE_EINVAL, "train_targets: bad n_bins / sigma");
   hipStream_t st = (hipStream_t)stream;
@@ -170,8 +173,15 @@ extern "C" int ccvpe_train_targets_f32(const float* center_xy, const float* angl
   pp.lab[0] = lab1; pp.lab[1] = lab2; pp.lab[2] = lab3; pp.lab[3] = lab4; pp.lab[4] = lab5; pp.lab[5] = lab6;
   const int cells = (h / 2) * (w / 2);
   hipLaunchKernelGGL(targets_pyramid_kernel, dim3((cells + 255) / 256, batch, 6), dim3(256), 0, st, center_xy, angle_deg, inv2s2,
-                     n_bins, 360.0f / n_bins, pp, h, w);
+                     n_bins, 360.0f / n_bins, ascending ? 1 : 0, pp, h, w);
   return check_launch("train_targets");
+}
+
+extern "C" int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
+                                       float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
+                                       float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream) {
+  return ccvpe_train_targets_ordered_f32(center_xy, angle_deg, n_bins, 0, sigma, gt, gt_norm, gt_ori, lab1, lab2, lab3, lab4, lab5,
+                                         lab6, scratch, batch, h, w, stream);
 }
 
 extern "C" int ccvpe_adam_chunk_elems(void) { return ADAM_CHUNK; }

@@ -23,6 +23,10 @@ and the 1 + 16 + 2 channel ground truth then run on the device exactly as for VI
     pairs = KITTIPairs(root, "train_files.txt", shift_range_lat=20, shift_range_lon=20, rotation_range=10)
     for batch in DeviceBatches(pairs, 64, grd_hw=(256, 1024), n_bins=16, rank=rank, world=world): ...
 
+Oxford RobotCar (datasets.py:183-353): `OxfordPairs(grd_image_root, sat_path, split)` — list files + yaw fixtures, the UTM ->
+map-pixel fit, an 800 x 800 patch of the one large aerial map per sample; `DeviceBatches(pairs, B, grd_hw=(154, 231),
+ascending_bins=True)`.
+
 Sharding: DeviceBatches gives rank r the contiguous shard harness.shard_indices(len, world, r) of the index list (after the
 optional seeded shuffle, identical on every rank): no sample is seen twice, no collective is needed.
 """
@@ -227,6 +231,91 @@ class KITTIPairs(object):
                     city=name[:38], index=int(idx))
 
 
+# ---- Oxford RobotCar (datasets.py:183-353, train_OxfordRobotCar.py:49-72) ---------------------------------------------
+# Ground control points of the reference's aerial map: UTM (easting, northing) -> (column, row) of `satellite_map_new.png`
+# (datasets.py:252-263: four corners + centre; the affine map is their least-squares fit).
+OXFORD_UTM = ((619400., 5736195.), (619400., 5734600.), (620795., 5736195.), (620795., 5734600.), (620100., 5735400.))
+OXFORD_PIX = ((900., 900.), (492., 18168.), (15966., 1260.), (15553., 18528.), (8255., 9688.))
+OXFORD_LISTS = {"train": (("training.txt",), "train_yaw.npy"), "val": (("validation.txt",), "val_yaw.npy"),
+                "test": (("test1_j.txt", "test2_j.txt", "test3_j.txt"), "test_yaw.npy")}
+
+
+class OxfordPairs(object):
+    """Host-side index of an Oxford RobotCar split + per-sample decode: `<image> <...> <easting> <northing>` lines, the yaw
+    fixtures (`*_yaw.npy`, radians, 0 = west, clockwise), ONE large aerial map from which an 800 x 800 patch is cut per sample —
+    around the vehicle plus a random offset of up to 200 * sqrt(2) map pixels (train: two draws from Python's `random` module,
+    or from `rng`, a `random.Random`), or the half-overlapping grid patch that holds the vehicle at least 200 pixels from its
+    border (val / test).  The Gaussian's centre is the vehicle's position in the 512 x 512 resized patch; the orientation bins of
+    this loader count UP (DeviceBatches(..., ascending_bins=True))."""
+
+    def __init__(self, grd_image_root, sat_path, split="train", rng=None):
+        from PIL import Image
+        if split not in OXFORD_LISTS:
+            raise ValueError("split must be 'train', 'val' or 'test'")
+        self.root, self.split = grd_image_root, split
+        Image.MAX_IMAGE_PIXELS = None                                  # the real map is 16 k x 19 k pixels
+        self.map = Image.open(sat_path)
+        self.map.load()
+        files, yaw = OXFORD_LISTS[split]
+        self.rows, self.list_lengths = [], []
+        for fn in files:
+            with open(os.path.join(grd_image_root, fn)) as f:
+                rows = [ln[:-1].split(" ") for ln in f.readlines()]
+            self.list_lengths.append(len(rows))
+            self.rows += rows
+        self.yaw = np.load(os.path.join(grd_image_root, yaw))
+        if len(self.yaw) < len(self.rows):
+            raise ValueError("%s has %d entries for %d samples" % (yaw, len(self.yaw), len(self.rows)))
+        utm = np.asarray([r[2:] for r in self.rows], dtype=np.float64)            # [n, 2]: easting, northing
+        src = np.hstack([np.asarray(OXFORD_UTM), np.ones((5, 1))])
+        dst = np.hstack([np.asarray(OXFORD_PIX), np.ones((5, 1))])
+        self.utm = utm
+        self.affine = np.linalg.lstsq(src, dst, rcond=None)[0]                   # 3 x 3; its last column maps the padding 1 to 1
+        self._rng, self._rng_lock = rng, threading.Lock()
+
+    def __len__(self):
+        return len(self.rows)
+
+    def offset(self):
+        """Training: the (row, column) offset of the patch centre from the vehicle, in map pixels (datasets.py:296-300)."""
+        import math
+        import random
+        with self._rng_lock:
+            u = random.random if self._rng is None else self._rng.random
+            alpha, r = 2 * math.pi * u(), 200 * np.sqrt(2) * u()
+        return int(r * math.cos(alpha)), int(r * math.sin(alpha))
+
+    def sample(self, idx, sat_hw=(512, 512), grd_hw=(154, 231)):
+        from PIL import Image
+        with Image.open(os.path.join(self.root, self.rows[idx][0])) as im:
+            grd = np.array(im.convert("RGB"))
+        # one sample at a time, as the reference evaluates it (a batched product may round differently in the last place)
+        col, row = (float(v) for v in np.dot(np.hstack([self.utm[idx:idx + 1], np.ones((1, 1))]), self.affine)[0, :2])
+        if self.split == "train":
+            drow, dcol = self.offset()
+            r0, c0 = int(row + drow), int(col + dcol)
+            box = (c0 - 400, r0 - 400, c0 + 400, r0 + 400)
+            cy = int(np.round((400 + drow) / 800 * 512 - 256))
+            cx = int(np.round((400 + dcol) / 800 * 512 - 256))
+        else:
+            def grid(v):                    # patch origin = a multiple of 400 such that the vehicle sits in [200, 600) of the patch
+                k = int(v // 400)
+                if np.round(v - 400 * k) < 200:
+                    k -= 1
+                return k, int(np.round(v - 400 * k))
+            kc, pc = grid(col)
+            kr, pr = grid(row)
+            box = (kc * 400, kr * 400, kc * 400 + 800, kr * 400 + 800)
+            cy = int(-(pr / 800 * 512 - 256))
+            cx = int(-(pc / 800 * 512 - 256))
+        sat = np.array(self.map.crop(box).convert("RGB"))
+        angle = float(self.yaw[idx]) / np.pi * 180 - 90                          # 0 = north, clockwise (datasets.py:334-337)
+        if angle < 0:
+            angle += 360
+        return dict(grd_u8=grd, sat_u8=sat, roll=0, angle_deg=float(angle), center=(float(cx), float(cy)), city="oxford",
+                    index=int(idx))
+
+
 class Batch(object):
     """One device batch: grd [B,3,h,w_fov], sat [B,3,H,W] (normalised fp32), angle_deg [B], center [B,2], cities, indices and —
     with targets — gt [B,1,H,W], gt_flat [B,H*W], gt_ori [B,2,H,W], labels (six max-pooled orientation-binned maps)."""
@@ -234,12 +323,14 @@ class Batch(object):
 
 
 class DeviceBatches(object):
-    """Iterates a VIGORPairs / KITTIPairs index in device batches (KITTI: grd_hw=(256, 1024), n_bins=16).  Decoding runs `workers` samples ahead on a thread pool; resize,
+    """Iterates a VIGORPairs / KITTIPairs / OxfordPairs index in device batches (KITTI: grd_hw=(256, 1024), n_bins=16; Oxford:
+    grd_hw=(154, 231), ascending_bins=True).  Decoding runs `workers` samples ahead on a thread pool; resize,
     normalisation, roll, FoV crop and the ground truth are kernels on `device` (no CPU fallback: preprocess raises without
     the HIP library).  fov < 360 keeps the first fov/360 of the rolled panorama's columns (train_VIGOR.py:177-178)."""
 
     def __init__(self, pairs, batch_size, device="cuda", indices=None, shuffle=False, seed=0, rank=0, world=1, workers=8,
-                 prefetch=2, grd_hw=(320, 640), sat_hw=(512, 512), fov=360, targets=True, n_bins=20, drop_last=False):
+                 prefetch=2, grd_hw=(320, 640), sat_hw=(512, 512), fov=360, targets=True, n_bins=20, drop_last=False,
+                 ascending_bins=False):
         from . import harness
         self.pairs, self.batch_size, self.device = pairs, int(batch_size), torch.device(device)
         idx = np.arange(len(pairs)) if indices is None else np.asarray(indices)
@@ -250,7 +341,7 @@ class DeviceBatches(object):
         self.workers, self.prefetch = int(workers), int(prefetch)
         self.grd_hw, self.sat_hw, self.fov = tuple(grd_hw), tuple(sat_hw), fov
         self.keep_w = int(fov / 360 * grd_hw[1])
-        self.targets, self.n_bins, self.drop_last = targets, n_bins, drop_last
+        self.targets, self.n_bins, self.drop_last, self.ascending_bins = targets, n_bins, drop_last, bool(ascending_bins)
 
     def __len__(self):
         n = len(self.indices)
@@ -278,7 +369,8 @@ class DeviceBatches(object):
         out.gt = out.gt_flat = out.gt_ori = out.labels = None
         if self.targets:
             out.gt, out.gt_flat, out.gt_ori, out.labels = targets.train_targets(out.center, out.angle_deg % 360.0, self.n_bins,
-                                                                               self.sat_hw[0], self.sat_hw[1])
+                                                                               self.sat_hw[0], self.sat_hw[1],
+                                                                               ascending=self.ascending_bins)
         return out
 
     def __iter__(self):

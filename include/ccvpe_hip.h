@@ -422,6 +422,13 @@ int ccvpe_train_targets_nblk(int h, int w);
 int ccvpe_train_targets_f32(const float* center_xy, const float* angle_deg, int n_bins, float sigma, float* gt,
                             float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3, float* lab4,
                             float* lab5, float* lab6, float* scratch, int batch, int h, int w, void* stream);
+/* The same with the order of the orientation bins as a parameter: ascending = 0 is ccvpe_train_targets_f32 (VIGOR / KITTI: the
+ * two bins are n - index and n - index - 1, datasets.py:156-161 / :489-494), ascending = 1 the Oxford RobotCar loader's
+ * (datasets.py:340-347: bins index and index + 1, n - 1 wrapping to 0). */
+int ccvpe_train_targets_ordered_f32(const float* center_xy, const float* angle_deg, int n_bins, int ascending, float sigma,
+                                    float* gt, float* gt_norm, float* gt_ori, float* lab1, float* lab2, float* lab3,
+                                    float* lab4, float* lab5, float* lab6, float* scratch, int batch, int h, int w,
+                                    void* stream);
 int ccvpe_adam_chunk_elems(void);
 int ccvpe_adam_hyper_floats(void);
 int ccvpe_adam_step_f32(const void* table, const float* hyper, const int* chunk_tensor, const int* chunk_off, int n_chunks,

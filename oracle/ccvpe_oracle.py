@@ -297,10 +297,11 @@ def orientation_loss(ori, gt_orientation, gt):
 # ----------------------------------------------------------------------------------------
 # training ground truth (what the datasets build per sample and the training loop max-pools)
 # ----------------------------------------------------------------------------------------
-def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0):
+def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0, ascending=False):
     """datasets.py:145-166 (VIGOR: 20 bins of 18 deg; cx = col_offset, cy = -row_offset) and :470-501 (KITTI: 16 bins of
     22.5 deg; cx = x_offset, cy = y_offset), then train_VIGOR.py:120-128: gt, gt / sum(gt), the (cos, sin) map and
-    MaxPool2d(k, k)(gt_with_ori) for k = 64..2.  numpy float64 -> float32 exactly as the reference does."""
+    MaxPool2d(k, k)(gt_with_ori) for k = 64..2.  numpy float64 -> float32 exactly as the reference does.
+    ascending=True: the Oxford RobotCar loader's bin order (datasets.py:340-347; cx / cy = col / row_offset_resized)."""
     import numpy as np
     bw = 360.0 / n_bins
     gts, oris, gwo = [], [], []
@@ -313,7 +314,10 @@ def train_targets(center_xy, angle_deg, n_bins, height=512, width=512, sigma=4.0
         w = np.zeros([n_bins, height, width], dtype=np.float32)
         index = int(ang // bw)
         ratio = (ang % bw) / bw
-        if index == 0:
+        if ascending:
+            w[index] = e * (1 - ratio)
+            w[0 if index == n_bins - 1 else index + 1] = e * ratio
+        elif index == 0:
             w[0] = e * (1 - ratio)
             w[n_bins - 1] = e * ratio
         else:

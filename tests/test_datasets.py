@@ -248,3 +248,78 @@ def test_kitti_sample_matches_the_reference_datasets_live(tmp_path):
             assert torch.equal(g[0], gt) and torch.equal(ori[0], orientation)
             for k, lab in zip((64, 32, 16, 8, 4, 2), labs):
                 assert torch.equal(lab[0], F.max_pool2d(gt_with_ori[None], k, stride=k)[0])
+
+
+# ---- Oxford RobotCar ----------------------------------------------------------------------------------------------------
+def make_oxford_tree(root, n=3, seed=8):
+    """A tiny Oxford RobotCar directory: list files + yaw fixtures + camera images, and an aerial 'map' that covers the
+    top-left 2600 x 2800 pixels of the real one (the vehicles sit ~60-80 m south-east of the map's north-west control point)."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    g = os.path.join(root, "grd") + "/"
+    os.makedirs(g)
+    yy, xx = np.mgrid[0:2800, 0:2600]
+    sat = np.stack([(xx * 7 + yy * 3) % 251, (xx // 16 * 13 + yy // 16 * 29) % 241, (xx * yy // 64) % 239], -1).astype(np.uint8)
+    sat_path = os.path.join(root, "satellite_map_new.png")
+    Image.fromarray(sat, "RGB").save(sat_path)
+    for fn, yaw in (("training.txt", "train_yaw.npy"), ("validation.txt", "val_yaw.npy"), ("test1_j.txt", None),
+                    ("test2_j.txt", None), ("test3_j.txt", "test_yaw.npy")):
+        rows = []
+        for k in range(n):
+            name = "%s_%d.png" % (fn.split(".")[0], k)
+            Image.fromarray((rng.rand(60, 90, 3) * 255).astype(np.uint8), "RGB").save(g + name)
+            rows.append("%s %d %.4f %.4f\n" % (name, 1000 + k, 619400 + rng.uniform(55, 85), 5736195 - rng.uniform(60, 90)))
+        with open(g + fn, "w") as f:
+            f.write("".join(rows))
+        if yaw:
+            np.save(g + yaw, rng.uniform(0, 2 * np.pi, size=(3 * n if fn == "test3_j.txt" else n)))
+    return g, sat_path
+
+
+def test_oxford_index_and_grid_patches(tmp_path):
+    g, sat_path = make_oxford_tree(str(tmp_path))
+    te = DS.OxfordPairs(g, sat_path, split="test")
+    assert len(te) == 9 and te.list_lengths == [3, 3, 3] and te.rows[3][0] == "test2_j_0.png"
+    for i in range(9):
+        s = te.sample(i)
+        assert s["sat_u8"].shape == (800, 800, 3) and s["grd_u8"].shape == (60, 90, 3)
+        assert abs(s["center"][0]) <= 128 and abs(s["center"][1]) <= 128       # the vehicle sits in the middle half of a grid patch
+        assert 0 <= s["angle_deg"] < 360
+    import random
+    tr = DS.OxfordPairs(g, sat_path, split="train", rng=random.Random(4))
+    offs = [tr.offset() for _ in range(200)]
+    assert max(np.hypot(a, b) for a, b in offs) <= 200 * np.sqrt(2) and len(set(offs)) > 150
+
+
+@pytest.mark.skipif(not reference_available(), reason="reference not present")
+def test_oxford_sample_matches_the_reference_dataset_live(tmp_path):
+    """The reference's OxfordRobotCarDataset on the same directory (Python's `random` seeded identically on both sides): camera
+    image, the 800 x 800 map patch, orientation angle and — through the oracle's restatement with ASCENDING bins — gt, gt_with_ori
+    (max-pooled) and the orientation map."""
+    import random
+    import torch.nn.functional as F
+    g, sat_path = make_oxford_tree(str(tmp_path))
+    D = import_reference_datasets()
+
+    def to_u8(im):
+        return torch.from_numpy(np.array(im.convert("RGB"))).permute(2, 0, 1)
+
+    def to_512(im):          # the reference reads the ground-truth size from the transformed aerial image: give it 512 x 512
+        return torch.from_numpy(np.array(im.convert("RGB").resize((512, 512)))).permute(2, 0, 1)
+    for split in ("train", "val", "test"):
+        ref = D.OxfordRobotCarDataset(g, sat_path, split=split, transform=(to_u8, to_512))
+        ours = DS.OxfordPairs(g, sat_path, split=split)
+        assert len(ours) == len(ref)
+        for i in range(len(ours)):
+            random.seed(50 + i)
+            grd, sat, gt, gt_with_ori, orientation, angle = ref[i]
+            random.seed(50 + i)
+            s = ours.sample(i)
+            assert abs(s["angle_deg"] - angle) < 1e-9
+            assert np.array_equal(s["grd_u8"], grd.permute(1, 2, 0).numpy())
+            from PIL import Image
+            assert np.array_equal(np.array(Image.fromarray(s["sat_u8"]).resize((512, 512))), sat.permute(1, 2, 0).numpy())
+            gg, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 20, ascending=True)
+            assert torch.equal(gg[0], gt) and torch.equal(ori[0], orientation)
+            for k, lab in zip((64, 32, 16, 8, 4, 2), labs):
+                assert torch.equal(lab[0], F.max_pool2d(gt_with_ori[None], k, stride=k)[0])

@@ -95,3 +95,29 @@ def test_kitti_device_batches_match_the_oracle_pipeline_and_feed_the_model(tmp_p
     net = net.to("cuda:0").eval()
     out = net(last.grd, last.sat)
     assert tuple(out[0].shape) == (1, 512 * 512) and torch.isfinite(out[0]).all()
+
+
+def test_oxford_device_batches_ascending_bins_and_model(tmp_path, synth_sd):
+    """OxfordPairs (val split: deterministic grid patches) -> DeviceBatches with the Oxford geometry (154 x 231 camera image, 800 x 800
+    map patch resized to 512, 20 bins counted UP) against the oracle; a batch goes straight into CVM_OxfordRobotCar."""
+    from ccvpe_amd import models
+    from test_datasets import make_oxford_tree
+    g, sat_path = make_oxford_tree(str(tmp_path))
+    ds = DS.OxfordPairs(g, sat_path, split="val")
+    batch = next(iter(DS.DeviceBatches(ds, 3, device="cuda", workers=2, grd_hw=(154, 231), n_bins=20, ascending_bins=True)))
+    assert tuple(batch.grd.shape) == (3, 3, 154, 231) and tuple(batch.sat.shape) == (3, 3, 512, 512)
+    for j, i in enumerate(batch.indices):
+        s = ds.sample(i)
+        assert torch.equal(batch.grd[j].cpu(), O.preprocess_reference(s["grd_u8"], (154, 231)))
+        assert torch.equal(batch.sat[j].cpu(), O.preprocess_reference(s["sat_u8"], (512, 512)))
+        gg, flat, ori, labs = O.train_targets([list(s["center"])], [s["angle_deg"]], 20, ascending=True)
+        desc = O.train_targets([list(s["center"])], [s["angle_deg"]], 20)[3]
+        assert (batch.gt[j].cpu() - gg[0]).abs().max() < 1e-5
+        for a, w, d in zip(batch.labels, labs, desc):
+            assert (a[j].cpu() - w[0]).abs().max() < 1e-5
+            assert (w[0] - d[0]).abs().max() > 1e-3            # the two bin orders really differ for these angles
+    net = models.CVM_OxfordRobotCar("cuda")
+    net.load_state_dict(synth_sd("oxford", 0), strict=True)
+    net = net.to("cuda:0").eval()
+    out = net(batch.grd, batch.sat)
+    assert tuple(out[0].shape) == (3, 512 * 512) and torch.isfinite(out[0]).all()
