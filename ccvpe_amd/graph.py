@@ -43,3 +43,57 @@ class GraphedForward(object):
             self.sat.copy_(sat)
         self.graph.replay()
         return self.out
+
+
+class GraphedTrainStep(object):
+    """hipGraph-captured training iteration up to, not including, the optimizer step — for the small-batch regime (the
+    reference's default batch is 8, train_VIGOR.py:29), where a step is ~2 000 launches of a few microseconds each and the host
+    cannot keep the device busy.
+
+        step = GraphedTrainStep(lambda: loss_of(net(grd, sat), ...), net)                  # captures forward + losses + backward
+        for it in range(n):
+            grd_buf.copy_(next_grd); ...            # refill the tensors the closure reads (same storage every step)
+            loss = step()                           # one graph launch: weight re-pack, forward, losses, backward
+            opt.step()                              # eager: one Adam launch (its bias corrections are host numbers per step)
+
+    What is captured: everything `loss_fn()` enqueues — the per-step weight re-pack (one gather launch, ccvpe_amd/repack.py),
+    the train-mode forward on its streams, the losses, `loss.backward()` with its stream forks and joins, the BatchNorm
+    running-statistic updates.  drop_connect draws come from torch's generator, which is graph-safe: every replay consumes fresh
+    random numbers.  Gradients land in `p.grad` tensors of the graph's private pool at fixed addresses (the closure must not free
+    them: this class clears them ONCE before capture).  Single process only: the data-parallel all-reduce hooks are host logic."""
+
+    def __init__(self, loss_fn, net, warmup=2):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise RuntimeError("GraphedTrainStep: single-process training only")
+        if not net.training:
+            raise RuntimeError("GraphedTrainStep captures a training iteration; call net.train() first")
+        self.net, self.params = net, list(net.parameters())
+        self.loss_fn = loss_fn
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):                 # warms the allocator, builds the re-pack plan, the Adam tables, ...
+                self._clear()
+                loss_fn().backward()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._clear()
+        # the weights have not changed since the last warm-up step, so the forward would re-use its packed copies and the graph
+        # would hold no re-pack: drop them — the capture then records the gather launch that re-derives them on every replay
+        net.invalidate()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = loss_fn()
+            self.loss.backward()
+        self.loss = self.loss.detach()
+
+    def _clear(self):
+        for p in self.params:
+            p.grad = None
+
+    def __call__(self):
+        """Replays forward + losses + backward on the tensors the closure captured; returns the (static) loss tensor.  The
+        gradients are in `p.grad` (static tensors, overwritten by the next replay)."""
+        self.graph.replay()
+        return self.loss
