@@ -35,6 +35,7 @@ def test_graphed_train_step_matches_eager_and_trains(synth_sd):
     torch.manual_seed(5)
     le = loss_e()
     le.backward()
+    le = le.detach()
     want = {n: p.grad.clone() for n, p in net_e.named_parameters() if p.grad is not None}
     del net_e
 
