@@ -31,15 +31,14 @@ def _setup(synth_sd, batch):
 def test_graphed_train_step_matches_eager_and_trains(synth_sd):
     from ccvpe_amd import graph, optim
     batch = 2
-    net_e, loss_e = _setup(synth_sd, batch)
+    net, loss_fn = _setup(synth_sd, batch)
     torch.manual_seed(5)
-    le = loss_e()
+    le = loss_fn()
     le.backward()
     le = le.detach()
-    want = {n: p.grad.clone() for n, p in net_e.named_parameters() if p.grad is not None}
-    del net_e
-
-    net, loss_fn = _setup(synth_sd, batch)
+    want = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    # the same model (its weights are untouched: no optimizer step yet; the running statistics the warm-up steps move do not
+    # enter a train-mode forward)
     step = graph.GraphedTrainStep(loss_fn, net)
     assert getattr(net, "_pack_plan", None) is not None               # the re-pack inside the graph is the gather launch
     torch.manual_seed(5)
