@@ -13,7 +13,7 @@ from oracle import ccvpe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-STEPS = 4      # (10 in round 2: 150 s of CPU oracle steps; 4 keeps the GPU suite inside its 900 s time box)
+STEPS = 3      # (10 in round 2: 150 s of CPU oracle steps; 3 keeps the GPU suite inside its 900 s time box)
 LR = 1e-4                      # train_VIGOR.py:104
 
 
