@@ -7,6 +7,7 @@
     targets     training ground truth built on the device;  optim: one-launch Adam;  preprocess: PIL-exact input transform
     ops, backward   one Python wrapper per C entry point of libccvpe_hip.so (include/ccvpe_hip.h), _lib: the ctypes table
     harness     replica timing harness, data-parallel gradient all-reduce (RCCL);  graph: hipGraph capture;  evaluate: sharded eval
+    datasets    VIGOR / KITTI / Oxford RobotCar: split files -> index, decode, device batches;  repack: train-mode weight re-pack in one launch
     synth       deterministic synthetic weights / inputs shared by tests, goldens and bench.py
 
 Everything arithmetic runs in libccvpe_hip.so (ccvpe_amd/csrc/*.hip); there is no CPU or eager fallback.
