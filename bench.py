@@ -137,7 +137,7 @@ def cpu_baseline_train(sd, kind="vigor", batch=2, reps=2):
         times.append(time.perf_counter() - t0)
     med = statistics.median(times)
     return dict(value=batch / med, unit="img-pairs/s", cores=cores, kind="port",
-                sample="oracle train-mode forward + loss mix + autograd backward, %s, B=%d fp32, 1 warm-up + median of %d"
+                sample="oracle train forward + losses + autograd backward, %s, B=%d fp32, median of %d"
                        % (kind, batch, reps))
 
 
@@ -155,8 +155,8 @@ def _traffic(name, workload):
     except Exception:
         return None, None
     meta = d.get("#meta", {})
-    src = "profiles/pmc_traffic.json[%s] (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH x2 per MI355X_MICROARCH.md; " \
-          "static file taken at commit %s, not re-measured in this run)" % (workload, meta.get("commit", "unknown"))
+    src = "profiles/pmc_traffic.json[%s] @%s (static rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes, not re-measured here)" \
+          % (workload, meta.get("commit", "unknown"))
     return d.get(name), src
 
 
@@ -188,10 +188,10 @@ def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
         if ws is None:
             return None, None
         if ws["bound"] == "hbm":
-            roof = {"bound": "hbm", "kernel": "(whole step; hipGraph replay: no per-launch events)", "achieved": ws["achieved_GBps"],
+            roof = {"bound": "hbm", "kernel": "(whole step: graph replay has no per-launch events)", "achieved": ws["achieved_GBps"],
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac"], "traffic": None}
         else:
-            roof = {"bound": "mfma", "kernel": "(whole step; hipGraph replay: no per-launch events)", "achieved": ws["achieved_tflops"],
+            roof = {"bound": "mfma", "kernel": "(whole step: graph replay has no per-launch events)", "achieved": ws["achieved_tflops"],
                     "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ws["frac"], "traffic": None}
         roof["whole_step"] = ws
         return roof, None
@@ -248,15 +248,17 @@ def compact(entry):
     """Driver-visible summary of a side measurement (goes under config.<leg>)."""
     if "error" in entry:
         return {"error": entry["error"][:300]}
-    out = {"ms_per_step": entry["ms_per_step"], "pairs_per_s": entry["value"], "n_gpus": entry.get("n_gpus", 1),
-           "batch_per_gpu": entry.get("batch_per_gpu"), "steps": entry.get("steps"), "dtype": entry.get("dtype")}
+    out = {"ms_per_step": entry["ms_per_step"], "pairs_per_s": entry["value"], "batch_per_gpu": entry.get("batch_per_gpu"),
+           "dtype": entry.get("dtype")}
+    if entry.get("n_gpus", 1) != 1:
+        out["n_gpus"] = entry["n_gpus"]
     r = entry.get("roofline") or {}
     ws = r.get("whole_step") or {}
     if ws:
         out["whole_step_bound"] = ws.get("bound")
         out["whole_step_frac"] = ws.get("frac")
     if r.get("kernel"):
-        out["kernel"], out["kernel_frac"], out["kernel_bound"] = r["kernel"], r.get("frac"), r.get("bound")
+        out["kernel"], out["kernel_frac"] = r["kernel"], r.get("frac")
     cb = entry.get("cpu_baseline")
     if cb:
         out["cpu_baseline_pairs_per_s"] = round(cb["value"], 3)
@@ -458,7 +460,7 @@ def main():
                                               % (world, "exact big-batch infoNCE (2-scalar all-reduce per level)"
                                                  if args.exact_infonce else "per-rank loss means, as torch DDP"),
                                "loss_after_last_step": entry["loss_after_last_step"], "peak_hbm_gib": entry["peak_hbm_gib"],
-                               "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
+                               "weights": "seeded random init, reference state_dict layout"},
                     "roofline": entry.get("roofline"), "cpu_baseline": None}
             if coll is not None:
                 line["config"]["collective"] = coll
@@ -503,7 +505,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": "replicas x%d (no data-path collective)" % world,
                        "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per kernel)",
-                       "weights": "seeded random init (ccvpe_amd.synth), reference state_dict layout"},
+                       "weights": "seeded random init, reference state_dict layout"},
         }
         if args.model == "oxford" and args.batch == 1 and world == 1:
             # the reference's only published rate for this path family: "14 FPS" per-frame pose estimation with the Oxford
