@@ -16,16 +16,20 @@ One JSON line on rank 0 with, besides the contract fields:
                  region / their HIP-event durations; peak from MI355X_MICROARCH.md; traffic = PMC HBM bytes per launch from
                  the committed profiles/ pass (`traffic_source` names it), else null; `whole_step` prices the entire step.
   cpu_baseline — the CPU oracle (oracle/ccvpe_oracle.py, kind "port") on the host cores, bounded sample, rank 0 / N=1.
-  config       — besides the workload description, COMPACT summaries of the side measurements the default command also runs
-                 (the driver's record keeps `config` and `roofline`; it drops unknown top-level keys):
-                 fwd_bwd_vigor_b64 (BASELINE metric's "(fwd+bwd) VIGOR bs=64": the full training step, with its CPU
-                 baseline), C2_bf16 (configs[2]), C1_bf16 (C1 model in bf16 storage), C4_bf16_graph_b256 (configs[4]);
+  config       — besides the workload description, the side measurements the default command also runs, as FLAT scalar keys
+                 (the driver's record keeps the scalars of `config`; nested objects are dropped): `<leg>_ms`,
+                 `<leg>_pairs_per_s`, `<leg>_frac` (whole step against its governing roof), `<leg>_kernel[_frac]`, ... for
+                 leg = fwd_bwd_vigor_b64 (BASELINE metric's "(fwd+bwd) VIGOR bs=64": the full training step, with
+                 `_cpu_pairs_per_s`), c2_bf16 (configs[2]), c1_bf16 (C1 model in bf16 storage), c4_graph_b256 (configs[4]);
                  for N>1 additionally train_dp_kitti_b64 (configs[3]: the data-parallel training step with the RCCL
-                 gradient all-reduce) and `collective` (backend, ranks as RCCL counts them, all-reduce calls and bytes per
-                 step).  Each summary: ms_per_step, pairs_per_s, whole-step fraction of the governing roof, dominant kernel
-                 and its fraction.  A failure of the data-parallel leg prints the line and then EXITS NON-ZERO.
+                 gradient all-reduce) and `collective_*` (backend, ranks as RCCL counts them, all-reduce calls and bytes
+                 per step).  A failure of the data-parallel leg prints the line and then EXITS NON-ZERO.
 The per-kernel tables of every leg go to stderr (one JSON object per leg, prefix "[bench kernels]"), not into the line.
 `--train` makes the training step the headline (`--model kitti` = C3).
+
+`--gpus N` without a launcher (WORLD_SIZE unset) and N > 1: this process — before anything touches a GPU — starts the N ranks
+itself (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ...`
+as a child process), relays rank 0's line and exits with the child's code.  Under a launcher WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
@@ -244,30 +248,43 @@ def emit_kernel_table(tag, table):
         sys.stderr.flush()
 
 
-def compact(entry):
-    """Driver-visible summary of a side measurement (goes under config.<leg>)."""
+LEG_KEY = {"fwd_bwd_vigor_b64": "fwd_bwd_vigor_b64", "C2_bf16": "c2_bf16", "C1_bf16": "c1_bf16",
+           "C4_bf16_graph_b256": "c4_graph_b256", "train_dp_kitti_b64": "train_dp_kitti_b64"}
+
+
+def compact(tag, entry):
+    """Driver-visible summary of a side measurement: FLAT scalar keys `<leg>_<field>` directly under `config` (the driver's
+    record keeps the scalars of `config` and drops nested objects)."""
+    k = LEG_KEY.get(tag, tag.lower())
     if "error" in entry:
-        return {"error": entry["error"][:300]}
-    out = {"ms_per_step": entry["ms_per_step"], "pairs_per_s": entry["value"], "batch_per_gpu": entry.get("batch_per_gpu"),
-           "dtype": entry.get("dtype")}
+        return {k + "_error": entry["error"][:300]}
+    out = {k + "_ms": entry["ms_per_step"], k + "_pairs_per_s": entry["value"], k + "_batch_per_gpu": entry.get("batch_per_gpu"),
+           k + "_dtype": entry.get("dtype")}
     if entry.get("n_gpus", 1) != 1:
-        out["n_gpus"] = entry["n_gpus"]
+        out[k + "_n_gpus"] = entry["n_gpus"]
     r = entry.get("roofline") or {}
     ws = r.get("whole_step") or {}
     if ws:
-        out["whole_step_bound"] = ws.get("bound")
-        out["whole_step_frac"] = ws.get("frac")
+        out[k + "_bound"] = ws.get("bound")
+        out[k + "_frac"] = ws.get("frac")                   # whole step against the governing roof
     if r.get("kernel"):
-        out["kernel"], out["kernel_frac"] = r["kernel"], r.get("frac")
+        out[k + "_kernel"], out[k + "_kernel_frac"] = r["kernel"], r.get("frac")
     cb = entry.get("cpu_baseline")
     if cb:
-        out["cpu_baseline_pairs_per_s"] = round(cb["value"], 3)
-        out["cpu_cores"] = cb["cores"]
-        out["cpu_sample"] = cb["sample"]
-    for k in ("loss_after_last_step", "peak_hbm_gib", "launch"):
-        if k in entry:
-            out[k] = entry[k]
+        out[k + "_cpu_pairs_per_s"] = round(cb["value"], 3)
+        out[k + "_cpu_cores"] = cb["cores"]
+        out[k + "_cpu_sample"] = cb["sample"]
+    for f, short in (("loss_after_last_step", "loss"), ("peak_hbm_gib", "peak_hbm_gib"), ("launch", "launch")):
+        if f in entry:
+            out[k + "_" + short] = entry[f]
     return out
+
+
+def flat_collective(coll):
+    return {"collective_backend": coll["backend"], "collective_world_size_env": coll["world_size_env"],
+            "collective_ranks": coll["ranks_counted_by_allreduce"],
+            "collective_calls_per_step": coll["allreduce_calls_per_step"], "collective_bytes_per_step": coll["bytes_per_step"],
+            "collective_op": coll["op"]}
 
 
 def per_layer_table(rec, steps):
@@ -389,12 +406,68 @@ def collective_info(dev, m, world):
             "op": "ncclAvg in place on the flat gradient arena, 3 groups, issued from inside the backward"}
 
 
+# ------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the ranks as a child process (this process never creates a GPU context)
+# ------------------------------------------------------------------------------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv, script=None, timeout=None):
+    """Runs `bench.py argv` as n ranks under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1), relays the
+    children's stderr and rank 0's stdout, returns the launcher's exit code.  `script` (or CCVPE_BENCH_CHILD, tests only)
+    replaces bench.py as the program the ranks run."""
+    import subprocess
+    script = script or os.environ.get("CCVPE_BENCH_CHILD") or os.path.abspath(__file__)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + list(argv)
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr)
+    sys.stderr.flush()
+    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    for l in res.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+        sys.stdout.flush()
+    if res.returncode == 0 and not lines:
+        print("bench.py: the ranks exited 0 without printing a line", file=sys.stderr)
+        return 1
+    return res.returncode
+
+
+def check_world(args, world):
+    """The contract's --gpus N must be the number of ranks that are really running."""
+    if world != args.gpus:
+        print("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a %d-GPU number from %d rank(s)"
+              % (args.gpus, world, args.gpus, world), file=sys.stderr)
+        sys.exit(2)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
+        # nothing in this process has touched the GPU yet (device_count() does not create a context)
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
+            sys.exit(2)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     import torch
     import torch.distributed as dist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    check_world(args, world)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or "RANK" in os.environ:
@@ -463,7 +536,7 @@ def main():
                                "weights": "seeded random init, reference state_dict layout"},
                     "roofline": entry.get("roofline"), "cpu_baseline": None}
             if coll is not None:
-                line["config"]["collective"] = coll
+                line["config"].update(flat_collective(coll))
             if m["rec"] is not None and args.per_layer:
                 per_layer_table(m["rec"], args.steps)
             if world == 1 and not args.no_cpu_baseline and kind in ("vigor", "kitti"):
@@ -613,10 +686,10 @@ def main():
                 if rank == 0:
                     legs["train_dp_kitti_b64"] = {"error": repr(ex)}
             if rank == 0 and coll is not None:
-                line["config"]["collective"] = coll
+                line["config"].update(flat_collective(coll))
         if rank == 0:
             for tag, ent in legs.items():
-                line["config"][tag] = compact(ent)
+                line["config"].update(compact(tag, ent))
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

@@ -1,4 +1,4 @@
-// conv3x3_kernel / conv3x3_wreg_kernel: see the comment blocks below.  Included by conv3x3_f32.hip / conv3x3_bf16.hip.
+// conv3x3_kernel (and, in diagnostics builds, conv3x3_wreg_kernel): see the comment blocks below.  Included by conv3x3_f32.hip / conv3x3_bf16.hip.
 #pragma once
 #include "conv_common.h"
 
@@ -14,12 +14,16 @@ namespace ccvpe {
 // image and the bank-conflict fix is an XOR swizzle of the 16-byte piece index, applied to the per-lane
 // SOURCE address and to the fragment read: slot(r, c) = 4r + (c ^ perm[(r>>2)&3]), perm = (0,2,3,1)
 // (conflict-free for the four ds_read_b128 lane groups).  Needs Npad % BN == 0 (no row guard possible).
-// taps per stage of the DMA 3x3 kernel: 3 (a row of taps, default) or 1 (CCVPE_CONV3_TPS=1, for A/B runs)
-// CCVPE_CONV3_WREG=1: fp32 3x3 convolutions through conv3x3_wreg_kernel (W fragments straight from L2)
+#ifdef CCVPE_ABLATE   // diagnostics build only (make EXTRA=-DCCVPE_ABLATE): A/B switches read from the environment at load
+// CCVPE_CONV3_TPS=1: one tap per stage instead of a row of taps; CCVPE_CONV3_WREG=1: fp32 3x3 convolutions through
+// conv3x3_wreg_kernel (W fragments straight from L2); CCVPE_CONV3_NW8=0: never the 8-wave form of the 128-column tile
 static const bool g_conv3_wreg = getenv("CCVPE_CONV3_WREG") && getenv("CCVPE_CONV3_WREG")[0] == '1';
-// CCVPE_CONV3_NW8=0: never use the 8-wave form of the 128-column tile (A/B runs)
 static const bool g_conv3_nw8 = !(getenv("CCVPE_CONV3_NW8") && getenv("CCVPE_CONV3_NW8")[0] == '0');
 static const int g_conv3_tps = (getenv("CCVPE_CONV3_TPS") && getenv("CCVPE_CONV3_TPS")[0] == '1') ? 1 : 3;
+#else                 // product build: the measured defaults, no environment reads
+constexpr bool g_conv3_nw8 = true;
+constexpr int g_conv3_tps = 3;
+#endif
 
 // TPS = taps per stage.  TPS = 1: one (16-channel chunk, tap) per stage.  TPS = 3 (W by LDS-DMA only): a stage is one ROW of
 // taps (ky; kx = 0..2) of a chunk — three W panels land per stage, the fragments of tap kx+1 are read from LDS while the
@@ -302,6 +306,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_kernel(const
   CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
+#ifdef CCVPE_ABLATE   // the W-from-L2 experiment (measured the same or slower): diagnostics build only
 // ---------------------------------------------------------------------------------------------
 // 3x3 convolution, W FRAGMENTS STRAIGHT FROM L2 (no LDS for W, one barrier per 16-channel chunk).
 //
@@ -491,6 +496,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wreg_kernel(const IgemmParams 
   CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
+#endif  // CCVPE_ABLATE
+
 template <typename T, int MT, int NT, int WN, int NW>
 static int launch3x3_nw(const IgemmParams& p0, int batch, hipStream_t stream) {
   constexpr int WM = NW / WN;
@@ -507,12 +514,14 @@ static int launch3x3_nw(const IgemmParams& p0, int batch, hipStream_t stream) {
 #ifdef CCVPE_ABLATE
   p.ablate = getenv("CCVPE_C3_ABLATE") ? atoi(getenv("CCVPE_C3_ABLATE")) : 0;
 #endif
+#ifdef CCVPE_ABLATE
   if constexpr (NW == 4 && sizeof(T) == 4) {
     if (g_conv3_wreg && (size_t)p.Npad * p.Kpad < (1u << 30)) {        // 32-bit W offsets
       hipLaunchKernelGGL((conv3x3_wreg_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
       return check_launch("conv3x3_wreg_kernel");
     }
   }
+#endif
   // W by LDS-DMA when the tile is fully inside the packed rows (no row guard possible), a row of taps per stage for the
   // 4-wave form (the 8-wave form lives under a 128-VGPR cap: no room for the second fragment set)
   static bool attr_set[3] = {false, false, false};      // per (T, tile) instantiation of this launcher: one flag per kernel variant

@@ -321,8 +321,11 @@ static int launch(const IgemmParams& p0, hipStream_t stream, float* scratch = nu
 
 using namespace ccvpe;
 
-// CCVPE_PW_GEMM=0 routes the pointwise convs through the generic kernel again (A/B measurements)
+#ifdef CCVPE_ABLATE   // diagnostics build only: CCVPE_PW_GEMM=0 routes the pointwise convs through the generic kernel again
 static const bool g_use_pw = !(getenv("CCVPE_PW_GEMM") && getenv("CCVPE_PW_GEMM")[0] == '0');
+#else
+constexpr bool g_use_pw = true;
+#endif
 
 // route (optional): filled with the kernel family + tile the dispatcher picks for `d` (CCVPE_ROUTE_* | MT << 8 | NT << 12 |
 // WN << 16) and NOTHING is launched — ccvpe_conv_igemm_route(); tests and bench.py's launch recorder read it instead of

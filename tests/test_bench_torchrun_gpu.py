@@ -2,8 +2,9 @@
 --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` — run end to end once on the one GPU a test box has
 (N = 1; the launcher starts before anything touches the GPU).  Under a launcher bench.py creates the RCCL process group and
 runs the data-parallel CVM_KITTI training leg (BASELINE configs[3]); CCVPE_ALLREDUCE_SINGLE_RANK=1 makes the 1-rank group
-issue the real in-place ncclAvg all-reduces of the gradient arena.  Asserted: the JSON line's config.collective fields and
-the compact config.train_dp_kitti_b64 summary; and that a failure of that leg still prints the line, then exits non-zero."""
+issue the real in-place ncclAvg all-reduces of the gradient arena.  Asserted: the JSON line's flat config.collective_* fields and
+the flat config.train_dp_kitti_b64_* summary (at B = 64 per GPU: BASELINE configs[3]'s own batch); that a failure of that leg
+still prints the line, then exits non-zero; and that a --gpus / WORLD_SIZE mismatch is refused."""
 import json
 import os
 import socket
@@ -17,14 +18,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(extra_env, batch):
+def _run(extra_env, batch, gpus=1):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCVPE_ALLREDUCE_SINGLE_RANK="1", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
            "--batch", str(batch), "--legs", "dp", "--no-cpu-baseline"]
     res = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
@@ -32,22 +33,30 @@ def _run(extra_env, batch):
 
 
 def test_bench_under_torchrun_reports_the_collective():
-    res, line = _run({}, 4)
+    res, line = _run({}, 64)
     assert res.returncode == 0 and line is not None, res.stdout[-2000:] + res.stderr[-4000:]
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["warmup"] == 1 and line["value"] > 0
     assert len(json.dumps(line)) < 6000, "the JSON line must stay compact (per-kernel tables go to stderr)"
     assert "[bench kernels]" in res.stderr
-    coll = line["config"]["collective"]
-    assert coll["backend"].startswith("nccl") and coll["world_size_env"] == 1 and coll["ranks_counted_by_allreduce"] == 1
-    assert coll["allreduce_calls_per_step"] == 3.0                       # the three gradient groups of the arena
-    assert coll["bytes_per_step"] >= 4 * 55_000_000                      # CVM_KITTI: 60.4 M parameters (57.9 M with a gradient), fp32
-    dp = line["config"]["train_dp_kitti_b64"]
-    assert "error" not in dp and dp["ms_per_step"] > 0 and dp["pairs_per_s"] > 0 and dp["whole_step_frac"] > 0
-    assert dp["loss_after_last_step"] == dp["loss_after_last_step"]      # finite
+    cfg = line["config"]
+    assert all(not isinstance(v, (dict, list)) for v in cfg.values()), "config must hold flat scalars only (the driver drops nested objects)"
+    assert cfg["collective_backend"].startswith("nccl") and cfg["collective_world_size_env"] == 1 and cfg["collective_ranks"] == 1
+    assert cfg["collective_calls_per_step"] == 3.0                       # the three gradient groups of the arena
+    assert cfg["collective_bytes_per_step"] >= 4 * 55_000_000            # CVM_KITTI: 60.4 M parameters (57.9 M with a gradient), fp32
+    assert "train_dp_kitti_b64_error" not in cfg, cfg.get("train_dp_kitti_b64_error")
+    assert cfg["train_dp_kitti_b64_batch_per_gpu"] == 64
+    assert cfg["train_dp_kitti_b64_ms"] > 0 and cfg["train_dp_kitti_b64_pairs_per_s"] > 0 and cfg["train_dp_kitti_b64_frac"] > 0
+    assert cfg["train_dp_kitti_b64_loss"] == cfg["train_dp_kitti_b64_loss"]      # finite
 
 
 def test_bench_dp_failure_prints_the_line_and_exits_nonzero():
     res, line = _run({"CCVPE_BENCH_FAIL_DP": "1"}, 2)
     assert res.returncode != 0, "a failed data-parallel leg must fail the run"
     assert line is not None and line["value"] > 0, res.stdout[-2000:] + res.stderr[-2000:]
-    assert "injected failure" in line["config"]["train_dp_kitti_b64"]["error"]
+    assert "injected failure" in line["config"]["train_dp_kitti_b64_error"]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    res, line = _run({}, 2, gpus=2)                 # one rank under the launcher, but --gpus 2
+    assert res.returncode != 0 and line is None, res.stdout[-2000:]
+    assert "WORLD_SIZE=1" in res.stderr

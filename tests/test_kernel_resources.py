@@ -51,3 +51,29 @@ def test_hot_kernels_keep_two_waves_per_simd():
     assert len(hot) > 100
     low = [k["name"][:90] for k in hot if int(k.get("Occupancy [waves/SIMD]", "0")) < 2]
     assert not low, "occupancy below 2 waves/SIMD:\n" + "\n".join(low)
+
+
+def test_product_library_reads_no_environment_switches():
+    """A/B switches (CCVPE_CONV3_*, CCVPE_PW_GEMM, CCVPE_*_ABLATE) and the experiments behind them live under
+    `#ifdef CCVPE_ABLATE` (diagnostics build: `make EXTRA=-DCCVPE_ABLATE`); the product library neither imports getenv nor
+    carries the W-from-L2 experiment kernel."""
+    import subprocess
+    _lib.build(verbose=False)
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in syms
+    res = "".join(open(p, errors="replace").read() for p in glob.glob(os.path.join(CSRC, "conv3x3_*.res")))
+    assert "conv3x3_kernel" in res and "conv3x3_wreg_kernel" not in res
+    for path in glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h")):
+        depth = 0
+        for n, line in enumerate(open(path), 1):
+            s = line.strip()
+            if s.startswith("#ifdef CCVPE_ABLATE"):
+                depth += 1
+            elif s.startswith("#if") and depth:
+                depth += 1
+            elif s.startswith("#endif") and depth:
+                depth -= 1
+            elif s.startswith("#else") and depth == 1:
+                depth = 0                     # the product branch of an #ifdef CCVPE_ABLATE / #else pair
+            code = line.split("//")[0]
+            assert depth or "getenv(" not in code, "%s:%d reads the environment in the product build" % (os.path.basename(path), n)
