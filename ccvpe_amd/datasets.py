@@ -27,8 +27,11 @@ Oxford RobotCar (datasets.py:183-353): `OxfordPairs(grd_image_root, sat_path, sp
 map-pixel fit, an 800 x 800 patch of the one large aerial map per sample; `DeviceBatches(pairs, B, grd_hw=(154, 231),
 ascending_bins=True)`.
 
-Sharding: DeviceBatches gives rank r the contiguous shard harness.shard_indices(len, world, r) of the index list (after the
-optional seeded shuffle, identical on every rank): no sample is seen twice, no collective is needed.
+Sharding: DeviceBatches gives rank r a contiguous shard of the index list (after the optional seeded shuffle, identical on
+every rank).  Evaluation (`shard="exact"`): harness.shard_indices — no sample is seen twice, no collective is needed, ranks
+may differ by one batch.  Training (`shard="pad"`, the default with targets and world > 1): every rank iterates the SAME
+number of batches (short shards wrap around, as torch's DistributedSampler pads), because each step all-reduces gradients.
+A sample's random choices (`pairs.draw(i)`) are drawn in index order on the producer thread, decoding runs on the pool.
 """
 import os
 import queue
@@ -55,7 +58,7 @@ class VIGORPairs(object):
     device pipeline needs; nothing here touches the GPU."""
 
     def __init__(self, root, label_root="splits_new", split="samearea", train=True, pos_only=True, ori_noise=180.0,
-                 random_orientation=None, seed=0):
+                 random_orientation=None, seed=0, strict_orientation=True):
         if split not in ("samearea", "crossarea"):
             raise ValueError("split must be 'samearea' or 'crossarea'")
         self.root, self.split, self.train, self.pos_only = root, split, bool(train), bool(pos_only)
@@ -79,11 +82,12 @@ class VIGORPairs(object):
         # panoramas: "<pano> <sat0> <drow0> <dcol0> <sat1> ... <sat3> <drow3> <dcol3>" (positive first, then 3 semi-positives)
         grd_paths, labels, deltas, city_of = [], [], [], []
         for city in self.cities:
-            with open(os.path.join(root, label_root, city, _label_file(split, self.train))) as f:
-                for line in f:
+            path = os.path.join(root, label_root, city, _label_file(split, self.train))
+            with open(path) as f:
+                for lineno, line in enumerate(f, 1):
                     tok = line.split(" ")
-                    if len(tok) < 13:
-                        continue
+                    if len(tok) < 13:           # the reference indexes tok[1..12] and raises here; a skipped line would shift
+                        raise ValueError("%s:%d: expected 13 fields, got %d" % (path, lineno, len(tok)))   # every later fixture entry
                     grd_paths.append(os.path.join(root, city, "panorama", tok[0]))
                     labels.append([sat_index[tok[i]] for i in (1, 4, 7, 10)])
                     deltas.append([[float(tok[i]), float(tok[i + 1])] for i in (2, 5, 8, 11)])
@@ -91,8 +95,11 @@ class VIGORPairs(object):
         self.grd_paths, self.city_of = grd_paths, city_of
         self.labels = np.asarray(labels, dtype=np.int64).reshape(-1, 4)
         self.deltas = np.asarray(deltas, dtype=np.float64).reshape(-1, 4, 2)       # (row, col) offsets in raw aerial pixels
-        if self.random_orientation is not None and len(self.random_orientation) < len(grd_paths):
-            raise ValueError("random_orientation has %d entries for %d samples" % (len(self.random_orientation), len(grd_paths)))
+        # the fixture is indexed by sample position: it must describe exactly this index (strict_orientation=False accepts a
+        # longer array, as the reference silently does — used by the tests that pair the fixture's head with a small tree)
+        n_ori = None if self.random_orientation is None else len(self.random_orientation)
+        if n_ori is not None and (n_ori < len(grd_paths) or (strict_orientation and n_ori != len(grd_paths))):
+            raise ValueError("random_orientation has %d entries for %d samples" % (n_ori, len(grd_paths)))
 
     def __len__(self):
         return len(self.grd_paths)
@@ -120,7 +127,12 @@ class VIGORPairs(object):
             k = int(ok[self._rng.integers(len(ok))])
         return k, self.deltas[idx, k, 0], self.deltas[idx, k, 1]
 
-    def sample(self, idx, sat_hw=(512, 512), grd_hw=(320, 640)):
+    def draw(self, idx):
+        """The sample's random choices, in the order sample() makes them.  DeviceBatches calls this on ONE thread in index order
+        and hands the result to sample(draws=...), so a seeded iteration is reproducible whatever the decode threads do."""
+        return self.rotation_fraction(idx), self.positive(idx)
+
+    def sample(self, idx, sat_hw=(512, 512), grd_hw=(320, 640), draws=None):
         """Decode sample idx.  Returns a dict: grd_u8 / sat_u8 (HWC uint8 numpy, as PIL decodes them), roll (pixels of the
         RESIZED panorama, datasets.py:121), angle_deg, center (cx, cy) of the Gaussian on the resized aerial grid
         (cx = column offset, cy = -row offset, both rescaled and rounded as datasets.py:141-142 does), city."""
@@ -130,8 +142,7 @@ class VIGORPairs(object):
                 grd = np.array(im.convert("RGB"))             # owning, writable: torch.from_numpy needs that
         except (OSError, ValueError):                                  # unreadable panorama -> blank image (datasets.py:103-105)
             grd = np.zeros((grd_hw[0], grd_hw[1], 3), dtype=np.uint8)
-        rot = self.rotation_fraction(idx)
-        k, drow, dcol = self.positive(idx)
+        rot, (k, drow, dcol) = self.draw(idx) if draws is None else draws
         with Image.open(self.sat_paths[self.labels[idx, k]]) as im:
             sat = np.array(im.convert("RGB"))
         h_raw, w_raw = sat.shape[0], sat.shape[1]
@@ -159,7 +170,8 @@ class KITTIPairs(object):
     :506-640 `SatGrdDatasetTest`).  A line of a TRAINING file is `<day>/<drive>/<frame>.png`; a line of a TEST file carries the
     sample's fixed perturbation: `<name> <shift_x> <shift_y> <theta>` (test=True).  Training perturbations are three uniform
     draws in [-1, 1) per sample — from numpy's global generator when rng is None (so `np.random.seed(s)` reproduces the
-    reference's sequence sample by sample), else from `rng` (a numpy Generator / RandomState; draws are serialised by a lock)."""
+    reference's sequence sample by sample when samples are drawn in order: sample() called sequentially, or DeviceBatches, which
+    calls draw() in index order on one thread), else from `rng` (a numpy Generator / RandomState; draws are serialised by a lock)."""
 
     def __init__(self, root, file, shift_range_lat=20.0, shift_range_lon=20.0, rotation_range=10.0, test=False, rng=None):
         self.root, self.test = root, bool(test)
@@ -193,7 +205,11 @@ class KITTIPairs(object):
             sx, sy, r = u(-1, 1), u(-1, 1), u(-1, 1)                                # datasets.py:452-453,463 (this order)
         return float(sx), float(sy), float(r) * self.rotation_range
 
-    def sample(self, idx, sat_hw=(512, 512), grd_hw=(256, 1024)):
+    def draw(self, idx):
+        """The sample's random choices (see VIGORPairs.draw)."""
+        return self.perturbation(idx)
+
+    def sample(self, idx, sat_hw=(512, 512), grd_hw=(256, 1024), draws=None):
         """Decode + align sample idx.  Returns the dict DeviceBatches consumes: grd_u8 (the left camera image as decoded),
         sat_u8 (the aligned, perturbed 512 x 512 aerial crop), roll = 0, angle_deg (orientation ground truth in [0, 360]),
         center = (x_offset, y_offset) of the Gaussian (datasets.py:475-476), city = the drive, index."""
@@ -206,7 +222,7 @@ class KITTIPairs(object):
             heading = float(f.readline().split(" ")[5])
         with Image.open(grd_path, "r") as im:
             grd = np.array(im.convert("RGB"))
-        sx, sy, ori = self.perturbation(idx)
+        sx, sy, ori = self.perturbation(idx) if draws is None else draws
         mpp = self.meter_per_pixel
         sat = sat.rotate(-heading / np.pi * 180)                                    # east = the vehicle heading
         sat = sat.transform(sat.size, Image.AFFINE, (1, 0, KITTI_CAMERA_SHIFT[0] / mpp, 0, 1, KITTI_CAMERA_SHIFT[1] / mpp),
@@ -285,14 +301,18 @@ class OxfordPairs(object):
             alpha, r = 2 * math.pi * u(), 200 * np.sqrt(2) * u()
         return int(r * math.cos(alpha)), int(r * math.sin(alpha))
 
-    def sample(self, idx, sat_hw=(512, 512), grd_hw=(154, 231)):
+    def draw(self, idx):
+        """The sample's random choice (see VIGORPairs.draw): the patch offset in training, nothing otherwise."""
+        return self.offset() if self.split == "train" else None
+
+    def sample(self, idx, sat_hw=(512, 512), grd_hw=(154, 231), draws=None):
         from PIL import Image
         with Image.open(os.path.join(self.root, self.rows[idx][0])) as im:
             grd = np.array(im.convert("RGB"))
         # one sample at a time, as the reference evaluates it (a batched product may round differently in the last place)
         col, row = (float(v) for v in np.dot(np.hstack([self.utm[idx:idx + 1], np.ones((1, 1))]), self.affine)[0, :2])
         if self.split == "train":
-            drow, dcol = self.offset()
+            drow, dcol = self.offset() if draws is None else draws
             r0, c0 = int(row + drow), int(col + dcol)
             box = (c0 - 400, r0 - 400, c0 + 400, r0 + 400)
             cy = int(np.round((400 + drow) / 800 * 512 - 256))
@@ -316,6 +336,22 @@ class OxfordPairs(object):
                     index=int(idx))
 
 
+def shard_positions(n, world, rank, mode="exact"):
+    """Positions of range(n) that rank `rank` of `world` iterates (see DeviceBatches: "exact" / "pad" / "truncate")."""
+    from . import harness
+    if mode == "exact":
+        return np.asarray(harness.shard_indices(n, world, rank), dtype=np.int64)
+    if mode == "truncate":
+        per = n // world
+        return np.arange(rank * per, (rank + 1) * per, dtype=np.int64)
+    if mode == "pad":
+        per = (n + world - 1) // world
+        if n == 0:
+            return np.zeros((0,), dtype=np.int64)
+        return np.arange(rank * per, (rank + 1) * per, dtype=np.int64) % n
+    raise ValueError("shard must be 'exact', 'pad' or 'truncate'")
+
+
 class Batch(object):
     """One device batch: grd [B,3,h,w_fov], sat [B,3,H,W] (normalised fp32), angle_deg [B], center [B,2], cities, indices and —
     with targets — gt [B,1,H,W], gt_flat [B,H*W], gt_ori [B,2,H,W], labels (six max-pooled orientation-binned maps)."""
@@ -326,21 +362,30 @@ class DeviceBatches(object):
     """Iterates a VIGORPairs / KITTIPairs / OxfordPairs index in device batches (KITTI: grd_hw=(256, 1024), n_bins=16; Oxford:
     grd_hw=(154, 231), ascending_bins=True).  Decoding runs `workers` samples ahead on a thread pool; resize,
     normalisation, roll, FoV crop and the ground truth are kernels on `device` (no CPU fallback: preprocess raises without
-    the HIP library).  fov < 360 keeps the first fov/360 of the rolled panorama's columns (train_VIGOR.py:177-178)."""
+    the HIP library).  fov < 360 keeps the first fov/360 of the rolled panorama's columns (train_VIGOR.py:177-178).
+
+    Rank shards (`shard`): "exact" = the balanced contiguous shards of harness.shard_indices — every sample exactly once over the
+    ranks, shard sizes differ by at most one, so ranks may run a DIFFERENT number of batches: evaluation only (no collective).
+    "pad" = every rank gets ceil(n / world) samples, the short shards wrap around to the start of the index list
+    (torch's DistributedSampler rule); "truncate" = every rank gets floor(n / world).  With "pad" / "truncate" len(self) is
+    the same on every rank BY CONSTRUCTION — required for training, where each step all-reduces gradients inside the
+    backward and a rank with one batch more would wait for its peers until the RCCL timeout.  Default: "pad" when targets
+    are produced (training) and world > 1, else "exact"."""
 
     def __init__(self, pairs, batch_size, device="cuda", indices=None, shuffle=False, seed=0, rank=0, world=1, workers=8,
                  prefetch=2, grd_hw=(320, 640), sat_hw=(512, 512), fov=360, targets=True, n_bins=20, drop_last=False,
-                 ascending_bins=False):
-        from . import harness
+                 ascending_bins=False, shard=None):
         self.pairs, self.batch_size, self.device = pairs, int(batch_size), torch.device(device)
         idx = np.arange(len(pairs)) if indices is None else np.asarray(indices)
         if shuffle:
             idx = idx[np.random.default_rng(seed).permutation(len(idx))]      # same permutation on every rank
-        mine = harness.shard_indices(len(idx), world, rank)
-        self.indices = idx[mine]
+        if shard is None:
+            shard = "pad" if (targets and world > 1) else "exact"
+        self.shard = shard
+        self.indices = idx[shard_positions(len(idx), world, rank, shard)]
         self.workers, self.prefetch = int(workers), int(prefetch)
         self.grd_hw, self.sat_hw, self.fov = tuple(grd_hw), tuple(sat_hw), fov
-        self.keep_w = int(fov / 360 * grd_hw[1])
+        self.keep_w = int(grd_hw[1] * fov / 360)                              # train_VIGOR.py:177: int(w * FoV / 360)
         self.targets, self.n_bins, self.drop_last, self.ascending_bins = targets, n_bins, drop_last, bool(ascending_bins)
 
     def __len__(self):
@@ -348,7 +393,9 @@ class DeviceBatches(object):
         return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
 
     def _decode_batch(self, pool, chunk):
-        return list(pool.map(lambda i: self.pairs.sample(int(i), self.sat_hw, self.grd_hw), chunk))
+        # the random choices of the chunk are drawn HERE, on the producer thread, in index order; the pool only decodes
+        draws = [self.pairs.draw(int(i)) for i in chunk]
+        return list(pool.map(lambda a: self.pairs.sample(int(a[0]), self.sat_hw, self.grd_hw, draws=a[1]), zip(chunk, draws)))
 
     def _to_device(self, samples):
         from . import preprocess, targets

@@ -79,6 +79,13 @@ class GraphedTrainStep(object):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self._clear()
+        # The capture must record the ONE-LAUNCH gather re-pack.  Without a verified plan (CCVPE_PACK_GATHER=0, or the plan failed
+        # its bit-for-bit check) the forward would call graph.replay() of the re-pack hipGraph inside this capture — illegal, and
+        # reported by HIP as an opaque capture error: say what is wrong instead.
+        if getattr(net, "_pack_plan", None) is None:
+            raise RuntimeError("GraphedTrainStep needs the one-launch gather re-pack (models._pack_plan); it is unavailable: "
+                               + ("the plan failed verification" if getattr(net, "_pack_plan_failed", False)
+                                  else "CCVPE_PACK_GATHER=0 or a non-fp32 model"))
         # the weights have not changed since the last warm-up step, so the forward would re-use its packed copies and the graph
         # would hold no re-pack: drop them — the capture then records the gather launch that re-derives them on every replay
         net.invalidate()
@@ -87,6 +94,15 @@ class GraphedTrainStep(object):
             self.loss = loss_fn()
             self.loss.backward()
         self.loss = self.loss.detach()
+        # the gradient tensors the graph writes to: p.grad must STAY these objects (see __call__ / zero_grad)
+        self._static_grads = [p.grad for p in self.params]
+
+    def zero_grad(self):
+        """Zeroes the captured gradient tensors IN PLACE (never `optimizer.zero_grad(set_to_none=True)`: that detaches the
+        static tensors the graph writes to; not needed between replays either — a replay overwrites every gradient)."""
+        for g in self._static_grads:
+            if g is not None:
+                g.zero_()
 
     def _clear(self):
         for p in self.params:
@@ -96,4 +112,7 @@ class GraphedTrainStep(object):
         """Replays forward + losses + backward on the tensors the closure captured; returns the (static) loss tensor.  The
         gradients are in `p.grad` (static tensors, overwritten by the next replay)."""
         self.graph.replay()
+        for p, g in zip(self.params, self._static_grads):     # re-attach what a set_to_none zero_grad() dropped: the optimizer
+            if p.grad is not g:                               # must step on the tensors this replay has just written
+                p.grad = g
         return self.loss

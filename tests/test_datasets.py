@@ -75,7 +75,7 @@ def test_index_follows_the_split_files(tmp_path):
 def test_orientation_fixture_and_random_choices(tmp_path):
     make_vigor_tree(str(tmp_path))
     head = os.path.join(GOLDEN, "samearea_orientation_test_head256.npy")      # first 256 entries of the reference's fixture
-    ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=False, ori_noise=180, random_orientation=head)
+    ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=False, ori_noise=180, random_orientation=head, strict_orientation=False)
     angles = np.load(head)
     assert angles.dtype == np.float64 and 0.0 <= angles.min() and angles.max() < 360.0
     for i in range(len(ds)):
@@ -133,7 +133,7 @@ def test_sample_matches_the_reference_dataset_live(tmp_path):
     for split, train in (("samearea", False), ("crossarea", True), ("crossarea", False)):
         ref = D.VIGORDataset(str(tmp_path), split=split, train=train, transform=(tf((320, 640)), tf((512, 512))), pos_only=True,
                              ori_noise=180, random_orientation=orient)
-        ours = DS.VIGORPairs(str(tmp_path), split=split, train=train, pos_only=True, ori_noise=180, random_orientation=orient)
+        ours = DS.VIGORPairs(str(tmp_path), split=split, train=train, pos_only=True, ori_noise=180, random_orientation=orient, strict_orientation=False)
         assert len(ours) == len(ref)
         assert list(ours.grd_paths) == list(ref.grd_list) and list(ours.sat_paths) == list(ref.sat_list)
         assert np.array_equal(ours.labels, ref.label) and np.array_equal(ours.deltas, ref.delta)
@@ -159,6 +159,68 @@ def test_device_batches_shard_without_overlap(tmp_path):
     assert sorted(allidx.tolist()) == list(range(12)) and [len(p) for p in parts] == [4, 4, 4]
     assert not np.array_equal(np.concatenate(parts), np.arange(12))            # shuffled, identically on every rank
     assert len(DS.DeviceBatches(ds, 5, device="cpu")) == 3 and len(DS.DeviceBatches(ds, 5, device="cpu", drop_last=True)) == 2
+
+
+def test_training_shards_run_the_same_number_of_batches_on_every_rank():
+    """A training step all-reduces gradients inside the backward: a rank with one batch more would block until the RCCL
+    timeout.  "pad" (the default with targets and world > 1) and "truncate" make len() rank-independent by construction;
+    "exact" (evaluation) covers every sample once and may differ by a batch."""
+    class Fake(object):
+        def __init__(self, n):
+            self.n = n
+
+        def __len__(self):
+            return self.n
+
+    for n, world, bs, drop in ((129, 2, 64, False), (127, 2, 64, True), (130, 8, 4, False), (5, 8, 2, False), (1000, 3, 64, True)):
+        for mode in ("pad", "truncate"):
+            its = [DS.DeviceBatches(Fake(n), bs, device="cpu", rank=r, world=world, drop_last=drop, shard=mode) for r in range(world)]
+            assert len({len(it) for it in its}) == 1 and len({len(it.indices) for it in its}) == 1, (n, world, bs, drop, mode)
+            seen = set(np.concatenate([it.indices for it in its]).tolist())
+            if mode == "pad":
+                assert seen == set(range(n))                              # every sample at least once
+            else:
+                assert len(seen) == (n // world) * world                  # no sample twice
+        default = [DS.DeviceBatches(Fake(n), bs, device="cpu", rank=r, world=world, drop_last=drop) for r in range(world)]
+        assert all(it.shard == "pad" for it in default) and len({len(it) for it in default}) == 1
+    # the case of the advisor's finding: exact shards of 129 samples over 2 ranks at B = 64 give 2 and 1 batches
+    ev = [DS.DeviceBatches(Fake(129), 64, device="cpu", rank=r, world=2, targets=False) for r in range(2)]
+    assert [it.shard for it in ev] == ["exact", "exact"] and [len(it) for it in ev] == [2, 1]
+    assert sorted(np.concatenate([it.indices for it in ev]).tolist()) == list(range(129))
+    assert DS.DeviceBatches(Fake(7), 2, device="cpu", fov=70).keep_w == int(640 * 70 / 360)     # train_VIGOR.py:177
+
+
+def test_seeded_draws_do_not_depend_on_the_decode_threads(tmp_path):
+    """The random choices of a chunk are drawn on the producer thread in index order, so two seeded iterations with 8 decode
+    threads agree with each other and with a sequential pass."""
+    make_vigor_tree(str(tmp_path))
+
+    def run(workers):
+        ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=True, pos_only=False, ori_noise=180, seed=5)
+        it = DS.DeviceBatches(ds, 4, device="cpu", workers=workers, targets=False)
+        out = []
+        with __import__("concurrent.futures").futures.ThreadPoolExecutor(max_workers=workers) as pool:
+            for i in range(0, len(it.indices), 4):
+                out += [(s["index"], s["roll"], s["angle_deg"], s["center"]) for s in it._decode_batch(pool, it.indices[i:i + 4])]
+        return out
+
+    a, b, c = run(8), run(8), run(1)
+    assert a == b == c and len(a) == 12
+    ds = DS.VIGORPairs(str(tmp_path), split="samearea", train=True, pos_only=False, ori_noise=180, seed=5)
+    seq = [ds.sample(i) for i in range(12)]
+    assert [(s["index"], s["roll"], s["angle_deg"], s["center"]) for s in seq] == a
+
+
+def test_malformed_label_line_and_fixture_length_raise(tmp_path):
+    import pytest
+    make_vigor_tree(str(tmp_path))
+    with pytest.raises(ValueError, match="random_orientation has 13 entries for 12"):
+        DS.VIGORPairs(str(tmp_path), split="samearea", train=False, random_orientation=np.zeros(13))
+    path = os.path.join(str(tmp_path), "splits_new", DS.CITIES[("samearea", True)][0], "same_area_balanced_train.txt")
+    lines = open(path).read().splitlines()
+    open(path, "w").write("\n".join(lines[:1] + ["p_short.jpg s_x.png 1.0"] + lines[1:]) + "\n")
+    with pytest.raises(ValueError, match=r"same_area_balanced_train.txt:2: expected 13 fields"):
+        DS.VIGORPairs(str(tmp_path), split="samearea", train=True)
 
 
 # ---- KITTI ------------------------------------------------------------------------------------------------------------

@@ -56,8 +56,14 @@ def test_graphed_train_step_matches_eager_and_trains(synth_sd):
     # a few steps with the eager optimizer: the loss moves and stays finite, the re-pack inside the graph follows the weights
     opt = optim.Adam(net.parameters(), lr=1e-4)
     losses_seen = []
-    for _ in range(3):
+    static = [p.grad for p in net.parameters()]
+    for it in range(3):
+        if it == 1:
+            opt.zero_grad(set_to_none=True)       # detaches p.grad; the next replay re-attaches the tensors it writes
         loss = step()
+        assert all(p.grad is g for p, g in zip(net.parameters(), static))
         opt.step()
         losses_seen.append(float(loss))
+    step.zero_grad()
+    assert all(g is None or float(g.abs().max()) == 0.0 for g in static)
     assert all(x == x and abs(x) < 1e9 for x in losses_seen) and len(set(losses_seen)) > 1

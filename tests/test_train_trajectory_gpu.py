@@ -1,4 +1,4 @@
-"""A whole optimisation TRAJECTORY, not one gradient: 4 training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
+"""A whole optimisation TRAJECTORY, not one gradient: STEPS (3; 10 with CCVPE_SLOW_TESTS=1) training steps of CVM_VIGOR at B = 2 on the MI355X (device-side
 ground truth, train-mode forward with running-statistic updates, the reference's loss mix train_VIGOR.py:137-146, the HIP
 backward through the gradient arena, the one-launch Adam) against the CPU oracle driven by autograd + torch.optim.Adam on
 the same weights, pairs, drop_connect draws and targets.  Per-step gradients agree to ~1 % per tensor (golden_util
@@ -13,7 +13,9 @@ from oracle import ccvpe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-STEPS = 3      # (10 in round 2: 150 s of CPU oracle steps; 3 keeps the GPU suite inside its 900 s time box)
+import os
+# 10 steps in round 2 (150 s of CPU oracle steps); 3 keep the GPU suite inside its 900 s time box, CCVPE_SLOW_TESTS=1 runs the 10
+STEPS = 10 if os.environ.get("CCVPE_SLOW_TESTS") == "1" else 3
 LR = 1e-4                      # train_VIGOR.py:104
 
 
@@ -24,7 +26,7 @@ def _loss_mix(mod, out, gt, gt_flat, gt_ori, labels):
     return mod[1](out[0], gt_flat) + 1e4 * nce / 6 + 1e1 * mod[2](out[2], gt_ori, gt)
 
 
-def test_ten_step_trajectory_vs_oracle_and_torch_adam(synth_sd):
+def test_trajectory_vs_oracle_and_torch_adam(synth_sd):
     from ccvpe_amd import harness, losses, models, optim, targets
     c = G.TRAIN_CASE
     batch = c["batch"]
