@@ -16,6 +16,12 @@ FORWARD_CASES = {
                          batch=1, grd="vigor"),
     "vigor_prior180_fov180": dict(kind="vigor", ori_noise=180, circular=False, wseed=0,
                                   pseed=78, batch=1, grd="vigor_fov180"),
+    # the remaining ori_prior shapes at FoV 360 (models.py:489-511): ori_noise = 180 -> 21 shifts (+-10 coincide when L = C),
+    # ori_noise = 72 -> 9 shifts; score1 keeps its 20 channels for the orientation decoder
+    "vigor_prior180": dict(kind="vigor", ori_noise=180, circular=True, wseed=0, pseed=79,
+                           batch=1, grd="vigor"),
+    "vigor_prior72": dict(kind="vigor", ori_noise=72, circular=True, wseed=0, pseed=80,
+                          batch=1, grd="vigor"),
     "kitti": dict(kind="kitti", ori_noise=None, circular=False, wseed=1, pseed=5,
                   batch=1, grd="kitti"),
     # CVM_OxfordRobotCar: 154x231 ground image, centred matching window

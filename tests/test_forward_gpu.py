@@ -1,6 +1,7 @@
 """Whole-path parity on the MI355X: the drop-in modules (ccvpe_amd.models) against the golden
 vectors generated from the reference and against the CPU oracle on the same seeded inputs.
-Tolerance (north_star): 1e-3 relative on heat-map logits, arg-max pixel exact."""
+Tolerance: north_star asks for 1e-3 relative on heat-map logits with the arg-max pixel exact; the fp32 path is held to what
+it actually delivers — 1e-5 of max |logit| (observed ~1e-6), so a regression of one order of magnitude fails."""
 import pytest
 import torch
 
@@ -10,7 +11,8 @@ from oracle import ccvpe_oracle as O
 
 pytestmark = pytest.mark.gpu
 
-LOGIT_RTOL = 1e-3
+LOGIT_RTOL = 1e-5          # x max |logit| (norm-wise); observed ~1e-6
+SCORE_ATOL = 2e-5          # matching scores are cosines in [-1, 1]
 
 
 def build(case, synth_sd):
@@ -47,13 +49,12 @@ def test_forward_vs_reference_golden(name, synth_sd):
     G.assert_close(got["logits_s4"], want["logits_s4"], 0, LOGIT_RTOL * scale, "logits")
     G.assert_close(got["top4_val"], want["top4_val"], 0, LOGIT_RTOL * scale, "top4")
     G.assert_close(got["heat_sum"], want["heat_sum"], 1e-4, 0, "heatmap sums to 1")
-    G.assert_close(got["heat_at_top4"], want["heat_at_top4"], 5e-3, 0, "heatmap@top4")
-    G.assert_close(got["ori_at_argmax"], want["ori_at_argmax"], 0, 5e-3, "ori@argmax")
+    G.assert_close(got["heat_at_top4"], want["heat_at_top4"], 1e-3, 0, "heatmap@top4")
+    G.assert_close(got["ori_at_argmax"], want["ori_at_argmax"], 0, 1e-4, "ori@argmax")
     for i in range(1, 7):
         assert got["score%d" % i].shape == want["score%d" % i].shape
-        s = abs(want["score%d" % i]).max()
-        G.assert_close(got["score%d" % i], want["score%d" % i], 0, 1e-3 * s, "score%d" % i)
-        G.assert_close(got["score%d_mean" % i], want["score%d_mean" % i], 0, 1e-3 * s, "score mean")
+        G.assert_close(got["score%d" % i], want["score%d" % i], 0, SCORE_ATOL, "score%d" % i)
+        G.assert_close(got["score%d_mean" % i], want["score%d_mean" % i], 0, SCORE_ATOL, "score mean")
 
 
 @pytest.mark.parametrize("case", [
@@ -74,9 +75,9 @@ def test_forward_vs_oracle_batch2(case, synth_sd):
     assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
     assert rel_err(out[0], ref[0]) < LOGIT_RTOL
     assert torch.equal(out[0].argmax(1).cpu(), ref[0].argmax(1)), "arg-max pixel differs"
-    assert rel_err(out[1], ref[1]) < 5e-3
+    assert rel_err(out[1], ref[1]) < 1e-3
     for a, b in zip(out[3:], ref[3:]):
-        assert rel_err(a, b) < 1e-3
+        assert float((a.cpu() - b).abs().max()) < SCORE_ATOL
     # orientation: compare where the un-normalised vector is not degenerate -> angle error
     cos = (out[2].cpu() * ref[2]).sum(1).clamp(-1, 1)
     frac_bad = (cos < 0.9999).float().mean().item()

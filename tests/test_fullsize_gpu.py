@@ -3,14 +3,23 @@ every parity test elsewhere runs B <= 3, so the tile-tail, XCD-remap and split-K
 are pinned here by size-independent properties:
   * permutation invariance, BIT-exact: sample i of the batch gives the same 9 outputs wherever it sits in the batch
     (tile position, XCD assignment and workgroup order must not leak into the arithmetic);
-  * small-batch agreement: sample i run alone (B = 1: split-K + unfused level-6 path, i.e. a different summation order)
-    agrees within the tolerance of that re-ordering and has the same arg-max pixel;
+  * the ORACLE on samples {0, B/2 - 1, B - 1} alone: eval-mode samples are independent (models.py:150-343 has no cross-sample
+    op), so the CPU oracle run on those three samples IS the expected value of the benched batch at those positions — fp32:
+    logits within 1e-5 of scale, arg-max exact, scores within 2e-5, orientation at the arg-max; bf16: the bf16 bounds of
+    tests/test_bf16_gpu.py (logit error <= 6e-3 of the range, arg-max equal unless the oracle's top-1 / top-2 margin is
+    inside twice that bound);
+  * small-batch agreement: sample i run alone on the HIP path (B = 1: split-K + unfused level-6 path, i.e. a different
+    summation order) agrees within the tolerance of that re-ordering and has the same arg-max pixel;
   * heat-map rows sum to 1, matching scores lie in [-1, 1], the orientation field has unit norm;
   * the hipGraph replay at B = 256 is bit-identical to the eager forward."""
 import pytest
 import torch
 
 from ccvpe_amd import synth
+from oracle import ccvpe_oracle as O
+
+FP32_LOGIT_RTOL = 1e-5          # of max |logit|   (observed ~1e-6)
+BF16_LOGIT_BOUND = 6e-3         # of the logit range (tests/test_bf16_gpu.py LOGIT_ERR_BOUND)
 
 pytestmark = pytest.mark.gpu
 
@@ -47,6 +56,38 @@ def _check_alone(net, grd, sat, out, picks, rtol):
             assert float((a[0] - b[i]).abs().max()) <= max(rtol, 2e-5) * 10
 
 
+def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision):
+    """Samples `picks` of the benched batch against the CPU oracle run on those samples alone."""
+    idx = torch.tensor(list(picks))
+    with torch.no_grad():
+        ref = O.forward(synth_sd("vigor", 0), grd[idx].cpu(), sat[idx].cpu(), "vigor", circular, ori_noise)
+    got = [t[idx.to(t.device)].cpu() for t in out]
+    assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref]
+    for j, i in enumerate(picks):
+        rl, gl = ref[0][j], got[0][j]
+        ia, ib = int(rl.argmax()), int(gl.argmax())
+        if precision == "fp32":
+            err = float((gl - rl).abs().max() / rl.abs().max())
+            assert err <= FP32_LOGIT_RTOL, "sample %d of the batch vs the oracle: logits rel err %.3e" % (i, err)
+            assert ia == ib, "arg-max pixel of sample %d differs from the oracle's" % i
+            for a, b in zip(got[3:], ref[3:]):
+                assert float((a[j] - b[j]).abs().max()) <= 2e-5
+            assert float((got[2][j].reshape(2, -1)[:, ia] - ref[2][j].reshape(2, -1)[:, ia]).abs().max()) <= 1e-4
+            assert float((got[1][j].reshape(-1)[ia] - ref[1][j].reshape(-1)[ia]).abs() / ref[1][j].reshape(-1)[ia]) <= 1e-3
+        else:
+            rng = float(rl.max() - rl.min())
+            err = float((gl - rl).abs().max()) / rng
+            assert err <= BF16_LOGIT_BOUND, "sample %d (bf16) vs the oracle: logit error %.3e of the range" % (i, err)
+            top2 = rl.topk(2)[0]
+            margin = float(top2[0] - top2[1]) / rng
+            assert ia == ib or margin <= 2 * BF16_LOGIT_BOUND, "bf16 arg-max of sample %d moved at margin %.2e" % (i, margin)
+            if ia != ib:
+                assert float(rl[ia] - rl[ib]) / rng <= 2 * BF16_LOGIT_BOUND
+            for a, b in zip(got[3:], ref[3:]):
+                assert float((a[j] - b[j]).abs().max()) <= 2e-2
+            assert float((got[2][j].reshape(2, -1)[:, ia] - ref[2][j].reshape(2, -1)[:, ia]).abs().max()) <= 3e-2
+
+
 @pytest.mark.parametrize("name,ori_noise,circular,gshape,batch,precision,rtol", [
     ("C1 fp32 B=64", 0, True, "vigor", 64, "fp32", 1e-4),
     ("C2 bf16 B=32 N_rot=20", None, True, "vigor", 32, "bf16", 2e-2),
@@ -66,6 +107,7 @@ def test_batch_position_invariance_at_bench_size(synth_sd, name, ori_noise, circ
     for k, (a, b) in enumerate(zip(out, out_p)):
         assert torch.equal(a[perm], b), "output %d of %s depends on the sample's position in the batch" % (k, name)
     _check_alone(net, grd, sat, out, (0, batch // 2 - 1, batch - 1), rtol)
+    _check_oracle(synth_sd, out, grd, sat, (0, batch // 2 - 1, batch - 1), circular, ori_noise, precision)
 
 
 def test_c4_graph_replay_at_b256_matches_eager_and_subbatch(synth_sd):
@@ -83,3 +125,4 @@ def test_c4_graph_replay_at_b256_matches_eager_and_subbatch(synth_sd):
         assert torch.equal(a, b), "hipGraph replay differs from eager in output %d" % k
     del graphed, rep
     _check_alone(net, grd, sat, eager, (0, 101, 255), 2e-2)
+    _check_oracle(synth_sd, eager, grd, sat, (0, 127, 255), False, 180, "bf16")
