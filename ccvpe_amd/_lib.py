@@ -45,6 +45,16 @@ class UpconvDesc(ctypes.Structure):
     ]
 
 
+class TailDesc(ctypes.Structure):
+    """struct ccvpe_tail_desc (include/ccvpe_hip.h)."""
+    _fields_ = [
+        ("x", c_void_p), ("w", c_void_p), ("shift9", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("out", c_void_p),
+        ("batch", c_int), ("h1", c_int), ("w1", c_int),
+        ("c0", c_int), ("ld0", c_int), ("kpad", c_int),
+        ("cout", c_int), ("normalize", c_int),
+    ]
+
+
 # name -> (restype, argtypes); must list EVERY symbol include/ccvpe_hip.h declares
 # (tests/test_abi.py parses the header and checks this table and the .so against it).
 PROTOTYPES = {
@@ -53,6 +63,8 @@ PROTOTYPES = {
     "ccvpe_multi_copy_f32": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p]),
     "ccvpe_gather_repack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ccvpe_gather_repack_chunk": (c_int, []),
+    "ccvpe_tail512_f32": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
+    "ccvpe_tail512_bf16": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),

@@ -351,14 +351,17 @@ static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* 
 // ---------------------------------------------------------------------------------------------
 // SE gate (model.py:113-118): gate = sigmoid(W2 . swish(W1 . mean + b1) + b2).
 // Latency-bound (a few 100 KFLOP per sample), so the work is spread over G workgroups per sample:
-// each recomputes the cheap squeeze (mean) and FC1 and owns a 128-channel slice of FC2.
+// each recomputes the cheap squeeze (mean) and FC1 and owns `nsl` 128-channel slices of FC2.  Every workgroup re-reads all of
+// W1 (Cs x C fp32: 221 KB for the 1152-channel blocks) from L2, so G is chosen against the batch: with B >= 64 samples
+// C/128 = 9 workgroups per sample were 576 x 221 KB = 127 MB of L2 reads per launch (23 us for microseconds of arithmetic);
+// the host asks for about 256 workgroups per launch: G = ceil(256 / B), clamped to [1, C/128].
 // ---------------------------------------------------------------------------------------------
 constexpr int SE_SLICE = 128;
 
 __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int nblk, float inv_hw,
                                                       const float* __restrict__ w1, const float* __restrict__ b1,
                                                       const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ gate, int C, int Cs) {
+                                                      float* __restrict__ gate, int C, int Cs, int nsl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[C^4] | z[Cs^4] | red[256][4]
   float* mean = sm;
   float* z = sm + ((C + 3) & ~3);
@@ -449,17 +452,20 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     }
   }
   __syncthreads();
-  // FC2 slice: 2 threads per channel split the Cs sum (w2 is [Cs][C]: coalesced over c)
-  const int c = blockIdx.x * SE_SLICE + (tid & (SE_SLICE - 1));
+  // FC2 slices: 2 threads per channel split the Cs sum (w2 is [Cs][C]: coalesced over c)
   const int hsel = tid >> 7;                 // 0 or 1
-  float s = 0.f;
-  if (c < C) {
+  for (int u = 0; u < nsl; ++u) {
+    const int c = (blockIdx.x * nsl + u) * SE_SLICE + (tid & (SE_SLICE - 1));
+    float s = 0.f;
+    if (c < C) {
 #pragma unroll 8
-    for (int j = hsel; j < Cs; j += 2) s = fmaf(w2[(size_t)j * C + c], z[j], s);
+      for (int j = hsel; j < Cs; j += 2) s = fmaf(w2[(size_t)j * C + c], z[j], s);
+    }
+    if (u) __syncthreads();                  // red[] of the previous slice has been consumed
+    red[tid] = s;
+    __syncthreads();
+    if (hsel == 0 && c < C) gate[(size_t)b * C + c] = sigmoidf(red[tid] + red[tid + SE_SLICE] + b2[c]);
   }
-  red[tid] = s;
-  __syncthreads();
-  if (hsel == 0 && c < C) gate[(size_t)b * C + c] = sigmoidf(red[tid] + red[tid + SE_SLICE] + b2[c]);
 }
 
 }  // namespace ccvpe
@@ -562,7 +568,11 @@ extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, cons
                                  const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
   if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
   const size_t smem = (size_t)(((C + 3) & ~3) + ((Cs + 3) & ~3) + 1024) * sizeof(float);
-  hipLaunchKernelGGL(se_gate_kernel, dim3((C + SE_SLICE - 1) / SE_SLICE, B), dim3(256), smem, (hipStream_t)stream, part,
-                     nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs);
+  const int slices = (C + SE_SLICE - 1) / SE_SLICE;
+  int g = (256 + B - 1) / B;                 // workgroups per sample (see the kernel's comment)
+  g = g < 1 ? 1 : (g > slices ? slices : g);
+  const int nsl = (slices + g - 1) / g;
+  hipLaunchKernelGGL(se_gate_kernel, dim3((slices + nsl - 1) / nsl, B), dim3(256), smem, (hipStream_t)stream, part,
+                     nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs, nsl);
   return check_launch("se_gate_kernel");
 }

@@ -1,0 +1,327 @@
+// tail512_kernel: the whole 512 x 512 level of a decoder in ONE launch.
+//
+//   loc: deconv1 (k2 s2) -> conv1.0 3x3 + bias -> ReLU -> conv1.2 3x3 (16 -> 1) + bias            models.py:124-127,319
+//   ori: deconv1_ori     -> conv1_ori.0        -> ReLU -> conv1_ori.2 3x3 (16 -> 2) + bias -> F.normalize   models.py:145-148,341
+//
+// Before: upconv_halo_kernel<T,4,1,1> (folded deconv + conv.0, N = 16) wrote a [B,512,512,16] tensor (1.07 GB in fp32 at
+// B = 64) that head_conv_kernel read straight back: 1.23 + 0.45 ms per decoder in the fp32 forward, bound by neither roof.
+// Here the 16-channel tensor never leaves the chip — and never even reaches LDS:
+//
+//   stage 1  (MFMA, the FLOPs)  per output parity (py,px) the folded deconv + conv.0 is a GEMM over LOW-RES positions with
+//            2 x 2 taps (upconv_impl.h): K = 4 * c0, N = 16.  A wave owns ONE parity and keeps that parity's whole W
+//            (16 x 4*c0) in REGISTERS as MFMA A-fragments (48 VGPRs at c0 = 48): the K loop reads only pixel fragments from
+//            an LDS halo tile of x ((TY+2) x (TX+2) low-res pixels, one 64-byte channel chunk at a time, double buffered).
+//            No W traffic, no W barrier.  The accumulator of a 16-position tile ends as (lane = position, 4 consecutive
+//            channels per lane group): C layout of v_mfma_f32_16x16x4_f32.
+//   stage 2  (MFMA, +8 %)       conv.2 is applied in SCATTER form: s[t][pos] = sum_c w2[t][c] * mid[c][pos] for the 9 taps t is
+//            one more 16x16 MFMA per tile whose B operand IS the stage-1 accumulator (bias + ReLU applied in place; the k
+//            permutation "lane group q supplies channels 4q..4q+3" is exactly the C layout), A = w2 as [tap][channel].
+//   stage 3  (LDS gather)       the 9 tap planes s[t] of the tile's (2TY+2) x (2TX+2) mid grid go to LDS (aliasing the dead x
+//            buffers); out[Y][X] = b2 + sum_t s[t][Y+ky-1][X+kx-1] is 9 conflict-free ds_read_b32 per output, fixed order.
+//
+// The tile's mid grid has a one-pixel apron (conv.2 needs mid at Y-1 .. Y+1), so stage 1 computes (TY+1) x (TX+1) positions per
+// parity for TY x TX useful ones; positions are numbered linearly and cut into 16-position MFMA tiles with PER-LANE LDS
+// addresses, so only the last tile of a parity is ragged.  Mid pixels outside the image are zeros (conv.2's padding); x pixels
+// outside the image are zeros of the deconv output (the 9 border classes of shift9 carry the deconv bias, upconv_impl.h).
+//
+// Element type T = storage AND matrix type of stage 1: float (v_mfma_f32_16x16x4_f32, exact fp32) or bf16
+// (v_mfma_f32_16x16x32_bf16, fp32 accumulate); stage 2/3 are fp32 in both.  Same LDS byte geometry for both (a pixel row = one
+// 64-byte chunk = 16 fp32 / 32 bf16 channels, pitch 80 bytes).
+#include "conv_common.h"
+
+namespace ccvpe {
+
+struct TailParams {
+  const void* x;
+  const void* w;
+  const float* shift9;
+  const float* w2;
+  const float* b2;
+  float* out;
+  int H1, W1, c0, ld0, Kpad, normalize;
+  int tiles_x, tiles_y, tiles_total;
+};
+
+template <typename T, int COUT, int NCH, int TY, int TX, int WPP>
+struct TailGeom {
+  static constexpr int NW = 4 * WPP;
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int PW = TX + 1;
+  static constexpr int P = (TY + 1) * PW;            // stage-1 positions per parity
+  static constexpr int NTILE = (P + 15) / 16;
+  static constexpr int TPW = (NTILE + WPP - 1) / WPP; // 16-position tiles per wave
+  static constexpr int HR = TY + 2, HC = TX + 2, HPX = HR * HC;
+  static constexpr int LD = 20;                      // floats per staged pixel row (64 B + 16 B pad)
+  static constexpr int XBUF = HPX * LD;              // floats per x chunk buffer
+  static constexpr int NXB = NCH > 1 ? 2 : 1;
+  static constexpr int SH = 2 * TY + 2, SW = 2 * TX + 2, SPL = SH * SW;   // one tap plane of the mid grid
+  static constexpr int NPL = 10;                     // 9 tap planes + one junk plane (lanes whose tap index is >= 9 store there)
+  static constexpr int MAIN = (NXB * XBUF > NPL * SPL) ? NXB * XBUF : NPL * SPL;
+  static constexpr int LDS_BYTES = (MAIN + 9 * 16) * 4;
+  static constexpr int NOUT = (4 * TY * TX) / NTHR;  // outputs per thread in stage 3
+};
+
+template <typename T, int COUT, int NCH, int TY, int TX, int WPP>
+__global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams p) {
+  using G = TailGeom<T, COUT, NCH, TY, TX, WPP>;
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;                          // channels per 64-byte chunk
+  constexpr int NTHR = G::NTHR, PW = G::PW, P = G::P, TPW = G::TPW;
+  constexpr int HC = G::HC, HPX = G::HPX, LD = G::LD, XBUF = G::XBUF;
+  constexpr int SW = G::SW, SPL = G::SPL;
+  constexpr int H_IT = (HPX * 4 + NTHR - 1) / NTHR;
+  static_assert((4 * TY * TX) % NTHR == 0, "stage 3 hands every thread the same number of outputs");
+
+  extern __shared__ __attribute__((aligned(16))) float t5_sm[];
+  float* Xs = t5_sm;                                 // [NXB][HPX][LD]   (stage 1)
+  float* Sp = t5_sm;                                 // [9][SH][SW]      (stage 2/3, aliases Xs)
+  float* Sh9 = t5_sm + G::MAIN;                      // [9][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = sgpr(tid >> 6);
+  const int par = wave & 3, wsub = wave >> 2;
+  const int py = par >> 1, px = par & 1;
+  const int pix = lane & 15, q = lane >> 4;
+
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
+  const int tx = tile % p.tiles_x;
+  const int ty = (tile / p.tiles_x) % p.tiles_y;
+  const int b = tile / (p.tiles_x * p.tiles_y);
+  const int y0 = ty * TY, x0 = tx * TX;              // low-res origin of the tile
+  const int H2 = 2 * p.H1, W2 = 2 * p.W1;
+  const T* xg = reinterpret_cast<const T*>(p.x);
+
+  for (int i = tid; i < 9 * 16; i += NTHR) Sh9[i] = p.shift9[i];
+
+  // ---- W of this wave's parity: MFMA A-fragments in registers ------------------------------------------------------
+  f32x4 wr[4][NCH];
+  {
+    const T* wp = reinterpret_cast<const T*>(p.w) + ((size_t)par * 16 + pix) * p.Kpad;
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int ch = c * SK + q * E;                 // (all 4 * NCH loads in flight together: clamped address + mask, no branch)
+        wr[tap][c] = *reinterpret_cast<const f32x4*>(wp + (ch < p.c0 ? tap * p.c0 + ch : 0));
+      }
+#pragma unroll
+    for (int tap = 0; tap < 4; ++tap)
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) wr[tap][c] = keep_if(wr[tap][c], c * SK + q * E < p.c0);
+  }
+  // conv.2 as [tap][channel]: lane (tap = pix, q) holds channels 4q .. 4q+3 of output o
+  f32x4 w2f[COUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+    w2f[o] = keep_if(*reinterpret_cast<const f32x4*>(p.w2 + (o * 9 + min(pix, 8)) * 16 + q * 4), pix < 9);
+  }
+
+  // ---- halo staging: thread -> (halo pixel, 16-byte piece); coordinates are recomputed per chunk (NCH <= 3 times) rather
+  // than held in registers across the matrix loop ------------------------------------------------------------------------
+  const int hsub = tid & 3;                          // NTHR % 4 == 0: the piece index is the same for every `it`
+  f32x4 h_reg[H_IT];
+  unsigned h_keep = 0;
+  const int ld0s = sgpr(p.ld0);
+  auto load_halo = [&](int c) {                      // raw loads from clamped addresses, masked at the LDS store (STAGING RULE)
+    const int ch = c * SK + hsub * E;
+    h_keep = 0;
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) {
+      const int pxl = (tid + NTHR * it) >> 2;
+      const int hy = pxl / HC, hx = pxl - hy * HC;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const bool ok = pxl < HPX && (unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1 && ch < p.c0;
+      h_reg[it] = *reinterpret_cast<const f32x4*>(xg + (ok ? (size_t)((b * p.H1 + iy) * p.W1 + ix) * ld0s + ch : 0));
+      h_keep |= ok ? (1u << it) : 0u;
+    }
+  };
+  auto store_halo = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) {
+      const int pxl = (tid + NTHR * it) >> 2;
+      if (pxl < HPX) *reinterpret_cast<f32x4*>(Xs + buf * XBUF + pxl * LD + hsub * 4) = keep_if(h_reg[it], (h_keep >> it) & 1u);
+    }
+  };
+
+  // ---- stage 1 ------------------------------------------------------------------------------------------------------
+  // position of (tile i, lane): pt = (wsub*TPW + i)*16 + pix -> (iy, ix) in the (TY+1) x (TX+1) grid of this parity; its four
+  // taps are halo pixels (iy + du, ix + dv) for BOTH parities (the parity only moves the grid's origin)
+  int fbase[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int pc = min((wsub * TPW + i) * 16 + pix, P - 1);
+    const int iy = pc / PW, ix = pc - iy * PW;
+    fbase[i] = (iy * HC + ix) * LD + q * 4;
+  }
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  load_halo(0);
+  store_halo(0);
+  __syncthreads();
+  // The matrix loop is software-pipelined BY HAND: left to itself the compiler (at the register limit) issues each fragment read
+  // directly in front of the four MFMAs that consume it (ds_read, s_waitcnt lgkmcnt(0), 4 x v_mfma: an exposed LDS round trip
+  // per 128 cycles of matrix work) and sinks the next chunk's global loads below the MFMAs.  Here: the next chunk's halo loads
+  // go out first; a step = (pair of position tiles, tap); the fragments of step s+1 are requested before the MFMAs of step s;
+  // the two tiles of a pair alternate so that no MFMA waits for the accumulator of its predecessor.
+  constexpr int NPAIR = (TPW + 1) / 2, NS = NPAIR * 4;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    if (c + 1 < NCH) load_halo(c + 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* xb = Xs + (c & 1) * XBUF;
+    f32x4 fr[2][2];
+    auto read_step = [&](int s, f32x4* dst) {
+      const int g = s >> 2, tap = s & 3;
+      const int toff = ((tap >> 1) * HC + (tap & 1)) * LD;
+      dst[0] = *reinterpret_cast<const f32x4*>(xb + fbase[2 * g] + toff);
+      if (2 * g + 1 < TPW) dst[1] = *reinterpret_cast<const f32x4*>(xb + fbase[2 * g + 1] + toff);
+    };
+    read_step(0, fr[0]);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int g = s >> 2, tap = s & 3;
+      if (s + 1 < NS) read_step(s + 1, fr[(s + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);             // the reads above stay above this step's MFMAs
+      const f32x4 wv = wr[tap][c];
+      const f32x4 f0 = fr[s & 1][0], f1 = fr[s & 1][1];
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          acc[2 * g] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kk], f0[kk], acc[2 * g], 0, 0, 0);
+          if (2 * g + 1 < TPW) acc[2 * g + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[kk], f1[kk], acc[2 * g + 1], 0, 0, 0);
+        }
+      } else {
+        acc[2 * g] = mfma_stage<T>(wv, f0, acc[2 * g]);
+        if (2 * g + 1 < TPW) acc[2 * g + 1] = mfma_stage<T>(wv, f1, acc[2 * g + 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (c + 1 < NCH) {
+      store_halo((c + 1) & 1);
+      __syncthreads();
+    }
+  }
+  __syncthreads();                                   // every wave is done with the x buffers: the tap planes alias them
+  __builtin_amdgcn_sched_barrier(0);                 // (keeps the epilogue's address arithmetic out of the matrix loop's registers)
+
+  // ---- stage 2 + 3 ----------------------------------------------------------------------------------------------------
+  // bias (border class of the mid pixel) + ReLU in place; mid pixels outside the image are conv.2's zero padding
+#pragma unroll
+  for (int i = 0; i < TPW; ++i) {
+    const int pc = min((wsub * TPW + i) * 16 + pix, P - 1);
+    const int iy = pc / PW, ix = pc - iy * PW;
+    const int Y = 2 * (y0 + iy) - py, X = 2 * (x0 + ix) - px;
+    const bool inside = (unsigned)Y < (unsigned)H2 && (unsigned)X < (unsigned)W2;
+    const int rc = Y <= 0 ? 0 : (Y >= H2 - 1 ? 2 : 1);
+    const int cc = X <= 0 ? 0 : (X >= W2 - 1 ? 2 : 1);
+    const f32x4 sh = *reinterpret_cast<const f32x4*>(Sh9 + (rc * 3 + cc) * 16 + q * 4);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = inside ? fmaxf(acc[i][r] + sh[r], 0.f) : 0.f;
+  }
+  float res[COUT][G::NOUT];
+#pragma unroll
+  for (int o = 0; o < COUT; ++o) {
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s = __builtin_amdgcn_mfma_f32_16x16x4f32(w2f[o][r], acc[i][r], s, 0, 0, 0);
+      // lane (q, pix) now holds taps 4q .. 4q+3 of position pix
+      const int pt = (wsub * TPW + i) * 16 + pix;
+      const int iy = pt / PW, ix = pt - iy * PW;
+      float* dst = Sp + (2 * iy + 1 - py) * SW + (2 * ix + 1 - px);
+      if (pt < P) {                                  // (only the last tile of a parity is ragged)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[min(4 * q + r, 9) * SPL] = s[r];     // tap index >= 9: the junk plane
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < G::NOUT; ++k) {
+      const int e = tid + NTHR * k;
+      const int Yo = e / (2 * TX), Xo = e - Yo * (2 * TX);
+      float v = p.b2[o];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) v += Sp[t * SPL + (Yo + t / 3) * SW + Xo + t % 3];
+      res[o][k] = v;
+    }
+    if (o + 1 < COUT) __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < G::NOUT; ++k) {
+    const int e = tid + NTHR * k;
+    const int Yo = e / (2 * TX), Xo = e - Yo * (2 * TX);
+    if (COUT == 2 && p.normalize) {                  // F.normalize(p=2, dim=1, eps=1e-12)
+      const float n = fmaxf(sqrtf(res[0][k] * res[0][k] + res[COUT - 1][k] * res[COUT - 1][k]), 1e-12f);
+      res[0][k] /= n;
+      res[COUT - 1][k] /= n;
+    }
+#pragma unroll
+    for (int o = 0; o < COUT; ++o)
+      p.out[((size_t)(b * COUT + o) * H2 + 2 * y0 + Yo) * W2 + 2 * x0 + Xo] = res[o][k];
+  }
+}
+
+template <typename T, int COUT, int NCH, int TY, int TX, int WPP>
+static int launch_tail(const TailParams& p0, int batch, hipStream_t stream) {
+  using G = TailGeom<T, COUT, NCH, TY, TX, WPP>;
+  TailParams p = p0;
+  p.tiles_x = p.W1 / TX;
+  p.tiles_y = p.H1 / TY;
+  const long total = (long)p.tiles_x * p.tiles_y * batch;
+  if (total <= 0 || total > 0x7fffffffL) return fail(CCVPE_EINVAL, "tail512: bad grid");
+  p.tiles_total = (int)total;
+  static bool attr_set = false;                      // one flag per instantiation
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)tail512_kernel<T, COUT, NCH, TY, TX, WPP>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "tail512: set smem attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((tail512_kernel<T, COUT, NCH, TY, TX, WPP>), dim3(p.tiles_total), dim3(G::NTHR), G::LDS_BYTES, stream, p);
+  return check_launch("tail512_kernel");
+}
+
+template <typename T>
+static int tail_any(const ccvpe_tail_desc* d, void* stream) {
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;
+  if (!d) return fail(CCVPE_EINVAL, "tail512: null desc");
+  if (d->c0 <= 0 || d->c0 % 8 || d->ld0 % E || d->ld0 < d->c0) return fail(CCVPE_EINVAL, "tail512: c0 %% 8, ld0 %% %d, ld0 >= c0 required", E);
+  if (d->kpad < 4 * d->c0) return fail(CCVPE_EINVAL, "tail512: kpad %d < 4 * c0", d->kpad);
+  if (d->cout != 1 && d->cout != 2) return fail(CCVPE_EINVAL, "tail512: cout must be 1 or 2");
+  if (!d->x || !d->w || !d->shift9 || !d->w2 || !d->b2 || !d->out) return fail(CCVPE_EINVAL, "tail512: null pointer");
+  if (!aligned16(d->x) || !aligned16(d->w) || !aligned16(d->w2) || !aligned16(d->shift9))
+    return fail(CCVPE_EINVAL, "tail512: pointers must be 16-byte aligned");
+  if (d->batch <= 0 || d->h1 <= 0 || d->w1 <= 0 || (long)d->batch * d->h1 * d->w1 > 0x1fffffffL) return fail(CCVPE_EINVAL, "tail512: bad shape");
+  if (d->h1 % 16 || d->w1 % 16) return fail(CCVPE_EINVAL, "tail512: h1 and w1 must be multiples of 16 (got %d x %d)", d->h1, d->w1);
+  TailParams p;
+  p.x = d->x; p.w = d->w; p.shift9 = d->shift9; p.w2 = d->w2; p.b2 = d->b2; p.out = d->out;
+  p.H1 = d->h1; p.W1 = d->w1; p.c0 = d->c0; p.ld0 = d->ld0; p.Kpad = d->kpad; p.normalize = d->normalize;
+  p.tiles_x = p.tiles_y = p.tiles_total = 0;
+  const int nch = (d->c0 + SK - 1) / SK;
+  hipStream_t st = (hipStream_t)stream;
+  // Workgroup tile: 16 x 16 low-res pixels, one wave per parity, two workgroups per CU (a workgroup's stage 2/3 runs under the
+  // other's matrix loop).  Measured against 32 x 16 with two waves per parity and one workgroup per CU (B = 64, tools/tail_probe.py):
+  // fp32 loc 1.11 vs 1.23 ms, fp32 ori 0.95 vs 1.01, bf16 0.38-0.45 vs 0.48-0.50 — the smaller apron does not pay for the lost overlap.
+#define CCVPE_TAIL(COUT_, NCH_) \
+  if (d->cout == COUT_ && nch == NCH_) return launch_tail<T, COUT_, NCH_, 16, 16, 1>(p, d->batch, st);
+  if constexpr (sizeof(T) == 4) {
+    CCVPE_TAIL(1, 2) CCVPE_TAIL(1, 3) CCVPE_TAIL(2, 2)      // loc: 33 / 41 channels (ld 40 / 48); ori: 32
+  } else {
+    CCVPE_TAIL(1, 1) CCVPE_TAIL(1, 2) CCVPE_TAIL(2, 1)      // bf16 chunks hold 32 channels
+  }
+#undef CCVPE_TAIL
+  return fail(CCVPE_EINVAL, "tail512: (cout %d, c0 %d) not instantiated (fp32: cout 1 with c0 <= 48, cout 2 with c0 <= 32; bf16: cout 1 "
+                            "with c0 <= 64, cout 2 with c0 <= 32)", d->cout, d->c0);
+}
+
+}  // namespace ccvpe
+
+using namespace ccvpe;
+
+extern "C" int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream) { return tail_any<float>(desc, stream); }
+extern "C" int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream) { return tail_any<bf16_t>(desc, stream); }

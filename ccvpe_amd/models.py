@@ -157,6 +157,8 @@ FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEV
 # K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
 # instead.  B = 64 keeps every level folded (level 6 has 4096 low-res pixels).
 FOLD_MIN_PIXELS = 4096
+# level 1 (512 x 512) of both decoders as ONE launch (csrc/tail512.hip); CCVPE_FUSE_TAIL=0 restores upconv + head conv (A/B runs)
+FUSE_TAIL = __import__("os").environ.get("CCVPE_FUSE_TAIL", "1") != "0"
 # train mode: replay the per-step weight re-pack as one hipGraph (see _CVMBase._packed); CCVPE_PACK_GRAPH=0 keeps it eager
 PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
 # train mode, fp32: the per-step re-pack as ONE gather launch (ccvpe_amd/repack.py); CCVPE_PACK_GATHER=0 keeps the graph replay
@@ -542,6 +544,9 @@ class _CVMBase(nn.Module):
             ov = pk.ori[j]
             hw = xo.shape[1]
             skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
+            if j == 5 and FUSE_TAIL and j in FOLD_LEVELS and ops.tail512_ok(hw, hw, ov.n_a):
+                # the whole 512 x 512 level in one launch: deconv1_ori + conv1_ori + F.normalize (models.py:145-148,341)
+                return ops.tail512(xo, ov.k, ov.fw, ov.fshift, ov.w_b, ov.b_b, 2, True, batch=batch, h1=hw, w1=hw)
             if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:
                 y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
                                   src1=skip, c1=ov.c1, act=ops.ACT_RELU)
@@ -663,6 +668,10 @@ class _CVMBase(nn.Module):
                 else:
                     scores_out.append(sc)
                 skip = sfeats_loc[SKIP_BLOCKS[j]] if j < 5 else None
+                if j == 5 and FUSE_TAIL and j in FOLD_LEVELS and ops.tail512_ok(hw, hw, lv.n_a):
+                    # the whole 512 x 512 level in one launch: deconv1 + conv1 -> logits (models.py:124-127,319)
+                    logits_map = ops.tail512(cat, lv.ldo, lv.fw, lv.fshift, lv.w_b, lv.b_b, 1, False, batch=batch, h1=hw, w1=hw)
+                    break
                 if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:   # deconv folded into conv.0: one GEMM per output parity
                     y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,
                                       src1=skip, c1=lv.c1, act=ops.ACT_RELU)

@@ -217,6 +217,41 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
     return dst
 
 
+def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1):
+    """The whole 512 x 512 decoder level in one launch (ccvpe_tail512_f32 / _bf16): folded deconv + conv.0 + ReLU + conv.2
+    (+ F.normalize for cout = 2).  x [B,h1,w1,ld0]; w_packed / shift9 from models._pack_upconv (n = 16, no skip);
+    w2 [cout,3,3,16], b2 [cout] fp32; returns [B,cout,2h1,2w1] fp32."""
+    lib = _lib.load()
+    dt = _act_dtype(x)
+    _chk(x, "x", dt)
+    _chk(w_packed, "w", dt)
+    for t, nm in ((shift9, "shift9"), (w2, "w2"), (b2, "b2")):
+        _chk(t, nm)
+    if tuple(w2.shape) != (cout, 3, 3, 16) or tuple(shift9.shape) != (9, 16) or w_packed.shape[0] != 4 or w_packed.shape[1] != 16:
+        raise ValueError("tail512: w [4,16,kpad], shift9 [9,16], w2 [cout,3,3,16] expected")
+    out = torch.empty((batch, cout, 2 * h1, 2 * w1), device=x.device, dtype=torch.float32)
+    d = _lib.TailDesc()
+    d.x, d.w, d.shift9, d.w2, d.b2, d.out = _ptr(x), _ptr(w_packed), _ptr(shift9), _ptr(w2), _ptr(b2), _ptr(out)
+    d.batch, d.h1, d.w1 = batch, h1, w1
+    d.c0, d.ld0, d.kpad = c0, x.shape[-1], w_packed.shape[-1]
+    d.cout, d.normalize = cout, int(bool(normalize))
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
+    fn = lib.ccvpe_tail512_f32 if dt == torch.float32 else lib.ccvpe_tail512_bf16
+    check(fn(ctypes.byref(d), _stream()), "ccvpe_tail512")
+    if rec is not None:
+        m = batch * h1 * w1 * 4
+        esz = 4.0 if dt == torch.float32 else 2.0
+        rec.end("tail512_kernel<%s,%d>" % ("f32" if dt == torch.float32 else "bf16", cout), "tail M%d Keff%d" % (m, 4 * c0),
+                2.0 * m * 16 * (4 * c0 + 9 * cout), esz * batch * h1 * w1 * c0 + 4.0 * m * cout, ev0)
+    return out
+
+
+def tail512_ok(h1, w1, n_a):
+    """Shapes the fused 512 x 512 level handles (everything else runs ccvpe_upconv3x3 + ccvpe_head_conv3x3)."""
+    return n_a == 16 and h1 % 16 == 0 and w1 % 16 == 0
+
+
 def stem_conv(x_nchw, w, scale, shift, circular, out_dtype=torch.float32):
     lib = _lib.load()
     for t, nm in ((x_nchw, "x"), (w, "w"), (scale, "scale"), (shift, "shift")):

@@ -130,6 +130,30 @@ int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* desc, void* stream);
 int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* desc, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * The whole 512 x 512 level of a decoder in one launch (csrc/tail512.hip):
+ *   loc: x = deconv1(x); x = conv1(x)  [3x3 + ReLU + 3x3, 16 -> 16 -> 1]      models.py:124-127 (logits, :319)
+ *   ori: x = deconv1_ori(x); x = conv1_ori(x) [16 -> 16 -> 2]; F.normalize    models.py:145-148,341
+ * x [B,h1,w1,ld0] low-res input (c0 channels incl. zero padding; fp32 or bf16), w / shift9 as for ccvpe_upconv3x3
+ * with n = 16 and c1 = 0 ([4][16][kpad], [9][16]), w2 [cout][3][3][16] fp32, b2 [cout], out [B,cout,2h1,2w1] fp32
+ * (NCHW).  The 16-channel intermediate is never written.  h1, w1 multiples of 16.  Same results as ccvpe_upconv3x3 +
+ * ccvpe_head_conv3x3 (fp32: to rounding; bf16: better — the intermediate is not rounded to bf16).
+ * ----------------------------------------------------------------------------------------- */
+typedef struct ccvpe_tail_desc {
+  const void* x;
+  const void* w;
+  const float* shift9;
+  const float* w2;
+  const float* b2;
+  float* out;
+  int batch, h1, w1;
+  int c0, ld0, kpad;
+  int cout, normalize;
+} ccvpe_tail_desc;
+
+int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream);
+int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * EfficientNet stem: 3x3 stride-2 conv on the NCHW image + folded BN + swish, NHWC out.
  * TF-"SAME" padding (0 before, 1 after) from the 224 schedule; `circular` wraps along W and
  * zero-pads along H.  efficientnet_pytorch/model.py:181-182,289; utils.py:254-282,318-358.

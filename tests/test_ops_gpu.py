@@ -240,6 +240,54 @@ def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf1
     close(nchw(got).float(), want, 2e-2 if bf16 else 1e-4, "upconv cp=%d" % cp)
 
 
+@pytest.mark.parametrize("cp,cref,cout,h1,w1,bf16", [
+    (48, 41, 1, 32, 48, False),      # VIGOR loc level 1: [X/|X| 40 | max score | pad], fp32 (the arg-max decides here)
+    (32, 32, 2, 16, 32, False),      # ori level 1, fp32
+    (40, 33, 1, 32, 16, False),      # KITTI loc level 1 (ld 40: the third chunk is half empty)
+    (32, 32, 2, 32, 32, True),       # ori level 1 in bf16 storage (one 32-channel chunk)
+    (48, 41, 1, 16, 16, True),       # bf16 loc (two chunks, the second half empty)
+    (32, 25, 1, 16, 32, True),       # bf16, one chunk, cout 1
+])
+def test_tail512_fuses_the_512_level(ops, cp, cref, cout, h1, w1, bf16):
+    """deconv (k2 s2) -> conv3x3 + ReLU -> conv3x3 (16 -> cout) [-> F.normalize]  ==  ccvpe_tail512 (models.py:124-127,
+    145-148,319,341), incl. image borders, tile aprons and the ragged last MFMA tile; and == the unfused HIP pair."""
+    from ccvpe_amd.models import _pack_upconv
+    b = 3
+    dt = torch.bfloat16 if bf16 else torch.float32
+    rnd = (lambda t: t.to(dt).float())
+    x = rnd(synth.normal((b, cp, h1, w1), 700 + cp + cout))
+    x[:, cref:] = 0
+    wd = synth.normal((cref, 16, 2, 2), 702, (1.0 / cref) ** 0.5)
+    bd = synth.normal((16,), 703, 0.3)
+    w3 = synth.normal((16, 16, 3, 3), 704, (1.0 / (9 * 16)) ** 0.5)
+    b3 = synth.normal((16,), 705, 0.1)
+    w2 = synth.normal((cout, 16, 3, 3), 706, (1.0 / (9 * 16)) ** 0.5)
+    b2 = synth.normal((cout,), 707, 0.1)
+    mid = F.relu(F.conv2d(F.conv_transpose2d(x[:, :cref], wd, bd, stride=2), w3, b3, padding=1))
+    want = F.conv2d(mid, w2, b2, padding=1)
+    if cout == 2:
+        want = F.normalize(want, p=2, dim=1)
+    fw, fshift = _pack_upconv(wd.cuda(), bd.cuda(), [(0, 0, cref)], cp, w3.cuda(), b3.cuda(), dt)
+    xd = nhwc(x).to(dt).cuda().contiguous()
+    w2p = w2.permute(0, 2, 3, 1).contiguous().cuda()
+    got = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), cout, cout == 2, batch=b, h1=h1, w1=w1)
+    assert tuple(got.shape) == (b, cout, 2 * h1, 2 * w1) and got.dtype == torch.float32
+    # cout = 2: the normalised field is ill-conditioned where the un-normalised vector is tiny -> compare where it is not
+    if cout == 2:
+        raw = F.conv2d(mid, w2, b2, padding=1)
+        ok = (raw.pow(2).sum(1, keepdim=True).sqrt() > (0.2 if bf16 else 1e-2)).expand_as(want)
+        err = ((got.cpu() - want).abs() * ok).max().item()
+        assert err <= (3e-2 if bf16 else 1e-4), "tail512 ori: %.3e" % err
+        assert float((got.pow(2).sum(1).sqrt() - 1).abs().max()) < 1e-5
+    else:
+        close(got.cpu(), want, 2e-2 if bf16 else 1e-5, "tail512 cp=%d" % cp)
+    # the unfused HIP pair on the same operands
+    y = ops.upconv3x3(xd, cp, fw, fshift, 16, batch=b, h1=h1, w1=w1, act=ops.ACT_RELU)
+    ref2 = ops.head_conv3x3(y, w2p, b2.cuda(), cout, cout == 2)
+    if cout == 1:
+        close(got.cpu(), ref2.cpu(), 2e-2 if bf16 else 1e-5, "tail512 vs upconv + head")
+
+
 # ------------------------------------------------------------------------------------------
 # EfficientNet pieces
 # ------------------------------------------------------------------------------------------
