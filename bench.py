@@ -646,9 +646,14 @@ def main():
                 if graph:
                     from ccvpe_amd.graph import GraphedForward
                     f2 = GraphedForward(net2, g2, s2)
-                e2, r2 = forward_measure(f2, g2, s2, dev, 5, 2, record and not graph)
+                # timed pass WITHOUT per-launch events (two events per launch are ~0.3-0.5 ms of a 7-12 ms bf16 step: ~300
+                # launches), then a short pass with them for the per-kernel table / dominant kernel of this leg
+                e2, _ = forward_measure(f2, g2, s2, dev, 5, 2, False)
+                r2 = None
+                if record and not graph:
+                    _, r2 = forward_measure(f2, g2, s2, dev, 3, 1, True)
                 if rank == 0:
-                    roof, table = roofline_from(r2.summary() if r2 is not None else None, 5, "bf16", b2, "vigor", 1e3 * e2 / 5)
+                    roof, table = roofline_from(r2.summary() if r2 is not None else None, 3, "bf16", b2, "vigor", 1e3 * e2 / 5)
                     emit_kernel_table(tag, table)
                     legs[tag] = {"workload": what, "value": round(b2 * world * 5 / e2, 2), "n_gpus": world, "batch_per_gpu": b2,
                                  "ms_per_step": round(1e3 * e2 / 5, 3), "steps": 5, "dtype": "bf16", "roofline": roof,

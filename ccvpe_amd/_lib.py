@@ -51,7 +51,7 @@ class TailDesc(ctypes.Structure):
         ("x", c_void_p), ("w", c_void_p), ("shift9", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("out", c_void_p),
         ("batch", c_int), ("h1", c_int), ("w1", c_int),
         ("c0", c_int), ("ld0", c_int), ("kpad", c_int),
-        ("cout", c_int), ("normalize", c_int),
+        ("cout", c_int), ("normalize", c_int), ("split", c_int),
     ]
 
 
@@ -63,6 +63,12 @@ PROTOTYPES = {
     "ccvpe_multi_copy_f32": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), c_int, c_void_p]),
     "ccvpe_gather_repack_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "ccvpe_gather_repack_chunk": (c_int, []),
+    "ccvpe_ctx_create": (c_int, [c_void_p, ctypes.c_longlong, c_void_p, c_void_p, ctypes.POINTER(c_void_p)]),
+    "ccvpe_ctx_destroy": (c_int, [c_void_p]),
+    "ccvpe_ctx_info": (c_int, [c_void_p] + [ctypes.POINTER(ctypes.c_longlong)] * 4 + [ctypes.POINTER(c_int)] * 2),
+    "ccvpe_ctx_output": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_longlong),
+                                  ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
+    "ccvpe_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
     "ccvpe_tail512_f32": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_tail512_bf16": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),

@@ -149,17 +149,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_kernel(const
     }
   }
   const unsigned bs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
-  // one request (row group q of panel t) of the next stage: issued BETWEEN the matrix instructions of the running stage
-  auto load_w_piece = [&](int chunk, int tg, int dbuf, int t, int q) {
-    if constexpr (DMA) {
-      const int g = wave + NW * q;
-      if (g < BN / 16) {
-        const char* sbase = reinterpret_cast<const char*>(wp) + ((size_t)(tg * TPS + t) * ctot + (size_t)chunk * SK) * sizeof(T);
-        const unsigned lds = __builtin_amdgcn_readfirstlane(bs_lds + (unsigned)(((dbuf * TPS + t) * BN + g * 16) * BLD * 4));
-        asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(wvoff[q]), "s"(sbase) : "memory", "m0");
-      }
-    }
-  };
   auto load_w = [&](int chunk, int tg, int dbuf) {   // the TPS taps tg*TPS .. of `chunk` -> Bs[dbuf][0..TPS)
     if constexpr (DMA) {
 #pragma unroll
@@ -224,9 +213,6 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_kernel(const
 #else
   constexpr int abl = 0;
 #endif
-  if (abl & 512) {   // experiment: the second workgroup of a CU (odd hardware wave slot) starts half a stage late
-    if (__builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11)) & 1) __builtin_amdgcn_s_sleep(8);
-  }
   int chunk = 0, tg = 0;
   for (int s = 0; s < nstages; ++s) {
     const bool more = (s + 1 < nstages) && !(abl & 2);
@@ -257,18 +243,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_kernel(const
       if (t == 0) {
         // the next stage's W panels and (once per chunk) halo: requested under the whole stage's matrix work
         if (next_halo && !(abl & 64)) load_halo(chunk + 1);   // first: re-using h_reg makes the compiler wait for what is in flight
-        if (more && !(abl & 32) && !(abl & 256)) load_w(nchunk, ntg, (s + 1) & 1);
+        if (more && !(abl & 32)) load_w(nchunk, ntg, (s + 1) & 1);
       }
       if (TPS > 1) __builtin_amdgcn_sched_barrier(0);           // keep those reads / loads ABOVE this tap's MFMAs
-      if ((abl & 256) && DMA) {
-        // W requests of panel t spread over this tap's matrix instructions (one after each accumulator row)
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[cur][j], af[cur][i], acc[i][j]);
-          if (i < NSLOT && more && !(abl & 32)) load_w_piece(nchunk, ntg, (s + 1) & 1, t, i);
-        }
-      } else
       if (sizeof(T) == 4) {
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)

@@ -155,10 +155,13 @@ def _overlap_decoders(precision):
 FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
 # Below this many low-res pixels (batch * h * w) the folded GEMM has too few output tiles to fill the chip and walks
 # K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
-# instead.  B = 64 keeps every level folded (level 6 has 4096 low-res pixels).
-FOLD_MIN_PIXELS = 4096
+# instead.  Round 4 sweep (CVM_VIGOR, ms per forward at thresholds 1024 / 2048 / 4096): B = 32 bf16 6.53 / 6.49 / 6.69, fp32 18.97 /
+# 19.02 / 19.92; B = 16 bf16 4.03 / 4.02 / 4.02, fp32 11.40 / 11.25 / 11.24 -> 2048 (B >= 32 folds level 6, B <= 16 does not).
+FOLD_MIN_PIXELS = int(__import__("os").environ.get("CCVPE_FOLD_MIN_PIXELS", "2048"))
 # level 1 (512 x 512) of both decoders as ONE launch (csrc/tail512.hip); CCVPE_FUSE_TAIL=0 restores upconv + head conv (A/B runs)
 FUSE_TAIL = __import__("os").environ.get("CCVPE_FUSE_TAIL", "1") != "0"
+# bf16 storage path: the fp32 tail's matrix arithmetic on bf16 hi + lo planes (csrc/tail512.hip SPLIT); CCVPE_SPLIT_TAIL=0 = exact fp32
+SPLIT_TAIL = __import__("os").environ.get("CCVPE_SPLIT_TAIL", "1") != "0"
 # train mode: replay the per-step weight re-pack as one hipGraph (see _CVMBase._packed); CCVPE_PACK_GRAPH=0 keeps it eager
 PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
 # train mode, fp32: the per-step re-pack as ONE gather launch (ccvpe_amd/repack.py); CCVPE_PACK_GATHER=0 keeps the graph replay
@@ -670,7 +673,10 @@ class _CVMBase(nn.Module):
                 skip = sfeats_loc[SKIP_BLOCKS[j]] if j < 5 else None
                 if j == 5 and FUSE_TAIL and j in FOLD_LEVELS and ops.tail512_ok(hw, hw, lv.n_a):
                     # the whole 512 x 512 level in one launch: deconv1 + conv1 -> logits (models.py:124-127,319)
-                    logits_map = ops.tail512(cat, lv.ldo, lv.fw, lv.fshift, lv.w_b, lv.b_b, 1, False, batch=batch, h1=hw, w1=hw)
+                    # (bf16 storage path: its fp32 tail multiplies on the bf16 matrix cores with hi + lo operand planes — fp32-class
+                    # accuracy at a quarter of the matrix cycles; the fp32 path is exact fp32)
+                    logits_map = ops.tail512(cat, lv.ldo, lv.fw, lv.fshift, lv.w_b, lv.b_b, 1, False, batch=batch, h1=hw, w1=hw,
+                                             split=(self.precision == "bf16" and cat.dtype == torch.float32 and SPLIT_TAIL))
                     break
                 if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:   # deconv folded into conv.0: one GEMM per output parity
                     y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,

@@ -90,9 +90,22 @@ def conv_route_name(desc, is_bf16, out_f32=False, f32_names=False):
     return "%s_f32_kernel<%d,%d,%d>" % (fam, mt, nt, wn)
 
 
+# Plan recording (ccvpe_amd/plan.py): while a forward is being recorded every tensor this layer allocates comes from the
+# recorder's workspace and every tensor whose pointer goes to the library is remembered (weights are collected from those).
+_record = None
+
+
+def _empty(shape, device=None, dtype=torch.float32):
+    if _record is not None:
+        return _record.empty(shape, dtype, device)
+    return torch.empty(shape, device=device, dtype=dtype)
+
+
 def _ptr(t):
     if t is None:
         return None
+    if _record is not None:
+        _record.note(t)
     return ctypes.c_void_p(t.data_ptr())
 
 
@@ -136,7 +149,7 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         oshape = (batch, ho, wo)
     if dst is None:
         ldd = ldd if ldd is not None else cout
-        dst = torch.empty(oshape + (ldd,), device=src0.device, dtype=odt)
+        dst = _empty(oshape + (ldd,), device=src0.device, dtype=odt)
     elif ldd is None:
         ldd = dst.shape[-1]
     d = ConvDesc()
@@ -159,7 +172,7 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     if want > 0:          # small-batch GEMM: K cut into slices + deterministic second pass (csrc/conv_igemm.hip)
         global SPLIT_K_CALLS
         SPLIT_K_CALLS += 1
-        scratch = torch.empty((want,), device=src0.device, dtype=torch.float32)
+        scratch = _empty((want,), device=src0.device, dtype=torch.float32)
         if dt == torch.float32:
             check(lib.ccvpe_conv_igemm_splitk_f32(ctypes.byref(d), _ptr(scratch), _stream()), "ccvpe_conv_igemm_splitk_f32")
         else:
@@ -195,7 +208,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
     for t, nm in ((src0, "src0"), (src1, "src1"), (w_packed, "w")):
         _chk(t, nm, dt)
     _chk(shift9, "shift9")
-    dst = torch.empty((batch, 2 * h1, 2 * w1, n), device=src0.device, dtype=dt)
+    dst = _empty((batch, 2 * h1, 2 * w1, n), device=src0.device, dtype=dt)
     d = _lib.UpconvDesc()
     d.src0, d.src1, d.w, d.shift9, d.dst = _ptr(src0), _ptr(src1), _ptr(w_packed), _ptr(shift9), _ptr(dst)
     d.c0, d.ld0, d.c1, d.ld1 = c0, src0.shape[-1], c1, (src1.shape[-1] if src1 is not None else 0)
@@ -217,7 +230,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
     return dst
 
 
-def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1):
+def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1, split=False):
     """The whole 512 x 512 decoder level in one launch (ccvpe_tail512_f32 / _bf16): folded deconv + conv.0 + ReLU + conv.2
     (+ F.normalize for cout = 2).  x [B,h1,w1,ld0]; w_packed / shift9 from models._pack_upconv (n = 16, no skip);
     w2 [cout,3,3,16], b2 [cout] fp32; returns [B,cout,2h1,2w1] fp32."""
@@ -229,12 +242,12 @@ def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1):
         _chk(t, nm)
     if tuple(w2.shape) != (cout, 3, 3, 16) or tuple(shift9.shape) != (9, 16) or w_packed.shape[0] != 4 or w_packed.shape[1] != 16:
         raise ValueError("tail512: w [4,16,kpad], shift9 [9,16], w2 [cout,3,3,16] expected")
-    out = torch.empty((batch, cout, 2 * h1, 2 * w1), device=x.device, dtype=torch.float32)
+    out = _empty((batch, cout, 2 * h1, 2 * w1), device=x.device, dtype=torch.float32)
     d = _lib.TailDesc()
     d.x, d.w, d.shift9, d.w2, d.b2, d.out = _ptr(x), _ptr(w_packed), _ptr(shift9), _ptr(w2), _ptr(b2), _ptr(out)
     d.batch, d.h1, d.w1 = batch, h1, w1
     d.c0, d.ld0, d.kpad = c0, x.shape[-1], w_packed.shape[-1]
-    d.cout, d.normalize = cout, int(bool(normalize))
+    d.cout, d.normalize, d.split = cout, int(bool(normalize)), int(bool(split))
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
     fn = lib.ccvpe_tail512_f32 if dt == torch.float32 else lib.ccvpe_tail512_bf16
@@ -242,7 +255,7 @@ def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1):
     if rec is not None:
         m = batch * h1 * w1 * 4
         esz = 4.0 if dt == torch.float32 else 2.0
-        rec.end("tail512_kernel<%s,%d>" % ("f32" if dt == torch.float32 else "bf16", cout), "tail M%d Keff%d" % (m, 4 * c0),
+        rec.end("tail512_kernel<%s,%d>" % (("f32" if not split else "f32 as bf16 hi+lo") if dt == torch.float32 else "bf16", cout), "tail M%d Keff%d" % (m, 4 * c0),
                 2.0 * m * 16 * (4 * c0 + 9 * cout), esz * batch * h1 * w1 * c0 + 4.0 * m * cout, ev0)
     return out
 
@@ -260,7 +273,7 @@ def stem_conv(x_nchw, w, scale, shift, circular, out_dtype=torch.float32):
     if c != 3:
         raise ValueError("stem expects 3 input channels")
     ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
-    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=out_dtype)
+    y = _empty((b, ho, wo, 32), device=x_nchw.device, dtype=out_dtype)
     fn = lib.ccvpe_stem_conv_f32 if out_dtype == torch.float32 else lib.ccvpe_stem_conv_bf16
     check(fn(_ptr(x_nchw), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), b, h, wd, int(bool(circular)), _stream()),
           "ccvpe_stem_conv")
@@ -280,8 +293,8 @@ def dwconv(x, w, scale, shift, k, stride, circular):
     nblk = lib.ccvpe_dwconv_nblk(h, wd, c, stride)
     if nblk <= 0:
         raise _lib.CcvpeError("ccvpe_dwconv_nblk rejected shape %s" % (tuple(x.shape),))
-    y = torch.empty((b, ho, wo, c), device=x.device, dtype=dt)
-    part = torch.empty((b, nblk, c), device=x.device, dtype=torch.float32)
+    y = _empty((b, ho, wo, c), device=x.device, dtype=dt)
+    part = _empty((b, nblk, c), device=x.device, dtype=torch.float32)
     fn = lib.ccvpe_dwconv_f32 if dt == torch.float32 else lib.ccvpe_dwconv_bf16
     check(fn(_ptr(x), _ptr(w), _ptr(scale), _ptr(shift), _ptr(y), _ptr(part), b, h, wd, c, k, stride,
              int(bool(circular)), _stream()), "ccvpe_dwconv")
@@ -309,8 +322,8 @@ def mbconv_front(x, w_exp, s0, b0, w_dw, s1, b1, mid, k, stride, circular):
         raise _lib.CcvpeError("mbconv_front: unsupported shape %s" % (tuple(x.shape),))
     tot = (k - 1) if stride == 1 else (k - 2)
     ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
-    y = torch.empty((b, ho, wo, mid), device=x.device, dtype=dt)
-    part = torch.empty((b, nblk, mid), device=x.device, dtype=torch.float32)
+    y = _empty((b, ho, wo, mid), device=x.device, dtype=dt)
+    part = _empty((b, nblk, mid), device=x.device, dtype=torch.float32)
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
     fn = lib.ccvpe_mbconv_front_f32 if dt == torch.float32 else lib.ccvpe_mbconv_front_bf16
@@ -329,7 +342,7 @@ def se_gate(part, hw, w1, b1, w2, b2):
         _chk(t, nm)
     b, nblk, c = part.shape
     cs = w1.shape[0]
-    gate = torch.empty((b, c), device=part.device, dtype=torch.float32)
+    gate = _empty((b, c), device=part.device, dtype=torch.float32)
     check(lib.ccvpe_se_gate_f32(_ptr(part), nblk, 1.0 / float(hw), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2),
                                 _ptr(gate), b, c, cs, _stream()), "ccvpe_se_gate_f32")
     return gate
@@ -341,7 +354,7 @@ def ground_descriptor(y1, wh, bh, cd):
         _chk(t, nm)
     b, h, w, ld = y1.shape
     cd_arr = (ctypes.c_int * 6)(*cd)
-    out = torch.empty((b, w * sum(cd)), device=y1.device, dtype=torch.float32)
+    out = _empty((b, w * sum(cd)), device=y1.device, dtype=torch.float32)
     check(lib.ccvpe_ground_descriptor_f32(_ptr(y1), ld, _ptr(wh), _ptr(bh), cd_arr, _ptr(out), b, h, w,
                                           _stream()), "ccvpe_ground_descriptor_f32")
     return out
@@ -359,8 +372,8 @@ def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None, wind
     c = channels if channels is not None else ldx
     n = len(shifts)
     sh = (ctypes.c_int * n)(*shifts)
-    scores = torch.empty((b, n, h, w), device=x.device, dtype=torch.float32)
-    dstx = torch.empty((b, h, w, ldo), device=x.device, dtype=dt)
+    scores = _empty((b, n, h, w), device=x.device, dtype=torch.float32)
+    dstx = _empty((b, h, w, ldo), device=x.device, dtype=dt)
     fn = lib.ccvpe_match_level_f32 if dt == torch.float32 else lib.ccvpe_match_level_bf16
     check(fn(_ptr(x), ldx, _ptr(g), g.stride(0), L, sh, n, n_max, n_tail, stride, window_offset, _ptr(scores), _ptr(dstx),
              ldo, b, h * w, c, _stream()), "ccvpe_match_level")
@@ -376,7 +389,7 @@ def head_conv3x3(x, w, bias, cout, normalize):
     b, h, wd, c = x.shape
     if c != 16:
         raise ValueError("head conv expects 16 input channels")
-    out = torch.empty((b, cout, h, wd), device=x.device, dtype=torch.float32)
+    out = _empty((b, cout, h, wd), device=x.device, dtype=torch.float32)
     fn = lib.ccvpe_head_conv3x3_f32 if dt == torch.float32 else lib.ccvpe_head_conv3x3_bf16
     check(fn(_ptr(x), _ptr(w), _ptr(bias), _ptr(out), b, h, wd, cout, int(bool(normalize)), _stream()),
           "ccvpe_head_conv3x3")
@@ -389,7 +402,7 @@ def cast_f32(x):
         return x
     lib = _lib.load()
     _chk(x, "x", torch.bfloat16)
-    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    out = _empty(x.shape, device=x.device, dtype=torch.float32)
     check(lib.ccvpe_cast_bf16_f32(_ptr(x), _ptr(out), x.numel(), _stream()), "ccvpe_cast_bf16_f32")
     return out
 
@@ -398,7 +411,7 @@ def softmax_rows(logits):
     lib = _lib.load()
     _chk(logits, "logits")
     rows, n = logits.shape
-    out = torch.empty_like(logits)
+    out = _empty(logits.shape, device=logits.device, dtype=logits.dtype)
     check(lib.ccvpe_softmax_rows_f32(_ptr(logits), _ptr(out), rows, n, _stream()), "ccvpe_softmax_rows_f32")
     return out
 
@@ -413,7 +426,7 @@ def stem_conv_raw(x_nchw, w, circular):
     _chk(w, "w")
     b, c, h, wd = x_nchw.shape
     ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
-    y = torch.empty((b, ho, wo, 32), device=x_nchw.device, dtype=torch.float32)
+    y = _empty((b, ho, wo, 32), device=x_nchw.device, dtype=torch.float32)
     check(lib.ccvpe_stem_conv_raw_f32(_ptr(x_nchw), _ptr(w), _ptr(y), b, h, wd, int(bool(circular)), _stream()),
           "ccvpe_stem_conv_raw_f32")
     return y
@@ -426,7 +439,7 @@ def dwconv_raw(x, w, k, stride, circular):
     b, h, wd, c = x.shape
     tot = (k - 1) if stride == 1 else (k - 2)
     ho, wo = (h + tot - k) // stride + 1, (wd + tot - k) // stride + 1
-    y = torch.empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
+    y = _empty((b, ho, wo, c), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_dwconv_raw_f32(_ptr(x), _ptr(w), _ptr(y), b, h, wd, c, k, stride, int(bool(circular)), _stream()),
           "ccvpe_dwconv_raw_f32")
     return y
@@ -441,9 +454,9 @@ def bn_stats(x, run_mean=None, run_var=None, momentum=0.01):
     _chk(run_var, "run_var")
     c = x.shape[-1]
     rows = x.numel() // c
-    mean = torch.empty((c,), device=x.device, dtype=torch.float32)
-    var = torch.empty((c,), device=x.device, dtype=torch.float32)
-    scratch = torch.empty((lib.ccvpe_bn_stats_nblk(rows) * 3 * c,), device=x.device, dtype=torch.float32)
+    mean = _empty((c,), device=x.device, dtype=torch.float32)
+    var = _empty((c,), device=x.device, dtype=torch.float32)
+    scratch = _empty((lib.ccvpe_bn_stats_nblk(rows) * 3 * c,), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_bn_stats_f32(_ptr(x), rows, c, _ptr(mean), _ptr(var), _ptr(run_mean), _ptr(run_var),
                                  float(momentum), _ptr(scratch), _stream()), "ccvpe_bn_stats_f32")
     return mean, var
@@ -457,10 +470,10 @@ def bn_act(x, mean, var, gamma, beta, eps, act, residual=None, dc_scale=None, wa
         _chk(t, nm)
     b, c = x.shape[0], x.shape[-1]
     rps = x.numel() // (b * c)
-    y = torch.empty_like(x)
+    y = _empty(x.shape, device=x.device, dtype=x.dtype)
     part = None
     if want_se:
-        part = torch.empty((b, lib.ccvpe_bn_act_nblk(rps), c), device=x.device, dtype=torch.float32)
+        part = _empty((b, lib.ccvpe_bn_act_nblk(rps), c), device=x.device, dtype=torch.float32)
     check(lib.ccvpe_bn_act_f32(_ptr(x), _ptr(mean), _ptr(var), _ptr(gamma), _ptr(beta), float(eps), act, _ptr(residual),
                                _ptr(dc_scale), _ptr(y), _ptr(part), b, rps, c, _stream()), "ccvpe_bn_act_f32")
     return (y, part) if want_se else y
@@ -472,7 +485,7 @@ def eval_postprocess(heatmap, ori):
     _chk(heatmap, "heatmap")
     _chk(ori, "ori")
     b, _, h, w = heatmap.shape
-    out = torch.empty((b, 6), device=heatmap.device, dtype=torch.float32)
+    out = _empty((b, 6), device=heatmap.device, dtype=torch.float32)
     check(lib.ccvpe_eval_postprocess_f32(_ptr(heatmap), _ptr(ori), _ptr(out), b, h, w, _stream()),
           "ccvpe_eval_postprocess_f32")
     return out
@@ -483,8 +496,8 @@ def _loss_common(fn, name, tensors, extra):
     for i, t in enumerate(tensors):
         _chk(t, "%s arg %d" % (name, i))
     b = tensors[0].shape[0]
-    loss = torch.empty((1,), device=tensors[0].device, dtype=torch.float32)
-    scratch = torch.empty((2 * b,), device=tensors[0].device, dtype=torch.float32)
+    loss = _empty((1,), device=tensors[0].device, dtype=torch.float32)
+    scratch = _empty((2 * b,), device=tensors[0].device, dtype=torch.float32)
     return lib, loss, scratch, b
 
 
@@ -496,12 +509,12 @@ def infonce_loss(scores, labels, temperature=0.1, want_den=False, want_rows=Fals
     _chk(scores, "infonce scores")
     _chk(labels, "infonce labels")
     b, n = scores.shape
-    loss = torch.empty((1,), device=scores.device, dtype=torch.float32)
-    rows = torch.empty((4 * b + 4,), device=scores.device, dtype=torch.float32)
+    loss = _empty((1,), device=scores.device, dtype=torch.float32)
+    rows = _empty((4 * b + 4,), device=scores.device, dtype=torch.float32)
     nfl = lib.ccvpe_infonce_scratch_floats(b, n)
     if nfl <= 0:
         raise _lib.CcvpeError("ccvpe_infonce_scratch_floats rejected [%d, %d]" % (b, n))
-    scratch = torch.empty((nfl,), device=scores.device, dtype=torch.float32)
+    scratch = _empty((nfl,), device=scores.device, dtype=torch.float32)
     check(lib.ccvpe_infonce_loss_f32(_ptr(scores), _ptr(labels), float(temperature), _ptr(loss), _ptr(rows), _ptr(scratch),
                                      b, n, _stream()), "ccvpe_infonce_loss_f32")
     out = (loss[0],)

@@ -137,6 +137,9 @@ int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* desc, void* stream);
  * with n = 16 and c1 = 0 ([4][16][kpad], [9][16]), w2 [cout][3][3][16] fp32, b2 [cout], out [B,cout,2h1,2w1] fp32
  * (NCHW).  The 16-channel intermediate is never written.  h1, w1 multiples of 16.  Same results as ccvpe_upconv3x3 +
  * ccvpe_head_conv3x3 (fp32: to rounding; bf16: better — the intermediate is not rounded to bf16).
+ * split (ccvpe_tail512_f32 only, cout = 1): 0 = exact fp32 matrix arithmetic; 1 = the fp32 operands are split into bf16 hi + lo
+ * planes and multiplied on the bf16 matrix cores (hi.hi + lo.hi + hi.lo, fp32 accumulate: ~1e-5 of scale instead of bit-level
+ * fp32) — the fp32 tail of the bf16 STORAGE path (set_precision("bf16")), never used by the fp32 path.
  * ----------------------------------------------------------------------------------------- */
 typedef struct ccvpe_tail_desc {
   const void* x;
@@ -147,11 +150,35 @@ typedef struct ccvpe_tail_desc {
   float* out;
   int batch, h1, w1;
   int c0, ld0, kpad;
-  int cout, normalize;
+  int cout, normalize, split;
 } ccvpe_tail_desc;
 
 int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream);
 int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream);
+
+/* -------------------------------------------------------------------------------------------
+ * The WHOLE eval forward behind one entry point (csrc/plan.hip) — replaces the call sites
+ *   logits, heatmap, ori, score1..6 = model(grd, sat)      train_VIGOR.py:252-254,282 / train_KITTI.py:285-287,302 /
+ *                                                           visualize_qualitative_results_VIGOR.py:68-71
+ * for a model in eval mode (models.py:150-343, :448-652, :752-950, :954-1246).
+ * A ctx is created from a PLAN: the launch list of one forward for fixed (model, weights, batch, image sizes, precision),
+ * recorded and serialised by ccvpe_amd/plan.py (or read from a file the Python side wrote: tools/plan_run.cpp is a caller
+ * without Python).  plan: the serialised bytes (header, calls, descriptor blobs, packed weights).
+ * weights_dev / workspace_dev: device buffers of at least the plan's weights / workspace size (ccvpe_ctx_info on a ctx, or the
+ * Python Plan object) owned by the CALLER — or NULL: the library allocates and frees them.  The weights are uploaded here.
+ * ccvpe_forward: grd [B,3,h,w], sat [B,3,H,W] NCHW fp32 device tensors of the recorded shapes; every kernel is enqueued on
+ * `stream` (capturable in a hipGraph); out (may be NULL) receives the device pointers of the nine outputs — fp32, NCHW-
+ * contiguous, inside the ctx's workspace, valid until the next ccvpe_forward on this ctx.  One ctx serves one stream at a time.
+ * Errors: int status, ccvpe_last_error() names the failing call.
+ * ----------------------------------------------------------------------------------------- */
+typedef struct ccvpe_ctx ccvpe_ctx;
+int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weights_dev, void* workspace_dev, ccvpe_ctx** ctx);
+int ccvpe_ctx_destroy(ccvpe_ctx* ctx);
+int ccvpe_ctx_info(const ccvpe_ctx* ctx, long long* workspace_bytes, long long* weights_bytes, long long* grd_bytes,
+                   long long* sat_bytes, int* n_outputs, int* n_calls);
+int ccvpe_ctx_output(const ccvpe_ctx* ctx, int i, void** dev_ptr, long long* bytes, int* ndim, long long* dims4,
+                     long long* strides4);   /* strides in ELEMENTS: an output may be a view (ori_prior's score1 is a channel slice) */
+int ccvpe_forward(ccvpe_ctx* ctx, const void* grd, const void* sat, void** out, void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * EfficientNet stem: 3x3 stride-2 conv on the NCHW image + folded BN + swish, NHWC out.

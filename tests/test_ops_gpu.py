@@ -288,6 +288,33 @@ def test_tail512_fuses_the_512_level(ops, cp, cref, cout, h1, w1, bf16):
         close(got.cpu(), ref2.cpu(), 2e-2 if bf16 else 1e-5, "tail512 vs upconv + head")
 
 
+@pytest.mark.parametrize("cp,cref,h1,w1", [(48, 41, 16, 32), (40, 33, 32, 16), (32, 25, 16, 48)])
+def test_tail512_split_bf16_planes_are_fp32_class(ops, cp, cref, h1, w1):
+    """The fp32 tail of the bf16 STORAGE path: fp32 operands split into bf16 hi + lo planes, hi.hi + lo.hi + hi.lo on the bf16
+    matrix cores.  Against the float64 result: <= 3e-5 of scale (measured ~1e-5) where plain bf16 operands give ~4e-3 — and the
+    exact fp32 kernel on the same operands agrees to that level."""
+    from ccvpe_amd.models import _pack_upconv
+    b = 2
+    x = synth.normal((b, cp, h1, w1), 900 + cp)
+    x[:, cref:] = 0
+    wd = synth.normal((cref, 16, 2, 2), 902, (1.0 / cref) ** 0.5)
+    bd = synth.normal((16,), 903, 0.3)
+    w3 = synth.normal((16, 16, 3, 3), 904, (1.0 / (9 * 16)) ** 0.5)
+    b3 = synth.normal((16,), 905, 0.1)
+    w2 = synth.normal((1, 16, 3, 3), 906, (1.0 / (9 * 16)) ** 0.5)
+    b2 = synth.normal((1,), 907, 0.1)
+    dd = lambda t: t.double()
+    mid = F.relu(F.conv2d(F.conv_transpose2d(dd(x[:, :cref]), dd(wd), dd(bd), stride=2), dd(w3), dd(b3), padding=1))
+    want = F.conv2d(mid, dd(w2), dd(b2), padding=1)
+    fw, fshift = _pack_upconv(wd.cuda(), bd.cuda(), [(0, 0, cref)], cp, w3.cuda(), b3.cuda(), torch.float32)
+    xd = nhwc(x).cuda().contiguous()
+    w2p = w2.permute(0, 2, 3, 1).contiguous().cuda()
+    exact = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), 1, False, batch=b, h1=h1, w1=w1)
+    split = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), 1, False, batch=b, h1=h1, w1=w1, split=True)
+    close(exact.cpu(), want, 1e-5, "tail512 fp32")
+    close(split.cpu(), want, 3e-5, "tail512 split")
+
+
 # ------------------------------------------------------------------------------------------
 # EfficientNet pieces
 # ------------------------------------------------------------------------------------------

@@ -44,6 +44,10 @@ def main():
         t = timeit(f)
         err = float((f() - ref).abs().max())
         line += " | fused %.3f ms (%.0f TF on %.0f GFLOP, max diff vs unfused %.2e)" % (t, gf / t, gf, err)
+        if dt == torch.float32 and cout == 1:
+            f2 = lambda: ops.tail512(x, cp, fw, fshift, w2, b2, cout, False, batch=b, h1=h1, w1=h1, split=True)
+            t2 = timeit(f2)
+            line += " | split %.3f ms (max diff vs fp32 fused %.2e of %.2e)" % (t2, float((f2() - f()).abs().max()), float(f().abs().max()))
         print(line, flush=True)
 
 
