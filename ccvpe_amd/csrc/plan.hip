@@ -8,8 +8,10 @@
 //   GRD / SAT  the caller's input images (NCHW fp32), given per call.
 // ccvpe_amd/plan.py records the plan by running the Python forward once against a recording allocator and serialises it; the
 // bytes can be written to a file, so a caller WITHOUT Python (tools/plan_run.cpp) loads them, creates a ctx and runs.
-// The forward itself is a loop over the recorded calls: no Python, no per-call descriptor building, no allocation; everything
-// is enqueued on the caller's stream (hipGraph-capturable).  Host-only code: the kernels are the library's own entry points.
+// The forward itself is a loop over the recorded calls: no Python, no per-call descriptor building, no allocation.  Calls carry the
+// stream they were recorded on — the caller's stream, or the ctx's own side stream (ground encoder beside the aerial encoder,
+// and in bf16 storage the orientation decoder beside the localisation decoder) — with the recorded fork / join waits replayed
+// through events, so the whole forward is ordered after and before the caller's stream (hipGraph-capturable).  Host-only code: the kernels are the library's own entry points.
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -58,7 +60,7 @@ static const std::unordered_map<std::string, Invoker>& registry() {
 
 struct Patch { uint32_t call, arg, kind; uint64_t off; };              // per-run argument (input image / stream)
 struct BlobPatch { uint32_t blob, field, kind; uint64_t off; };        // per-run pointer field inside a descriptor blob
-struct Call { Invoker fn; std::string name; uint32_t first, nargs; };
+struct Call { Invoker fn; std::string name; uint32_t first, nargs, sid; int wait_on; };   // fn == nullptr: "@wait" (stream sid waits for stream wait_on)
 struct Output { uint64_t off, bytes; uint32_t dtype, ndim; long long dims[4], strides[4]; };
 
 }  // namespace ccvpe
@@ -74,6 +76,8 @@ struct ccvpe_ctx {
   char* weights = nullptr;
   char* workspace = nullptr;
   bool own_weights = false, own_workspace = false;
+  hipStream_t side = nullptr;                       // the forward's second stream (ground encoder / orientation decoder)
+  std::vector<hipEvent_t> events;                   // one per recorded stream wait
 };
 
 using namespace ccvpe;
@@ -148,20 +152,26 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
     if (!nm) break;
     std::string name(reinterpret_cast<const char*>(nm), strnlen(reinterpret_cast<const char*>(nm), 48));
     const uint32_t na = r.get<uint32_t>();
-    r.get<uint32_t>();
+    const uint32_t sid = r.get<uint32_t>() & 1u;
     if (na > 64) return bail(CCVPE_EINVAL, "call with more than 64 arguments");
-    auto it = registry().find(name);
-    if (it == registry().end()) {
-      delete c;
-      return fail(CCVPE_EINVAL, "ctx_create: the plan calls %s, which this library does not replay", name.c_str());
-    }
     for (uint32_t k = 0; k < na; ++k) {
       RawArg a{r.get<uint32_t>(), 0};
       r.get<uint32_t>();
       a.value = r.get<uint64_t>();
       raw[i].push_back(a);
     }
-    c->calls.push_back(Call{it->second, name, 0, na});
+    if (name == "@wait") {                             // stream raw[0] waits for what has been enqueued on stream raw[1]
+      if (na != 2) return bail(CCVPE_EINVAL, "malformed stream wait");
+      c->calls.push_back(Call{nullptr, name, 0, 0, (uint32_t)(raw[i][0].value & 1), (int)(raw[i][1].value & 1)});
+      raw[i].clear();
+      continue;
+    }
+    auto it = registry().find(name);
+    if (it == registry().end()) {
+      delete c;
+      return fail(CCVPE_EINVAL, "ctx_create: the plan calls %s, which this library does not replay", name.c_str());
+    }
+    c->calls.push_back(Call{it->second, name, 0, na, sid, -1});
   }
   if (!r.ok) return bail(CCVPE_EINVAL, "truncated plan");
   // the weights blob: 256-byte aligned from the start of the plan
@@ -219,6 +229,19 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
       c->args.push_back(v);
     }
   }
+  bool two_streams = false;
+  for (const Call& k : c->calls) {
+    two_streams = two_streams || k.sid == 1 || !k.fn;
+    if (!k.fn) {
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ccvpe_ctx_destroy(c); return fail(CCVPE_ELAUNCH, "ctx_create: hipEventCreate"); }
+      c->events.push_back(ev);
+    }
+  }
+  if (two_streams && hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) {
+    ccvpe_ctx_destroy(c);
+    return fail(CCVPE_ELAUNCH, "ctx_create: hipStreamCreate");
+  }
   *out = c;
   return CCVPE_OK;
 }
@@ -227,6 +250,8 @@ extern "C" int ccvpe_ctx_destroy(ccvpe_ctx* c) {
   if (!c) return CCVPE_OK;
   if (c->own_weights && c->weights) (void)hipFree(c->weights);
   if (c->own_workspace && c->workspace) (void)hipFree(c->workspace);
+  for (hipEvent_t ev : c->events) (void)hipEventDestroy(ev);
+  if (c->side) (void)hipStreamDestroy(c->side);
   delete c;
   return CCVPE_OK;
 }
@@ -264,14 +289,22 @@ extern "C" int ccvpe_forward(ccvpe_ctx* c, const void* grd, const void* sat, voi
     uint64_t v = 0;
     if (q.kind == K_GRD) v = (uint64_t)(uintptr_t)(reinterpret_cast<const char*>(grd) + q.off);
     else if (q.kind == K_SAT) v = (uint64_t)(uintptr_t)(reinterpret_cast<const char*>(sat) + q.off);
-    else v = (uint64_t)(uintptr_t)stream;
+    else v = (uint64_t)(uintptr_t)(c->calls[q.call].sid ? (void*)c->side : stream);
     c->args[c->calls[q.call].first + q.arg] = v;
   }
   for (const BlobPatch& q : c->blob_patches) {
     const uint64_t v = (uint64_t)(uintptr_t)(reinterpret_cast<const char*>(q.kind == K_GRD ? grd : sat) + q.off);
     std::memcpy(c->blobs[q.blob].data() + q.field, &v, 8);
   }
+  size_t nev = 0;
   for (const Call& k : c->calls) {
+    if (!k.fn) {                                        // fork / join: stream k.sid waits for stream k.wait_on
+      hipStream_t waiter = k.sid ? c->side : (hipStream_t)stream, waitee = k.wait_on ? c->side : (hipStream_t)stream;
+      hipEvent_t ev = c->events[nev++];
+      if (hipEventRecord(ev, waitee) != hipSuccess || hipStreamWaitEvent(waiter, ev, 0) != hipSuccess)
+        return fail(CCVPE_ELAUNCH, "forward: stream wait failed");
+      continue;
+    }
     const int rc = k.fn(c->args.data() + k.first, (int)k.nargs);
     if (rc != CCVPE_OK) return rc;                      // (the failing entry point has set ccvpe_last_error)
   }

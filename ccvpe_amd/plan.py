@@ -2,9 +2,12 @@
 ccvpe_forward, csrc/plan.hip) — SURVEY.md section 8(b)'s "opaque ccvpe_ctx per (model kind, B, grd H x W, N_rot set, dtype)".
 
 `record(net, grd, sat)` runs the Python forward (models.py:150-343 / :448-652 / :752-950 as ccvpe_amd/models.py lays it out)
-once against a recording allocator and a recording view of the library:
+once against a recording allocator and a recording view of the library (the forward keeps its two HIP streams: the ground
+encoder — and in bf16 storage the orientation decoder — run on a side stream; calls carry their stream, stream waits are
+recorded as fork / join marks and the ctx replays them on the caller's stream + one stream of its own):
   * every intermediate and output tensor comes from ONE workspace, placed by lifetime (a tensor's bytes are handed out again
-    once nothing references it — the eval forward is a single in-order stream of kernels, so program order is lifetime order);
+    once nothing references it: program order is lifetime order within a stream; main- and side-stream tensors live in two
+    regions, and bytes released while the OTHER stream may still be reading them are quarantined until the next join);
   * every library call is logged with its arguments; each pointer becomes (region, offset) with region = the workspace, the
     caller's grd / sat images, or the WEIGHTS blob the recorder assembles from whatever packed-weight tensors the calls touch.
 The result serialises to bytes (`Plan.to_bytes()`, `Plan.save(path)`): a caller without Python loads them (tools/plan_run.cpp).
@@ -16,7 +19,7 @@ import weakref
 
 import torch
 
-from . import _lib, models, ops
+from . import _lib, ops
 
 K_INT, K_FLT, K_NULL, K_WEIGHTS, K_WORKSPACE, K_GRD, K_SAT, K_STREAM, K_BLOB = range(9)
 ALIGN = 256
@@ -69,15 +72,27 @@ class _Arena(object):
 
 
 class _Recorder(object):
-    def __init__(self, device, arena_bytes, grd, sat):
+    def __init__(self, device, arena_bytes, grd, sat, side_fraction=0.45):
         self.ws = torch.empty((arena_bytes,), dtype=torch.uint8, device=device)
         self.base = self.ws.data_ptr()
-        self.arena = _Arena(arena_bytes)
+        # two regions: [0, split) for tensors allocated under the main stream, [split, size) for the side stream
+        self.split = int(arena_bytes * (1.0 - side_fraction)) // ALIGN * ALIGN
+        self.arenas = (_Arena(self.split), _Arena(arena_bytes - self.split))
+        self.size = arena_bytes
         self.grd, self.sat = grd, sat
         self.calls, self.blobs = [], []
         self.weights, self.weights_bytes = {}, 0         # data_ptr -> (offset, tensor)
-        self.seen = {}                                   # data_ptr -> tensor, for every tensor handed to ops._ptr()
-        self.stream = torch.cuda.current_stream().cuda_stream
+        self.seen = {}                                   # data_ptr -> tensor, for every NON-workspace tensor handed to ops._ptr()
+        self.main = torch.cuda.current_stream().cuda_stream
+        self.quarantine = []                             # (region, off, size): released under the other stream, free at the next join
+        self.n_waits = 0
+
+    def sid(self):
+        return 0 if torch.cuda.current_stream().cuda_stream == self.main else 1
+
+    @property
+    def peak(self):
+        return max(self.arenas[0].peak, self.split + self.arenas[1].peak if self.arenas[1].peak else 0)
 
     # -- allocation (ops._empty) ------------------------------------------------------------------------------------
     def empty(self, shape, dtype, device):
@@ -86,25 +101,46 @@ class _Recorder(object):
         for s in shape:
             n *= s
         item = torch.empty((), dtype=dtype).element_size()
-        off, size = self.arena.alloc(n * item)
+        region = self.sid()
+        off, size = self.arenas[region].alloc(n * item)
+        goff = off + (self.split if region else 0)
         # a ROOT tensor on the workspace's storage (not a view of self.ws): its views keep IT alive through ._base, so the
         # finalizer below runs only when the last alias of these bytes is gone
-        t = torch.empty((0,), dtype=dtype, device=device).set_(self.ws.untyped_storage(), off // item, shape)
-        weakref.finalize(t, self.arena.release, off, size)
+        t = torch.empty((0,), dtype=dtype, device=device).set_(self.ws.untyped_storage(), goff // item, shape)
+        weakref.finalize(t, self._release, region, off, size)
         return t
+
+    def _release(self, region, off, size):
+        if self.sid() == region:
+            self.arenas[region].release(off, size)       # in-order on its own stream: the bytes may be handed out again
+        else:
+            self.quarantine.append((region, off, size))  # the other stream may still be reading them: wait for a join
+
+    def wait(self, waiter, waitee):
+        """torch.cuda.Stream.wait_stream hook: `waiter` waits for everything enqueued on `waitee` so far."""
+        a = 0 if waiter.cuda_stream == self.main else 1
+        b = 0 if waitee.cuda_stream == self.main else 1
+        if a == b:
+            return
+        self.calls.append(("@wait", [(K_INT, a), (K_INT, b)], a))
+        self.n_waits += 1
+        if a == 0:                                       # a JOIN (main waits for side): quarantined bytes are safe again.
+            for region, off, size in self.quarantine:    # (a fork does not release: the side stream has only caught up with
+                self.arenas[region].release(off, size)   #  main, main has not waited for side)
+            self.quarantine = []
 
     # -- pointers ---------------------------------------------------------------------------------------------------
     def note(self, t):
         """ops._ptr hook: remember tensors that are NOT workspace tensors (packed weights) — holding a reference to a workspace
         tensor would keep its bytes from being handed out again."""
         p = t.data_ptr()
-        if not (self.base <= p < self.base + self.arena.size):
+        if not (self.base <= p < self.base + self.size):
             self.seen[p] = t
 
     def classify(self, addr):
         if addr is None or addr == 0:
             return K_NULL, 0
-        if self.base <= addr < self.base + self.arena.size:
+        if self.base <= addr < self.base + self.size:
             return K_WORKSPACE, addr - self.base
         for kind, t in ((K_GRD, self.grd), (K_SAT, self.sat)):
             p = t.data_ptr()
@@ -148,7 +184,7 @@ class _Recorder(object):
                 out.append((K_FLT, struct.unpack("<I", struct.pack("<f", float(a)))[0]))
             else:
                 out.append((K_INT, int(a) & 0xffffffffffffffff))
-        self.calls.append((name, out))
+        self.calls.append((name, out, self.sid()))
 
     def _struct_blob(self, obj):
         relocs = []
@@ -184,8 +220,16 @@ class Plan(object):
     """A recorded forward: calls, blobs, workspace / weights sizes, the weights blob (uint8 device tensor) and the outputs."""
 
     def __init__(self, rec, outputs, grd, sat):
-        self.calls, self.blobs = rec.calls, rec.blobs
-        self.workspace_bytes = (rec.arena.peak + ALIGN - 1) // ALIGN * ALIGN
+        # compact the two regions: the side region starts where the main region's high-water mark ends
+        main_peak = (rec.arenas[0].peak + ALIGN - 1) // ALIGN * ALIGN
+        shift = rec.split - main_peak
+
+        def fix(off):
+            return off - shift if off >= rec.split else off
+        self.calls = [(n, [(k, fix(v)) if k == K_WORKSPACE else (k, v) for k, v in a], sid) for n, a, sid in rec.calls]
+        self.blobs = [(d, [(f, k, fix(v)) if k == K_WORKSPACE else (f, k, v) for f, k, v in r]) for d, r in rec.blobs]
+        self.workspace_bytes = main_peak + (rec.arenas[1].peak + ALIGN - 1) // ALIGN * ALIGN
+        self.n_waits = rec.n_waits
         self.weights_bytes = (rec.weights_bytes + ALIGN - 1) // ALIGN * ALIGN
         self.grd_shape, self.sat_shape = tuple(grd.shape), tuple(sat.shape)
         self.outputs = []
@@ -197,7 +241,7 @@ class Plan(object):
                 raise RuntimeError("plan: an output lives outside the workspace")
             # (an output may be a strided view: ori_prior returns a channel slice of the level-1 score volume, models.py:501-511)
             extent = 4 * (1 + sum((n - 1) * st for n, st in zip(t.shape, t.stride())))
-            self.outputs.append((off, extent, tuple(t.shape), tuple(t.stride())))
+            self.outputs.append((fix(off), extent, tuple(t.shape), tuple(t.stride())))
         blob = torch.zeros((max(self.weights_bytes, ALIGN),), dtype=torch.uint8, device=grd.device)
         for off, t in rec.weights.values():
             n = t.numel() * t.element_size()
@@ -219,9 +263,9 @@ class Plan(object):
             for field, kind, value in relocs:
                 head.append(struct.pack("<IIQ", field, kind, value))
             head.append(data + b"\0" * ((-len(data)) % 8))
-        for name, args in self.calls:
+        for name, args, sid in self.calls:
             head.append(name.encode().ljust(48, b"\0"))
-            head.append(struct.pack("<II", len(args), 0))
+            head.append(struct.pack("<II", len(args), sid))
             for kind, value in args:
                 head.append(struct.pack("<IIQ", kind, 0, value))
         body = b"".join(head)
@@ -258,17 +302,30 @@ def record(net, grd, sat, arena_bytes=None):
             arena_bytes = int(1.5 * (torch.cuda.max_memory_allocated(dev) - before)) + (64 << 20)
         net._packed()                                # the packed weights exist before recording starts
     lib = _lib.load()
-    saved = (ops._record, _lib.load, models.EVAL_TWO_STREAMS, models._OVERLAP_ENV)
-    rec = _Recorder(dev, arena_bytes, grd, sat)
-    try:
-        ops._record = rec
-        proxy = _RecordingLib(lib, rec)
-        _lib.load = lambda: proxy
-        models.EVAL_TWO_STREAMS, models._OVERLAP_ENV = False, "0"        # a plan is one in-order stream of calls
-        with torch.no_grad():
-            outs = net(grd, sat)
-    finally:
-        ops._record, _lib.load, models.EVAL_TWO_STREAMS, models._OVERLAP_ENV = saved
+    saved = (ops._record, _lib.load, torch.cuda.Stream.wait_stream)
+    for attempt in range(4):
+        rec = _Recorder(dev, arena_bytes, grd, sat)
+        orig_wait = saved[2]
+
+        def wait_stream(self, other, _rec=rec, _orig=orig_wait):
+            _rec.wait(self, other)
+            return _orig(self, other)
+        try:
+            ops._record = rec
+            proxy = _RecordingLib(lib, rec)
+            _lib.load = lambda: proxy
+            torch.cuda.Stream.wait_stream = wait_stream
+            with torch.no_grad():
+                outs = net(grd, sat)
+            break
+        except MemoryError:                          # a region was too small (first-fit fragmentation): grow and record again
+            arena_bytes = int(arena_bytes * 1.5)
+            outs = None
+        finally:
+            ops._record, _lib.load, torch.cuda.Stream.wait_stream = saved
+            torch.cuda.synchronize(dev)
+    if outs is None:
+        raise MemoryError("plan.record: workspace regions exhausted after growing the arena")
     torch.cuda.synchronize(dev)
     return Plan(rec, outs, grd, sat), outs
 
