@@ -8,6 +8,7 @@
     ops, backward   one Python wrapper per C entry point of libccvpe_hip.so (include/ccvpe_hip.h), _lib: the ctypes table
     harness     replica timing harness, data-parallel gradient all-reduce (RCCL);  graph: hipGraph capture;  evaluate: sharded eval
     datasets    VIGOR / KITTI / Oxford RobotCar: split files -> index, decode, device batches;  repack: train-mode weight re-pack in one launch
+    plan        the eval forward as one C call: record / serialise a launch plan, PlannedForward (ccvpe_ctx_create / ccvpe_forward)
     synth       deterministic synthetic weights / inputs shared by tests, goldens and bench.py
 
 Everything arithmetic runs in libccvpe_hip.so (ccvpe_amd/csrc/*.hip); there is no CPU or eager fallback.

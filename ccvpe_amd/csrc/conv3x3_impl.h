@@ -43,7 +43,7 @@ struct Conv3Geom {
 };
 
 template <typename T, int MT, int NT, int WN, int NW, bool DMA, int TPS>
-__global__ __launch_bounds__(64 * NW, NW == 8 ? 4 : 2) void conv3x3_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * NW, (NW == 8 && sizeof(T) == 4) ? 4 : 2) void conv3x3_kernel(const IgemmParams p) {
   static_assert(TPS == 1 || (TPS == 3 && DMA), "a row of taps per stage needs the DMA W path");
   using G = Conv3Geom<T, MT, NT, WN, NW, DMA, TPS>;
   constexpr int BLD = G::BLD;                      // floats per W stage row
@@ -536,7 +536,7 @@ static int launch3x3_nw(const IgemmParams& p0, int batch, hipStream_t stream) {
   };
   int rc;
   if (p.Npad % BN == 0) {
-    if constexpr (NW == 4 && !(NT == 5 && WN == 1)) {      // (256 x 80 tile: a row of taps per stage measured the same, 117.8 vs 117.0 TF)
+    if constexpr ((NW == 4 || sizeof(T) == 2) && !(NT == 5 && WN == 1)) {      // (256 x 80 tile: a row of taps per stage measured the same, 117.8 vs 117.0 TF)
       if (g_conv3_tps == 3) rc = go(0, conv3x3_kernel<T, MT, NT, WN, NW, true, 3>, Conv3Geom<T, MT, NT, WN, NW, true, 3>::LDS_BYTES);
       else rc = go(1, conv3x3_kernel<T, MT, NT, WN, NW, true, 1>, Conv3Geom<T, MT, NT, WN, NW, true, 1>::LDS_BYTES);
     } else {
@@ -560,6 +560,16 @@ static int launch3x3(const IgemmParams& p0, int batch, hipStream_t stream) {
     constexpr int BN = 16 * NT * WN;
     const long blocks8 = (long)((p0.W + 15) / 16) * ((p0.H + TH8 - 1) / TH8) * batch * ((p0.Npad + BN - 1) / BN);
     if (g_conv3_nw8 && p0.H % TH8 == 0 && blocks8 >= 512) return launch3x3_nw<T, MT, NT, WN, 8>(p0, batch, stream);
+  }
+  if constexpr (WN == 2 && (NT == 4 || NT == 5) && sizeof(T) == 2) {
+    // bf16: 8 waves share one W panel and one halo (256-pixel tile, a row of taps per stage, one workgroup per CU, no VGPR cap).
+    // Round 4, isolated layers at B = 64 (tools/gpu/ab_c3.sh): 640 -> 640 at 16 x 16 885 -> 916 TF, 320 -> 320 at 32 x 32 832 -> 870,
+    // 1344 -> 640 875 -> 920; 160 -> 160 at 64 x 64 (ONE column tile) 757 -> 734: only layers with >= 2 column tiles take it.
+    constexpr int TH8 = 16 * MT * (8 / WN) / 16;
+    constexpr int BN = 16 * NT * WN;
+    const long tiles_n = (p0.Npad + BN - 1) / BN;
+    const long blocks8 = (long)((p0.W + 15) / 16) * ((p0.H + TH8 - 1) / TH8) * batch * tiles_n;
+    if (p0.H % TH8 == 0 && blocks8 >= 256 && tiles_n >= 2) return launch3x3_nw<T, MT, NT, WN, 8>(p0, batch, stream);
   }
   return launch3x3_nw<T, MT, NT, WN, 4>(p0, batch, stream);
 }

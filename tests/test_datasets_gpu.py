@@ -46,7 +46,7 @@ def test_device_batches_shards_and_model_forward(tmp_path, synth_sd):
     from ccvpe_amd import models
     make_vigor_tree(str(tmp_path))
     ds = DS.VIGORPairs(str(tmp_path), split="crossarea", train=False, ori_noise=180,
-                       random_orientation=os.path.join(GOLDEN, "crossarea_orientation_test_head256.npy"))
+                       random_orientation=os.path.join(GOLDEN, "crossarea_orientation_test_head256.npy"), strict_orientation=False)
     got = [sum((b.indices for b in DS.DeviceBatches(ds, 2, device="cuda", rank=r, world=2, targets=False)), []) for r in range(2)]
     assert sorted(got[0] + got[1]) == list(range(6)) and not set(got[0]) & set(got[1])
     net = models.CVM_VIGOR_ori_prior("cuda", 180, True)
