@@ -99,6 +99,33 @@ def test_a_caller_without_python_reproduces_the_forward(synth_sd, tmp_path):
     assert got.shape == want.shape and np.array_equal(got, want), "the C++ caller's outputs differ from the Python forward"
 
 
+def test_ccvpe_forward_is_capturable_in_a_hipgraph(synth_sd):
+    """ccvpe_forward enqueues on the caller's stream and on the ctx's own side stream, joined through events: a capture on the
+    caller's stream takes the whole forward (both streams) into the graph; the replay reproduces the eager outputs."""
+    from ccvpe_amd import plan
+    net, gshape = _net(synth_sd, "vigor20", "bf16")
+    grd, sat = synth.synthetic_pair(2, gshape, 41)
+    grd, sat = grd.cuda(), sat.cuda()
+    eager = [t.clone() for t in net(grd, sat)]
+    pf = plan.PlannedForward(net, grd, sat)
+    assert pf.plan.n_waits >= 2                            # the recorded fork / join of the two streams
+    pf(grd, sat)
+    torch.cuda.synchronize()
+    sg, ss = grd.clone(), sat.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pf(sg, ss)
+    grd2, sat2 = synth.synthetic_pair(2, gshape, 42)
+    sg.copy_(grd2.cuda())
+    ss.copy_(sat2.cuda())
+    g.replay()
+    torch.cuda.synchronize()
+    want = net(grd2.cuda(), sat2.cuda())
+    for k, (a, b) in enumerate(zip(pf.outputs, want)):
+        assert torch.equal(a, b), "graph replay of ccvpe_forward differs in output %d" % k
+    del eager
+
+
 def test_ctx_rejects_what_it_cannot_replay(synth_sd):
     import ctypes
     from ccvpe_amd import _lib, plan
