@@ -350,32 +350,34 @@ static void dw_geometry(int H, int W, int C, int stride, int* cgx, int* P, int* 
 
 // ---------------------------------------------------------------------------------------------
 // SE gate (model.py:113-118): gate = sigmoid(W2 . swish(W1 . mean + b1) + b2).
-// Latency-bound (a few 100 KFLOP per sample), so the work is spread over G workgroups per sample:
-// each recomputes the cheap squeeze (mean) and FC1 and owns `nsl` 128-channel slices of FC2.  Every workgroup re-reads all of
-// W1 (Cs x C fp32: 221 KB for the 1152-channel blocks) from L2, so G is chosen against the batch: with B >= 64 samples
-// C/128 = 9 workgroups per sample were 576 x 221 KB = 127 MB of L2 reads per launch (23 us for microseconds of arithmetic);
-// the host asks for about 256 workgroups per launch: G = ceil(256 / B), clamped to [1, C/128].
+// A few 100 KFLOP per sample: pure LATENCY.  The round-1..3 kernel (256 threads, 4 outputs per wave and pass, 128-channel FC2
+// slices) was a chain of dependent L2 round trips: the per-dispatch trace of round 4 (tools/gpu/se_trace.sh) shows 7-9 us for
+// the early blocks but 16 / 24 / 51 us for the 480- / 672- / 1152-channel blocks — 20 of the 32 launches of a forward, 0.75 ms per
+// step for microseconds of arithmetic (FC1: 3 passes x 3 round trips over W1; FC2: 24 dependent iterations per slice).
+// Now: 1024 threads per workgroup and every phase is ONE round trip — the partial rows are summed by up to 1024 / (C/4) row lanes
+// with four 16-byte loads in flight each; FC1 gives each of the 16 waves up to three outputs at once (every load of its three W1
+// rows in flight together); FC2 gives a channel of the workgroup's range to 1024 / range threads that split the Cs sum.
+// G workgroups per sample each recompute the cheap squeeze + FC1 and own C / G channels of FC2 (G = ceil(256 / B), <= C / 128).
+// Fixed summation orders throughout (deterministic).
 // ---------------------------------------------------------------------------------------------
-constexpr int SE_SLICE = 128;
+constexpr int SE_THREADS = 1024;
 
-__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ part, int nblk, float inv_hw,
-                                                      const float* __restrict__ w1, const float* __restrict__ b1,
-                                                      const float* __restrict__ w2, const float* __restrict__ b2,
-                                                      float* __restrict__ gate, int C, int Cs, int nsl) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[C^4] | z[Cs^4] | red[256][4]
+__global__ __launch_bounds__(SE_THREADS) void se_gate_kernel(const float* __restrict__ part, int nblk, float inv_hw,
+                                                             const float* __restrict__ w1, const float* __restrict__ b1,
+                                                             const float* __restrict__ w2, const float* __restrict__ b2,
+                                                             float* __restrict__ gate, int C, int Cs, int cpw) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];  // mean[C^4] | z[Cs^4] | red[1024][4]
   float* mean = sm;
   float* z = sm + ((C + 3) & ~3);
   float* red = z + ((Cs + 3) & ~3);       // 16-byte aligned: the row-lane sums are float4
   const int b = blockIdx.y;
   const int tid = threadIdx.x;
-  // The nblk partial rows are summed by R row lanes in parallel (fixed assignment => deterministic).  A thread owns FOUR
-  // channels (one 16-byte load per row) when C % 4 == 0, so a narrow early block (C = 32 ... 240 with 50-128 partial rows)
-  // has 256 / (C/4) = 4 ... 32 row lanes and each walks a few rows with four loads in flight; with one channel per thread
-  // C = 96 left two row lanes walking 64 rows each — ~16 dependent L2 round trips, 50 us for a [64, 128, 96] tensor.
-  if ((C & 3) == 0 && nblk > 1) {
+  const int lane = tid & 63, wave = tid >> 6;
+  // ---- squeeze: mean over the plane = inv_hw * sum of the nblk partial rows ------------------------------------------
+  if ((C & 3) == 0) {
     const int C4 = C >> 2;
-    const int cw = C4 < 256 ? C4 : 256;
-    const int R = 256 / cw;
+    const int cw = C4 < SE_THREADS ? C4 : SE_THREADS;
+    const int R = SE_THREADS / cw;                 // row lanes (fixed assignment of rows to lanes => deterministic)
     f32x4* red4 = reinterpret_cast<f32x4*>(red);
     for (int c0 = 0; c0 < C4; c0 += cw) {
       const int cl = tid % cw, rr = tid / cw;
@@ -392,79 +394,99 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
         }
         for (; q < nblk; q += R) s0 += p[(size_t)q * C4];
       }
-      red4[tid] = (s0 + s1) + (s2 + s3);
-      __syncthreads();
-      if (rr == 0 && c4 < C4) {
-        f32x4 t = red4[cl];
-        for (int j = 1; j < R; ++j) t += red4[j * cw + cl];
-        *reinterpret_cast<f32x4*>(mean + 4 * c4) = t * inv_hw;
+      if (R == 1) {
+        if (c4 < C4 && rr == 0) *reinterpret_cast<f32x4*>(mean + 4 * c4) = ((s0 + s1) + (s2 + s3)) * inv_hw;
+      } else {
+        red4[tid] = (s0 + s1) + (s2 + s3);
+        __syncthreads();
+        if (rr == 0 && c4 < C4) {
+          f32x4 t = red4[cl];
+          for (int j = 1; j < R; ++j) t += red4[j * cw + cl];
+          *reinterpret_cast<f32x4*>(mean + 4 * c4) = t * inv_hw;
+        }
       }
       __syncthreads();
     }
   } else {
-  const int cw = C < 256 ? C : 256;
-  const int R = 256 / cw;
-  for (int c0 = 0; c0 < C; c0 += cw) {
-    const int cl = tid % cw, rr = tid / cw;
-    const int c = c0 + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (rr < R && c < C) {
-      const float* p = part + (size_t)b * nblk * C + c;
-      int q = rr;
-      for (; q + 3 * R < nblk; q += 4 * R) {     // 4 independent loads in flight
-        s0 += p[(size_t)q * C];
-        s1 += p[(size_t)(q + R) * C];
-        s2 += p[(size_t)(q + 2 * R) * C];
-        s3 += p[(size_t)(q + 3 * R) * C];
+    const int cw = C < SE_THREADS ? C : SE_THREADS;
+    const int R = SE_THREADS / cw;
+    for (int c0 = 0; c0 < C; c0 += cw) {
+      const int cl = tid % cw, rr = tid / cw;
+      const int c = c0 + cl;
+      float s0 = 0.f, s1 = 0.f;
+      if (rr < R && c < C) {
+        const float* p = part + (size_t)b * nblk * C + c;
+        int q = rr;
+        for (; q + R < nblk; q += 2 * R) {
+          s0 += p[(size_t)q * C];
+          s1 += p[(size_t)(q + R) * C];
+        }
+        if (q < nblk) s0 += p[(size_t)q * C];
       }
-      for (; q < nblk; q += R) s0 += p[(size_t)q * C];
+      red[tid] = s0 + s1;
+      __syncthreads();
+      if (rr == 0 && c < C) {
+        float t = red[cl];
+        for (int j = 1; j < R; ++j) t += red[j * cw + cl];
+        mean[c] = t * inv_hw;
+      }
+      __syncthreads();
     }
-    red[tid] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (rr == 0 && c < C) {
-      float t = red[cl];
-      for (int j = 1; j < R; ++j) t += red[j * cw + cl];
-      mean[c] = t * inv_hw;
-    }
-    __syncthreads();
   }
-  }
-  const int lane = tid & 63, wave = tid >> 6;
-  // FC1: 4 outputs per pass and wave (independent accumulators: the loads of 4 weight rows are in
-  // flight together; one pass per output made this kernel a chain of ~12 L2 latencies)
-  for (int j0 = wave * 4; j0 < Cs; j0 += 16) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    const int j1 = min(j0 + 1, Cs - 1), j2 = min(j0 + 2, Cs - 1), j3 = min(j0 + 3, Cs - 1);
-#pragma unroll 6                             // 24 independent weight loads in flight per pass (C = 1152: 3 round trips, not 18)
-    for (int c = lane; c < C; c += 64) {
-      const float m = mean[c];
-      s0 = fmaf(w1[(size_t)j0 * C + c], m, s0);
-      s1 = fmaf(w1[(size_t)j1 * C + c], m, s1);
-      s2 = fmaf(w1[(size_t)j2 * C + c], m, s2);
-      s3 = fmaf(w1[(size_t)j3 * C + c], m, s3);
+  // ---- FC1: wave w owns outputs w, w + 16, w + 32 (three at once: all of their W1 loads are in flight together) -------
+  for (int j0 = wave; j0 < Cs; j0 += 48) {
+    const int j1 = min(j0 + 16, Cs - 1), j2 = min(j0 + 32, Cs - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    if ((C & 3) == 0) {
+      const int C4 = C >> 2;
+      const f32x4* r0 = reinterpret_cast<const f32x4*>(w1 + (size_t)j0 * C);
+      const f32x4* r1 = reinterpret_cast<const f32x4*>(w1 + (size_t)j1 * C);
+      const f32x4* r2 = reinterpret_cast<const f32x4*>(w1 + (size_t)j2 * C);
+#pragma unroll 5                             // C = 1152: 4.5 x 3 sixteen-byte loads per lane, one round trip
+      for (int c4 = lane; c4 < C4; c4 += 64) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(mean + 4 * c4);
+        const f32x4 a = r0[c4], bb = r1[c4], cc = r2[c4];
+        s0 += a[0] * m[0] + a[1] * m[1] + a[2] * m[2] + a[3] * m[3];
+        s1 += bb[0] * m[0] + bb[1] * m[1] + bb[2] * m[2] + bb[3] * m[3];
+        s2 += cc[0] * m[0] + cc[1] * m[1] + cc[2] * m[2] + cc[3] * m[3];
+      }
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        const float m = mean[c];
+        s0 = fmaf(w1[(size_t)j0 * C + c], m, s0);
+        s1 = fmaf(w1[(size_t)j1 * C + c], m, s1);
+        s2 = fmaf(w1[(size_t)j2 * C + c], m, s2);
+      }
     }
-    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2); s3 = wave_sum(s3);
+    s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
     if (lane == 0) {
       z[j0] = swishf(s0 + b1[j0]);
-      if (j0 + 1 < Cs) z[j0 + 1] = swishf(s1 + b1[j0 + 1]);
-      if (j0 + 2 < Cs) z[j0 + 2] = swishf(s2 + b1[j0 + 2]);
-      if (j0 + 3 < Cs) z[j0 + 3] = swishf(s3 + b1[j0 + 3]);
+      if (j0 + 16 < Cs) z[j0 + 16] = swishf(s1 + b1[j0 + 16]);
+      if (j0 + 32 < Cs) z[j0 + 32] = swishf(s2 + b1[j0 + 32]);
     }
   }
   __syncthreads();
-  // FC2 slices: 2 threads per channel split the Cs sum (w2 is [Cs][C]: coalesced over c)
-  const int hsel = tid >> 7;                 // 0 or 1
-  for (int u = 0; u < nsl; ++u) {
-    const int c = (blockIdx.x * nsl + u) * SE_SLICE + (tid & (SE_SLICE - 1));
+  // ---- FC2 for this workgroup's channels [c_lo, c_lo + cpw): JG threads per channel split the Cs sum (w2 is [Cs][C]:
+  // coalesced over c), every load of a thread in flight together -------------------------------------------------------
+  const int c_lo = blockIdx.x * cpw;
+  const int cwid = cpw < SE_THREADS ? cpw : SE_THREADS;
+  const int JG = SE_THREADS / cwid;
+  for (int cb = 0; cb < cpw; cb += cwid) {
+    const int cg = tid % cwid, jg = tid / cwid;
+    const int c = c_lo + cb + cg;
     float s = 0.f;
-    if (c < C) {
+    if (jg < JG && cb + cg < cpw && c < C) {
 #pragma unroll 8
-      for (int j = hsel; j < Cs; j += 2) s = fmaf(w2[(size_t)j * C + c], z[j], s);
+      for (int j = jg; j < Cs; j += JG) s = fmaf(w2[(size_t)j * C + c], z[j], s);
     }
-    if (u) __syncthreads();                  // red[] of the previous slice has been consumed
+    if (cb) __syncthreads();                 // red[] of the previous chunk has been consumed
     red[tid] = s;
     __syncthreads();
-    if (hsel == 0 && c < C) gate[(size_t)b * C + c] = sigmoidf(red[tid] + red[tid + SE_SLICE] + b2[c]);
+    if (jg == 0 && cb + cg < cpw && c < C) {
+      float t = red[cg];
+      for (int j = 1; j < JG; ++j) t += red[j * cwid + cg];
+      gate[(size_t)b * C + c] = sigmoidf(t + b2[c]);
+    }
   }
 }
 
@@ -567,12 +589,19 @@ extern "C" int ccvpe_dwconv_bf16(const void* x, const float* w, const float* sca
 extern "C" int ccvpe_se_gate_f32(const float* part, int nblk, float inv_hw, const float* w1, const float* b1,
                                  const float* w2, const float* b2, float* gate, int B, int C, int Cs, void* stream) {
   if (B <= 0 || C <= 0 || Cs <= 0 || nblk <= 0) return fail(CCVPE_EINVAL, "se_gate: bad shape");
-  const size_t smem = (size_t)(((C + 3) & ~3) + ((Cs + 3) & ~3) + 1024) * sizeof(float);
-  const int slices = (C + SE_SLICE - 1) / SE_SLICE;
+  const size_t smem = (size_t)(((C + 3) & ~3) + ((Cs + 3) & ~3) + 4 * SE_THREADS) * sizeof(float);
+  const int slices = (C + 127) / 128;
   int g = (256 + B - 1) / B;                 // workgroups per sample (see the kernel's comment)
   g = g < 1 ? 1 : (g > slices ? slices : g);
-  const int nsl = (slices + g - 1) / g;
-  hipLaunchKernelGGL(se_gate_kernel, dim3((slices + nsl - 1) / nsl, B), dim3(256), smem, (hipStream_t)stream, part,
-                     nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs, nsl);
+  const int cpw = (((C + g - 1) / g) + 3) & ~3;        // channels per workgroup
+  static bool attr_set = false;
+  if (!attr_set && smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)se_gate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+      return fail(CCVPE_ELAUNCH, "se_gate: set smem attr");
+    attr_set = true;
+  }
+  if (smem > 64 * 1024) return fail(CCVPE_EINVAL, "se_gate: C = %d is too wide", C);
+  hipLaunchKernelGGL(se_gate_kernel, dim3((C + cpw - 1) / cpw, B), dim3(SE_THREADS), smem, (hipStream_t)stream, part,
+                     nblk, inv_hw, w1, b1, w2, b2, gate, C, Cs, cpw);
   return check_launch("se_gate_kernel");
 }

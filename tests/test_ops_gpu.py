@@ -347,8 +347,9 @@ def test_dwconv_and_squeeze(ops, k, s, c, h, w, circ):
     close(part.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials")
 
 
-def test_se_gate(ops):
-    b, c, cs, nblk = 3, 240, 10, 7
+@pytest.mark.parametrize("b,c,cs,nblk", [(3, 240, 10, 7), (64, 1152, 48, 1), (2, 1152, 48, 1), (64, 672, 28, 1), (5, 480, 20, 1),
+                                          (64, 96, 4, 128), (7, 144, 6, 100), (300, 32, 8, 64), (4, 30, 7, 5), (1, 2048, 100, 3)])
+def test_se_gate(ops, b, c, cs, nblk):
     part = synth.normal((b, nblk, c), 50)
     w1 = synth.normal((cs, c), 51, 0.1)
     b1 = synth.normal((cs,), 52, 0.1)
@@ -358,7 +359,7 @@ def test_se_gate(ops):
     z = O.swish(mean @ w1.t() + b1)
     want = torch.sigmoid(z @ w2.t() + b2)
     got = ops.se_gate(dev(part), 35, dev(w1), dev(b1), dev(w2.t()), dev(b2))
-    close(got, want, 1e-5, "se gate")
+    close(got, want, 1e-5, "se gate b%d c%d" % (b, c))
 
 
 @pytest.mark.parametrize("circ", [True, False])
