@@ -51,7 +51,7 @@ class TailDesc(ctypes.Structure):
         ("x", c_void_p), ("w", c_void_p), ("shift9", c_void_p), ("w2", c_void_p), ("b2", c_void_p), ("out", c_void_p),
         ("batch", c_int), ("h1", c_int), ("w1", c_int),
         ("c0", c_int), ("ld0", c_int), ("kpad", c_int),
-        ("cout", c_int), ("normalize", c_int), ("split", c_int),
+        ("cout", c_int), ("normalize", c_int), ("split", c_int), ("softmax_partial", c_void_p),
     ]
 
 
@@ -69,6 +69,8 @@ PROTOTYPES = {
     "ccvpe_ctx_output": (c_int, [c_void_p, c_int, ctypes.POINTER(c_void_p), ctypes.POINTER(ctypes.c_longlong),
                                   ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "ccvpe_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
+    "ccvpe_tail512_partials": (c_int, [ctypes.POINTER(TailDesc), c_int]),
+    "ccvpe_softmax_apply_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_tail512_f32": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_tail512_bf16": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),

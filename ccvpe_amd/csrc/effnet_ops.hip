@@ -10,78 +10,93 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // ---------------------------------------------------------------------------------------------
 // Stem: 3x3 stride-2 conv, NCHW image -> NHWC [.,32], folded BN + swish.
 // efficientnet_pytorch/model.py:181-182,289 ; padding utils.py:265-277 (zero), :341-353 (circular W)
-// One thread per output pixel, all 32 output channels in registers; weights broadcast from LDS.
-// ---------------------------------------------------------------------------------------------
+//
+// Round 4: on the fp32 matrix cores.  The round-1..3 kernel (one thread per output pixel, 864 FMAs against LDS-broadcast
+// weights, 27 strided dword gathers) took 213 us per aerial batch whatever the output type (469 MB bf16 / 738 MB fp32: neither
+// HBM- nor FMA-bound — load-issue and LDS-broadcast bound).  Now a workgroup stages the (2 TH + 1) x (2 TW + 1) x 3 input patch of
+// a TH x TW output tile in LDS with coalesced row loads and computes out[pixel][32] = patch[pixel][27] . W[27][32] as
+// v_mfma_f32_16x16x4_f32: K = 27 padded to 28 = 7 k-steps, N = 32 = 2 column tiles, W (14 registers per lane) loaded once; a lane's
+// B operand for k-step s is ONE ds_read_b32 at a per-lane constant offset (its k = 4s + q picks (ky, kx, ci)) plus the pixel's
+// column.  Exact fp32 (the fp32 MFMA is a k-ordered fmaf chain), for both output types.  The C layout gives a lane 4 consecutive
+// channels of one pixel: 16-byte (fp32) / 8-byte (bf16) stores, a pixel's 128 bytes complete within two store instructions.
 // RAW: write the convolution result only (train mode: BatchNorm needs the batch statistics first)
+// ---------------------------------------------------------------------------------------------
+constexpr int ST_TH = 4, ST_TW = 64;                   // output tile: one wave per output row, 4 pixel tiles of 16 per wave
+constexpr int ST_IR = 2 * ST_TH + 1, ST_IC = 2 * ST_TW + 1, ST_PITCH = ST_IC + 3;    // input patch rows / columns / LDS pitch
+
 template <typename T, bool RAW>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, T* __restrict__ y,
-                                                        int B, int H, int W, int Ho, int Wo, int circular) {
-  __shared__ __attribute__((aligned(16))) float ws[27 * 32];
-  __shared__ float ssc[32], ssh[32];
-  for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = w[i];
-  if (threadIdx.x < 32) {
-    ssc[threadIdx.x] = RAW ? 1.f : scale[threadIdx.x];
-    ssh[threadIdx.x] = RAW ? 0.f : shift[threadIdx.x];
+                                                        int B, int H, int W, int Ho, int Wo, int circular, int tiles_x,
+                                                        int tiles_y) {
+  __shared__ float img[3 * ST_IR * ST_PITCH];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pix = lane & 15, q = lane >> 4;
+  int lb;
+  {                                                    // XCD-aware order: neighbouring tiles of a sample share input rows in one L2
+    const int total = gridDim.x;
+    const int qq = total / 8, r = total % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + loc;
+  }
+  const int tx = lb % tiles_x, ty = (lb / tiles_x) % tiles_y, b = lb / (tiles_x * tiles_y);
+  const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+  // ---- the input patch: rows 2 oy0 .. 2 oy0 + 8, columns 2 ox0 .. 2 ox0 + 128 of the three planes (pad before = 0) --------
+  const float* xb = x + (size_t)b * 3 * H * W;
+  for (int idx = tid; idx < 3 * ST_IR * ST_PITCH; idx += 256) {
+    const int row = idx / ST_PITCH, c = idx - row * ST_PITCH;
+    const int ci = row / ST_IR, r = row - ci * ST_IR;
+    const int iy = 2 * oy0 + r;
+    int ix = 2 * ox0 + c;
+    if (circular && ix >= W) ix -= W;
+    const bool ok = c < ST_IC && iy < H && ix < W;
+    img[idx] = ok ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+  }
+  // ---- W fragments (A operand: lane (n = pix, q) supplies W[k = 4 s + q][n]) and the lane's patch offsets ----------------
+  float wr[7][2];
+  int off[7];
+#pragma unroll
+  for (int s = 0; s < 7; ++s) {
+    const int k = 4 * s + q;
+    const bool kv = k < 27;
+    const int kc = kv ? k : 0;
+    wr[s][0] = kv ? w[kc * 32 + pix] : 0.f;
+    wr[s][1] = kv ? w[kc * 32 + 16 + pix] : 0.f;
+    const int tap = kc / 3, ci = kc - tap * 3;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    off[s] = (ci * ST_IR + 2 * wave + ky) * ST_PITCH + kx + 2 * pix;
+  }
+  f32x4 sc[2], sh[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sc[j] = RAW ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(scale + 16 * j + 4 * q);
+    sh[j] = RAW ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(shift + 16 * j + 4 * q);
   }
   __syncthreads();
-  // output rows go through LDS: a thread owns one pixel (32 channels = 128 bytes), so storing from registers made every
-  // store instruction touch 64 different cache lines with 16 bytes each (1.66 TB/s algorithmic on a pure streaming kernel);
-  // staged [pixel][32 + 4 pad] the workgroup writes its 256 pixels x 128 bytes as one contiguous 32 KB run
-  __shared__ __attribute__((aligned(16))) float ot[256 * 36];
-  const long total = (long)B * Ho * Wo;
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  const bool live = idx < total;
-  const long idc = live ? idx : total - 1;
-  const int ox = (int)(idc % Wo);
-  const int oy = (int)((idc / Wo) % Ho);
-  const int b = (int)(idc / ((long)Wo * Ho));
-
-  float acc[32];
+  const int oy = oy0 + wave;
 #pragma unroll
-  for (int c = 0; c < 32; ++c) acc[c] = 0.f;
-  const size_t plane = (size_t)H * W;
+  for (int i = 0; i < ST_TW / 16; ++i) {
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    float xv[7];
 #pragma unroll
-  for (int ky = 0; ky < 3; ++ky) {
-    const int iy = 2 * oy + ky;  // pad before = 0
-    if (iy >= H) continue;
+    for (int s = 0; s < 7; ++s) xv[s] = img[off[s] + 32 * i];
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
-      int ix = 2 * ox + kx;
-      if (ix >= W) {
-        if (!circular) continue;
-        ix -= W;
-      }
-#pragma unroll
-      for (int ci = 0; ci < 3; ++ci) {
-        const float v = x[((size_t)(b * 3 + ci)) * plane + (size_t)iy * W + ix];
-        const float* wp = &ws[((ky * 3 + kx) * 3 + ci) * 32];
-#pragma unroll
-        for (int c = 0; c < 32; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
-      }
+    for (int s = 0; s < 7; ++s) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[s][0], xv[s], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[s][1], xv[s], acc1, 0, 0, 0);
     }
-  }
+    const int ox = ox0 + 16 * i + pix;
+    if (oy < Ho && ox < Wo) {
+      T* dst = y + (((size_t)b * Ho + oy) * Wo + ox) * 32 + 4 * q;
+      f32x4 v0 = acc0 * sc[0] + sh[0], v1 = acc1 * sc[1] + sh[1];
+      if (!RAW) {
 #pragma unroll
-  for (int c4 = 0; c4 < 8; ++c4) {
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int c = c4 * 4 + j;
-      const float v = acc[c] * ssc[c] + ssh[c];
-      o[j] = RAW ? acc[c] : swishf(v);
+        for (int r = 0; r < 4; ++r) { v0[r] = swishf(v0[r]); v1[r] = swishf(v1[r]); }
+      }
+      st4<T>(dst, v0);
+      st4<T>(dst + 16, v1);
     }
-    *reinterpret_cast<f32x4*>(&ot[threadIdx.x * 36 + c4 * 4]) = o;
-  }
-  __syncthreads();
-  const long p0 = (long)blockIdx.x * 256;
-  const int npx = (int)(total - p0 < 256 ? total - p0 : 256);
-  T* out = y + (size_t)p0 * 32;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int piece = it * 256 + threadIdx.x;      // consecutive lanes -> consecutive 16-byte (fp32) / 8-byte (bf16) pieces
-    const int pp = piece >> 3, c4 = piece & 7;
-    if (pp < npx) st4<T>(out + (size_t)pp * 32 + c4 * 4, *reinterpret_cast<const f32x4*>(&ot[pp * 36 + c4 * 4]));
   }
 }
 
@@ -500,9 +515,11 @@ static int stem_any(const float* x, const float* w, const float* scale, const fl
   if (B <= 0 || H < 3 || W < 3) return fail(CCVPE_EINVAL, "stem: bad shape");
   if (!aligned16(y)) return fail(CCVPE_EINVAL, "stem: y must be 16-byte aligned");
   const int Ho = (H + 1 - 3) / 2 + 1, Wo = (W + 1 - 3) / 2 + 1;
-  const long total = (long)B * Ho * Wo;
-  hipLaunchKernelGGL((stem_conv_kernel<T, RAW>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     w, scale, shift, y, B, H, W, Ho, Wo, circular);
+  const int tiles_x = (Wo + ST_TW - 1) / ST_TW, tiles_y = (Ho + ST_TH - 1) / ST_TH;
+  const long total = (long)B * tiles_x * tiles_y;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "stem: grid too large");
+  hipLaunchKernelGGL((stem_conv_kernel<T, RAW>), dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, x, w, scale, shift, y,
+                     B, H, W, Ho, Wo, circular, tiles_x, tiles_y);
   return check_launch("stem_conv_kernel");
 }
 

@@ -168,6 +168,33 @@ __global__ __launch_bounds__(1024) void softmax_rows_kernel(const float* __restr
   for (int i = (n4 << 2) + threadIdx.x; i < n; i += blockDim.x) o[i] = expf(r[i] - m) * inv;
 }
 
+// Softmax from per-piece partials (ccvpe_tail512 writes (max, sum exp(l - max)) for every piece of a row it produced):
+// workgroup (slice, row) merges the row's P partial pairs — M = max m_p, S = sum s_p exp(m_p - M), fixed order — and writes
+// exp(l - M) / S for its slice of the row.  One read of the logits and one write of the heat-map by rows x slices workgroups.
+__global__ __launch_bounds__(1024) void softmax_apply_kernel(const float* __restrict__ in, const float* __restrict__ part,
+                                                             int P, float* __restrict__ out, int n, int slice_len) {
+  __shared__ float sh[16];
+  const int row = blockIdx.y;
+  const float* pr = part + (size_t)row * P * 2;
+  float m = -INFINITY;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) m = fmaxf(m, pr[2 * i]);
+  m = block_max(m, sh);
+  float s = 0.f;
+  for (int i = threadIdx.x; i < P; i += blockDim.x) s += pr[2 * i + 1] * expf(pr[2 * i] - m);
+  s = block_sum(s, sh);
+  const float inv = 1.0f / s;
+  const int e0 = blockIdx.x * slice_len, e1 = min(e0 + slice_len, n);
+  const float* r = in + (size_t)row * n;
+  float* o = out + (size_t)row * n;
+  for (int i = e0 + 4 * threadIdx.x; i < e1; i += 4 * blockDim.x) {      // slice_len % 4 == 0 and n % 4 == 0
+    const f32x4 v = *reinterpret_cast<const f32x4*>(r + i);
+    f32x4 e;
+    e[0] = expf(v[0] - m) * inv; e[1] = expf(v[1] - m) * inv;
+    e[2] = expf(v[2] - m) * inv; e[3] = expf(v[3] - m) * inv;
+    *reinterpret_cast<f32x4*>(o + i) = e;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Losses (losses.py).  Stage 1: one workgroup per sample writes partial (num, den); stage 2: one
 // wave combines them in fixed order.  masked_select is rewritten as a masked sum (graph-capturable).
@@ -404,6 +431,18 @@ extern "C" int ccvpe_softmax_rows_f32(const float* in, float* out, int rows, int
   if (!aligned16(in) || !aligned16(out) || (n % 4)) return fail(CCVPE_EINVAL, "softmax: 16-byte aligned rows required");
   hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(1024), 0, (hipStream_t)stream, in, out, n);
   return check_launch("softmax_rows_kernel");
+}
+
+extern "C" int ccvpe_softmax_apply_f32(const float* logits, const float* partials, int n_partials, float* out, int rows, int n,
+                                       void* stream) {
+  if (rows <= 0 || n <= 0 || n_partials <= 0 || rows > 65535) return fail(CCVPE_EINVAL, "softmax_apply: bad shape");
+  if (!aligned16(logits) || !aligned16(out) || (n % 4)) return fail(CCVPE_EINVAL, "softmax_apply: 16-byte aligned rows required");
+  int slices = (1024 + rows - 1) / rows;               // ~1024 workgroups per launch
+  slices = slices < 1 ? 1 : (slices > 64 ? 64 : slices);
+  const int slice_len = (((n + slices - 1) / slices) + 3) & ~3;
+  hipLaunchKernelGGL(softmax_apply_kernel, dim3((n + slice_len - 1) / slice_len, rows), dim3(1024), 0, (hipStream_t)stream, logits,
+                     partials, n_partials, out, n, slice_len);
+  return check_launch("softmax_apply_kernel");
 }
 
 extern "C" int ccvpe_eval_postprocess_f32(const float* heatmap, const float* ori, float* out, int B, int h, int w,

@@ -52,7 +52,7 @@ static const std::unordered_map<std::string, Invoker>& registry() {
       CCVPE_REG(ccvpe_dwconv_f32), CCVPE_REG(ccvpe_dwconv_bf16), CCVPE_REG(ccvpe_mbconv_front_f32), CCVPE_REG(ccvpe_mbconv_front_bf16),
       CCVPE_REG(ccvpe_se_gate_f32), CCVPE_REG(ccvpe_ground_descriptor_f32), CCVPE_REG(ccvpe_match_level_f32),
       CCVPE_REG(ccvpe_match_level_bf16), CCVPE_REG(ccvpe_head_conv3x3_f32), CCVPE_REG(ccvpe_head_conv3x3_bf16),
-      CCVPE_REG(ccvpe_softmax_rows_f32), CCVPE_REG(ccvpe_cast_bf16_f32), CCVPE_REG(ccvpe_eval_postprocess_f32),
+      CCVPE_REG(ccvpe_softmax_rows_f32), CCVPE_REG(ccvpe_softmax_apply_f32), CCVPE_REG(ccvpe_cast_bf16_f32), CCVPE_REG(ccvpe_eval_postprocess_f32),
   };
   return r;
 }

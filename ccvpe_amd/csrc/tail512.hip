@@ -46,6 +46,7 @@ struct TailParams {
   const float* w2;
   const float* b2;
   float* out;
+  float* smx;        // cout == 1, optional: per (tile, wave) softmax partials (max, sum exp(l - max)) of the logits this wave wrote
   int H1, W1, c0, ld0, Kpad, normalize;
   int tiles_x, tiles_y, tiles_total, tiles_per_wg;
 };
@@ -349,6 +350,24 @@ __global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams 
     for (int o = 0; o < COUT; ++o)
       p.out[((size_t)(b * COUT + o) * H2 + 2 * y0 + Yo) * W2 + 2 * x0 + Xo] = res[o][k];
   }
+  if (COUT == 1 && p.smx) {
+    // softmax partials of the heat-map head (models.py:319-320), one pair per (tile, wave): the row-wide max / sum sweeps of
+    // softmax_rows_kernel (64 workgroups, one CU's bandwidth each: 108 us at B = 64) become a 2 KB merge in
+    // softmax_apply_kernel.  Wave-local: no LDS, no barrier.
+    float m = res[0][0];
+#pragma unroll
+    for (int k = 1; k < G::NOUT; ++k) m = fmaxf(m, res[0][k]);
+    m = wave_max(m);
+    float e = 0.f;
+#pragma unroll
+    for (int k = 0; k < G::NOUT; ++k) e += expf(res[0][k] - m);
+    e = wave_sum(e);
+    if (lane == 0) {
+      float* dst = p.smx + ((size_t)t * G::NW + wave) * 2;       // tile index t is sample-major: [B][tiles][waves][2]
+      dst[0] = m;
+      dst[1] = e;
+    }
+  }
   if constexpr (!PERSIST) break;                     // one tile per workgroup
   tile_coords(min(t + 1, t_end - 1), b, y0, x0);
   __syncthreads();                                   // the tap planes are dead: the next tile's halo may overwrite them
@@ -395,6 +414,7 @@ static int tail_any(const ccvpe_tail_desc* d, void* stream) {
   if (d->h1 % 16 || d->w1 % 16) return fail(CCVPE_EINVAL, "tail512: h1 and w1 must be multiples of 16 (got %d x %d)", d->h1, d->w1);
   TailParams p;
   p.x = d->x; p.w = d->w; p.shift9 = d->shift9; p.w2 = d->w2; p.b2 = d->b2; p.out = d->out;
+  p.smx = d->cout == 1 ? d->softmax_partial : nullptr;
   p.H1 = d->h1; p.W1 = d->w1; p.c0 = d->c0; p.ld0 = d->ld0; p.Kpad = d->kpad; p.normalize = d->normalize;
   p.tiles_x = p.tiles_y = p.tiles_total = p.tiles_per_wg = 0;
   const int nch = (d->c0 + SK - 1) / SK;
@@ -425,9 +445,22 @@ static int tail_any(const ccvpe_tail_desc* d, void* stream) {
                             "with c0 <= 64, cout 2 with c0 <= 32)", d->cout, d->c0);
 }
 
+// (tile rows, tile columns, waves) of the instantiation a descriptor runs: the softmax-partial count depends on it
+template <typename T>
+static int tail_partials(const ccvpe_tail_desc* d) {
+  if (!d || d->h1 <= 0 || d->w1 <= 0) return fail(CCVPE_EINVAL, "tail512_partials: bad desc");
+  const bool small = sizeof(T) == 2 || d->split;                 // 8 x 16 tiles (bf16, split), 16 x 16 otherwise; 4 waves
+  const int ty = small ? 8 : 16;
+  if (d->h1 % ty || d->w1 % 16) return fail(CCVPE_EINVAL, "tail512_partials: shape not tiled");
+  return (d->h1 / ty) * (d->w1 / 16) * 4;
+}
+
 }  // namespace ccvpe
 
 using namespace ccvpe;
 
+extern "C" int ccvpe_tail512_partials(const ccvpe_tail_desc* desc, int is_bf16) {
+  return is_bf16 ? tail_partials<bf16_t>(desc) : tail_partials<float>(desc);
+}
 extern "C" int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream) { return tail_any<float>(desc, stream); }
 extern "C" int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream) { return tail_any<bf16_t>(desc, stream); }

@@ -630,6 +630,7 @@ class _CVMBase(nn.Module):
             overlap = _overlap_decoders(self.precision)
             loc_shifts = self._loc_shifts()
             scores_out = []
+            smx = None
             x = sdesc
             cat6 = None
             goff = 0
@@ -675,8 +676,9 @@ class _CVMBase(nn.Module):
                     # the whole 512 x 512 level in one launch: deconv1 + conv1 -> logits (models.py:124-127,319)
                     # (bf16 storage path: its fp32 tail multiplies on the bf16 matrix cores with hi + lo operand planes — fp32-class
                     # accuracy at a quarter of the matrix cycles; the fp32 path is exact fp32)
-                    logits_map = ops.tail512(cat, lv.ldo, lv.fw, lv.fshift, lv.w_b, lv.b_b, 1, False, batch=batch, h1=hw, w1=hw,
-                                             split=(self.precision == "bf16" and cat.dtype == torch.float32 and SPLIT_TAIL))
+                    logits_map, smx = ops.tail512(cat, lv.ldo, lv.fw, lv.fshift, lv.w_b, lv.b_b, 1, False, batch=batch, h1=hw, w1=hw,
+                                                  split=(self.precision == "bf16" and cat.dtype == torch.float32 and SPLIT_TAIL),
+                                                  want_softmax=True)
                     break
                 if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:   # deconv folded into conv.0: one GEMM per output parity
                     y = ops.upconv3x3(cat, lv.ldo, lv.fw, lv.fshift, lv.n_a, batch=batch, h1=hw, w1=hw,
@@ -693,7 +695,10 @@ class _CVMBase(nn.Module):
                 else:
                     logits_map = ops.head_conv3x3(y, lv.w_b, lv.b_b, 1, False)      # [B,1,512,512]
             logits = logits_map.reshape(batch, -1)                                   # models.py:319
-            heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)             # models.py:320
+            if smx is not None:      # the fused 512 x 512 level left per-tile softmax partials: one pass instead of three sweeps
+                heatmap = ops.softmax_apply(logits, smx).reshape(logits_map.shape)   # models.py:320
+            else:
+                heatmap = ops.softmax_rows(logits).reshape(logits_map.shape)
 
             if overlap:
                 main.wait_stream(side)          # join the orientation decoder

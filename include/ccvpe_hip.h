@@ -151,10 +151,17 @@ typedef struct ccvpe_tail_desc {
   int batch, h1, w1;
   int c0, ld0, kpad;
   int cout, normalize, split;
+  float* softmax_partial;   /* cout = 1, optional (NULL: not written): [B][ccvpe_tail512_partials()][2] = (max, sum exp(l - max)) of the
+                               logits of every (tile, wave) — the heat-map softmax (models.py:319-320) then needs no row-wide max /
+                               sum sweep: ccvpe_softmax_apply_f32 */
 } ccvpe_tail_desc;
 
 int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream);
 int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream);
+int ccvpe_tail512_partials(const ccvpe_tail_desc* desc, int is_bf16);   /* partial pairs per sample for this descriptor (launches nothing) */
+/* Softmax(dim=-1) over rows of n logits from n_partials (max, sum exp) pairs per row (models.py:320): out = exp(l - M) / S. */
+int ccvpe_softmax_apply_f32(const float* logits, const float* partials, int n_partials, float* out, int rows, int n,
+                            void* stream);
 
 /* -------------------------------------------------------------------------------------------
  * The WHOLE eval forward behind one entry point (csrc/plan.hip) — replaces the call sites

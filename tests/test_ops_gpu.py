@@ -281,6 +281,14 @@ def test_tail512_fuses_the_512_level(ops, cp, cref, cout, h1, w1, bf16):
         assert float((got.pow(2).sum(1).sqrt() - 1).abs().max()) < 1e-5
     else:
         close(got.cpu(), want, 2e-2 if bf16 else 1e-5, "tail512 cp=%d" % cp)
+    if cout == 1:
+        # the heat-map softmax (models.py:319-320) from the per-(tile, wave) partials the same launch leaves behind
+        lg, smx = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), 1, False, batch=b, h1=h1, w1=w1, want_softmax=True)
+        assert torch.equal(lg, got)
+        heat = ops.softmax_apply(lg.reshape(b, -1), smx)
+        want_h = torch.softmax(lg.reshape(b, -1).double().cpu(), dim=1)
+        assert float((heat.cpu().double() - want_h).abs().max() / want_h.max()) < 1e-5
+        assert float((heat.sum(1) - 1).abs().max()) < 1e-5
     # the unfused HIP pair on the same operands
     y = ops.upconv3x3(xd, cp, fw, fshift, 16, batch=b, h1=h1, w1=w1, act=ops.ACT_RELU)
     ref2 = ops.head_conv3x3(y, w2p, b2.cuda(), cout, cout == 2)
@@ -313,6 +321,10 @@ def test_tail512_split_bf16_planes_are_fp32_class(ops, cp, cref, h1, w1):
     split = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), 1, False, batch=b, h1=h1, w1=w1, split=True)
     close(exact.cpu(), want, 1e-5, "tail512 fp32")
     close(split.cpu(), want, 3e-5, "tail512 split")
+    lg, smx = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), 1, False, batch=b, h1=h1, w1=w1, split=True, want_softmax=True)
+    heat = ops.softmax_apply(lg.reshape(b, -1), smx)
+    want_h = torch.softmax(lg.reshape(b, -1).double().cpu(), dim=1)
+    assert float((heat.cpu().double() - want_h).abs().max() / want_h.max()) < 1e-5
 
 
 # ------------------------------------------------------------------------------------------
@@ -328,6 +340,26 @@ def test_stem_golden(ops, circ, synth_sd):
     sc, sh = _fold_bn(sd, pfx + "._bn0")
     got = ops.stem_conv(dev(x), dev(sd[pfx + "._conv_stem.weight"].permute(2, 3, 1, 0)), dev(sc), dev(sh), circ)
     close(nchw(got), torch.from_numpy(want), 1e-4, "stem")
+
+
+@pytest.mark.parametrize("b,h,w,circ,bf16", [(2, 70, 301, True, False), (3, 37, 130, False, False), (1, 320, 640, True, True),
+                                             (2, 154, 231, False, True)])
+def test_stem_tiles_borders_and_wrap(ops, b, h, w, circ, bf16):
+    """The MFMA stem on shapes that are not multiples of its 4 x 64 output tile, odd sizes (Oxford's 154 x 231), zero and circular
+    padding (static SAME from the 224 schedule: pad (0, 1) on both axes, utils.py:265-277,341-353), fp32 and bf16 output."""
+    x = synth.normal((b, 3, h, w), 4300 + h)
+    wt = synth.normal((32, 3, 3, 3), 4301, (1.0 / 27) ** 0.5)
+    sc = synth.uniform((32,), 4302, 0.5, 1.5)
+    sh = synth.normal((32,), 4303, 0.1)
+    xp = F.pad(x, (0, 1, 0, 0), mode="circular") if circ else F.pad(x, (0, 1, 0, 0))
+    xp = F.pad(xp, (0, 0, 0, 1))
+    want = O.swish(F.conv2d(xp, wt, stride=2) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1))
+    got = ops.stem_conv(dev(x), dev(wt.permute(2, 3, 1, 0)), dev(sc), dev(sh), circ,
+                        out_dtype=torch.bfloat16 if bf16 else torch.float32)
+    assert tuple(got.shape) == (b, (h - 2) // 2 + 1, (w - 2) // 2 + 1, 32)
+    close(nchw(got).float(), want, 1e-2 if bf16 else 1e-5, "stem %dx%d" % (h, w))
+    raw = ops.stem_conv_raw(dev(x), dev(wt.permute(2, 3, 1, 0)), circ)
+    close(nchw(raw), F.conv2d(xp, wt, stride=2), 1e-5, "stem raw")
 
 
 @pytest.mark.parametrize("k,s,c,h,w,circ", [(3, 1, 32, 9, 12, False), (3, 2, 96, 10, 14, True), (5, 2, 144, 8, 12, True),
