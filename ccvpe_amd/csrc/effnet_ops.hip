@@ -44,14 +44,29 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
   const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
   // ---- the input patch: rows 2 oy0 .. 2 oy0 + 8, columns 2 ox0 .. 2 ox0 + 128 of the three planes (pad before = 0) --------
   const float* xb = x + (size_t)b * 3 * H * W;
-  for (int idx = tid; idx < 3 * ST_IR * ST_PITCH; idx += 256) {
-    const int row = idx / ST_PITCH, c = idx - row * ST_PITCH;
-    const int ci = row / ST_IR, r = row - ci * ST_IR;
-    const int iy = 2 * oy0 + r;
-    int ix = 2 * ox0 + c;
-    if (circular && ix >= W) ix -= W;
-    const bool ok = c < ST_IC && iy < H && ix < W;
-    img[idx] = ok ? xb[((size_t)ci * H + iy) * W + ix] : 0.f;
+  {
+    // all loads of the patch in flight together, from clamped addresses, masked at the LDS store: `ok ? load : 0` compiles to
+    // an exec-mask branch per load and serialises the 14 round trips of a thread
+    constexpr int NIT = (3 * ST_IR * ST_PITCH + 255) / 256;
+    float v[NIT];
+    unsigned okm = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = min(tid + 256 * it, 3 * ST_IR * ST_PITCH - 1);
+      const int row = idx / ST_PITCH, c = idx - row * ST_PITCH;
+      const int ci = row / ST_IR, r = row - ci * ST_IR;
+      const int iy = 2 * oy0 + r;
+      int ix = 2 * ox0 + c;
+      ix = (circular && ix >= W) ? ix - W : ix;
+      const bool ok = c < ST_IC && iy < H && ix < W;
+      v[it] = xb[ok ? ((size_t)ci * H + iy) * W + ix : 0];
+      okm |= ok ? (1u << it) : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = tid + 256 * it;
+      if (idx < 3 * ST_IR * ST_PITCH) img[idx] = ((okm >> it) & 1u) ? v[it] : 0.f;
+    }
   }
   // ---- W fragments (A operand: lane (n = pix, q) supplies W[k = 4 s + q][n]) and the lane's patch offsets ----------------
   float wr[7][2];
