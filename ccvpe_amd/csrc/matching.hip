@@ -103,9 +103,11 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   }
   // descriptor tables + ||g||
   float gsq = 0.f;
+#pragma unroll 4
   for (int k = tid; k < 2 * C; k += 256) {
     const int kk = k < C ? k : k - C;
-    const float v = kk < L ? g[(size_t)b * ldg + kk] : 0.f;
+    const float gv = g[(size_t)b * ldg + min(kk, L - 1)];       // unconditional (a guarded load is an exec-mask branch per load:
+    const float v = kk < L ? gv : 0.f;                          // the 10 loads of a thread at C = 1280 ran one after the other)
     gg[k] = v;
     if (PARTIAL) ww[k] = kk < L ? 1.f : 0.f;
     if (k < C) gsq = fmaf(v, v, gsq);

@@ -62,7 +62,8 @@ __global__ __launch_bounds__(256) void match_bwd_kernel(const float* __restrict_
   float gsq = 0.f;
   for (int k = tid; k < 2 * C; k += TPB) {
     const int kk = k < C ? k : k - C;
-    const float v = kk < L ? g[(size_t)b * ldg + kk] : 0.f;
+    const float gv = g[(size_t)b * ldg + min(kk, L - 1)];       // unconditional load (see matching.hip)
+    const float v = kk < L ? gv : 0.f;
     gg[k] = v;
     ww[k] = kk < L ? 1.f : 0.f;
     if (k < C) gsq = fmaf(v, v, gsq);
