@@ -126,33 +126,17 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const float* __restrict_
 // ---------------------------------------------------------------------------------------------
 constexpr int DW_TW = 4;
 
-// CPT = channels per thread: 4, or 8 for bf16 storage (16-byte requests: with 8-byte requests a wave's load covers eight 64-byte
-// pixel pieces — the bf16 kernel of block 0, 256 x 256 x 32, ran at 2.2 TB/s algorithmic).  The workgroup's strip coverage
-// (RB x P strips -> one squeeze-partial row) is the same for both, so ccvpe_dwconv_nblk() does not depend on the storage type.
-template <typename T, int CPT>
-__device__ __forceinline__ void dw_load(const T* p, f32x4* v) {
-  if constexpr (CPT == 4) {
-    v[0] = ld4<T>(p);
-  } else {
-    const cc_bf16x8 h = *reinterpret_cast<const cc_bf16x8*>(p);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { v[0][j] = (float)h[j]; v[1][j] = (float)h[j + 4]; }
-  }
-}
-
-template <typename T, int K, int S, bool RAW, int CPT>
+template <typename T, int K, int S, bool RAW>
 __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift, T* __restrict__ y,
                                                      float* __restrict__ se_partial, int H, int W, int C, int Ho,
                                                      int Wo, int cgx, int P, int nblk, int circular, int RB,
                                                      int ychunks, int total_blocks) {
-  static_assert(CPT == 4 || (CPT == 8 && sizeof(T) == 2), "8 channels per thread is the bf16 form");
-  constexpr int NH = CPT / 4;                               // float4 halves per thread
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;  // pad before (224-schedule SAME)
   constexpr int NCOL = (DW_TW - 1) * S + K;
-  constexpr int KYU_STRIP = (K == 3 && CPT == 4) ? 3 : 1;    // k = 5 / 8 channels: one kernel row (6-11 loads) in flight at a time, else 256 VGPRs
-  extern __shared__ __attribute__((aligned(16))) float red[];  // [P][cgx][NH] float4
+  constexpr int KYU_STRIP = K == 3 ? 3 : 1;    // k = 5: one kernel row (8-11 loads) in flight at a time, else 256 VGPRs
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [P][cgx] float4
 
   const int tid = threadIdx.x;
   const int cgl = tid % cgx;
@@ -170,23 +154,19 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   const int by = (lb / nblk) % ychunks;
   const int b = lb / (nblk * ychunks);
   const int cg = by * cgx + cgl;
-  const int c = cg * CPT;
+  const int c = cg * 4;
   const int sxn = (Wo + DW_TW - 1) / DW_TW;
 
-  f32x4 sum[NH];
-#pragma unroll
-  for (int h = 0; h < NH; ++h) sum[h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   for (int rb = 0; rb < RB; ++rb) {
   const int strip = (bx * RB + rb) * P + pl;
   const bool active = pl < P && strip < Ho * sxn && c < C;
   if (active) {
     const int oy = strip / sxn;
     const int ox0 = (strip - oy * sxn) * DW_TW;
-    f32x4 acc[DW_TW][NH];
+    f32x4 acc[DW_TW];
 #pragma unroll
-    for (int t = 0; t < DW_TW; ++t)
-#pragma unroll
-      for (int h = 0; h < NH; ++h) acc[t][h] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < DW_TW; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const T* xb = x + (size_t)b * H * W * C + c;
     // BRANCH-FREE window loads: rows / columns outside the image read a clamped (valid) address and are zeroed by AND-ing
     // the bits with a lane mask; the circular wrap is two selects.  (`ok ? load : 0` and `if (row outside) continue`
@@ -198,7 +178,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
       const int iy = oy * S - PB + ky;
       const bool rowok = (unsigned)iy < (unsigned)H;
       const size_t rbase = (size_t)(rowok ? iy : 0) * W;
-      f32x4 col[NCOL][NH];
+      f32x4 col[NCOL];
 #pragma unroll
       for (int j = 0; j < NCOL; ++j) {
         int ix = ox0 * S - PB + j;
@@ -207,51 +187,33 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
         const bool ok = rowok && (unsigned)ix < (unsigned)W;
         const int ixc = (unsigned)ix < (unsigned)W ? ix : 0;
         const int m = ok ? -1 : 0;
-        f32x4 v[NH];
-        dw_load<T, CPT>(xb + (rbase + ixc) * C, v);
-#pragma unroll
-        for (int h = 0; h < NH; ++h)
-          col[j][h] = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v[h]) & (i32x4){m, m, m, m});
+        const f32x4 v = ld4<T>(xb + (rbase + ixc) * C);
+        col[j] = __builtin_bit_cast(f32x4, __builtin_bit_cast(i32x4, v) & (i32x4){m, m, m, m});
       }
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
+        const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(ky * K + kx) * C + c);
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (size_t)(ky * K + kx) * C + c + 4 * h);
-#pragma unroll
-          for (int t = 0; t < DW_TW; ++t) acc[t][h] += col[t * S + kx][h] * wv;
-        }
+        for (int t = 0; t < DW_TW; ++t) acc[t] += col[t * S + kx] * wv;
       }
     }
-    f32x4 sc[NH], sh[NH];
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      sc[h] = RAW ? (f32x4){1.f, 1.f, 1.f, 1.f} : *reinterpret_cast<const f32x4*>(scale + c + 4 * h);
-      sh[h] = RAW ? (f32x4){0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(shift + c + 4 * h);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (!RAW) {
+      sc = *reinterpret_cast<const f32x4*>(scale + c);
+      sh = *reinterpret_cast<const f32x4*>(shift + c);
     }
     T* yb = y + ((size_t)(b * Ho + oy) * Wo) * C + c;
 #pragma unroll
     for (int t = 0; t < DW_TW; ++t) {
       const int ox = ox0 + t;
       if (ox < Wo) {
-        f32x4 v[NH];
+        f32x4 v = acc[t] * sc + sh;
+        if (!RAW) {
 #pragma unroll
-        for (int h = 0; h < NH; ++h) {
-          v[h] = acc[t][h] * sc[h] + sh[h];
-          if (!RAW) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[h][j] = swishf(v[h][j]);
-          }
-          sum[h] += v[h];
+          for (int j = 0; j < 4; ++j) v[j] = swishf(v[j]);
         }
-        if constexpr (CPT == 4) {
-          st4<T>(yb + (size_t)ox * C, v[0]);
-        } else {
-          cc_bf16x8 o;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) { o[j] = (cc_bf16)v[0][j]; o[j + 4] = (cc_bf16)v[NH - 1][j]; }
-          *reinterpret_cast<cc_bf16x8*>(yb + (size_t)ox * C) = o;
-        }
+        st4<T>(yb + (size_t)ox * C, v);
+        sum += v;
       }
     }
   }
@@ -259,17 +221,12 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const T* __restrict__ x, co
   if (RAW) return;   // no squeeze partials in raw mode (uniform: whole workgroup)
   // block reduction over the P strips, fixed order
   f32x4* red4 = reinterpret_cast<f32x4*>(red);
-#pragma unroll
-  for (int h = 0; h < NH; ++h)
-    if (pl < P) red4[(pl * cgx + cgl) * NH + h] = sum[h];
+  if (pl < P) red4[pl * cgx + cgl] = sum;
   __syncthreads();
   if (pl == 0 && c < C) {
-#pragma unroll
-    for (int h = 0; h < NH; ++h) {
-      f32x4 tot = red4[cgl * NH + h];
-      for (int q = 1; q < P; ++q) tot += red4[(q * cgx + cgl) * NH + h];
-      *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * nblk + bx) * C + c + 4 * h) = tot;
-    }
+    f32x4 tot = red4[cgl];
+    for (int q = 1; q < P; ++q) tot += red4[q * cgx + cgl];
+    *reinterpret_cast<f32x4*>(se_partial + ((size_t)b * nblk + bx) * C + c) = tot;
   }
 }
 
@@ -633,21 +590,10 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
   const long total = (long)nblk * yc * B;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "dwconv: grid too large");
   dim3 grid((unsigned)total);
-  hipStream_t st = (hipStream_t)stream;
-  // bf16 storage: 8 channels (16 bytes) per thread when the geometry halves evenly — half the channel groups, twice the strips
-  // per pass, half the passes: the same RB x P strips per workgroup, i.e. the same squeeze-partial rows
-  if constexpr (sizeof(T) == 2 && !RAW) {
-    if (cgx % 2 == 0 && RB % 2 == 0 && C % 8 == 0 && k == 3 && stride == 1) {      // (block 0: the one large depthwise tensor)
-      const int cgx8 = cgx / 2, P8 = 2 * P, RB8 = RB / 2;
-      const size_t smem8 = (size_t)P8 * cgx8 * 32;
-      hipLaunchKernelGGL((dwconv_kernel<T, 3, 1, RAW, 8>), grid, dim3(256), smem8, st, x, w, scale, shift, y, se_partial, H, W,
-                         C, Ho, Wo, cgx8, P8, nblk, circular, RB8, yc, (int)total);
-      return check_launch("dwconv_kernel");
-    }
-  }
   const size_t smem = (size_t)P * cgx * 16;
+  hipStream_t st = (hipStream_t)stream;
 #define DW_LAUNCH(K_, S_)                                                                                         \
-  hipLaunchKernelGGL((dwconv_kernel<T, K_, S_, RAW, 4>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
+  hipLaunchKernelGGL((dwconv_kernel<T, K_, S_, RAW>), grid, dim3(256), smem, st, x, w, scale, shift, y, se_partial, H, W, \
                      C, Ho, Wo, cgx, P, nblk, circular, RB, yc, (int)total)
   if (k == 3 && stride == 1) DW_LAUNCH(3, 1);
   else if (k == 3 && stride == 2) DW_LAUNCH(3, 2);

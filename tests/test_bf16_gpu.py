@@ -126,8 +126,7 @@ def test_igemm_bf16_2x2s2_and_deconv(ops):
 
 @pytest.mark.parametrize("k,s,c,h,w,circ", [(3, 1, 32, 9, 12, False), (5, 2, 144, 8, 12, True), (5, 1, 1152, 5, 9, True),
                                             (3, 2, 240, 7, 9, False),
-                                            # large enough for the 8-channels-per-thread form (block 0's geometry: >= 64 strip groups)
-                                            (3, 1, 32, 128, 130, False), (3, 1, 32, 96, 200, True)])
+                                            (3, 1, 32, 128, 130, False), (3, 1, 32, 96, 200, True)])      # block 0's geometry (RB > 1)
 def test_dwconv_bf16(ops, k, s, c, h, w, circ):
     b = 2
     x = r(synth.normal((b, c, h, w), 40 + c))
