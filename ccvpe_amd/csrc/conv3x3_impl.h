@@ -37,7 +37,14 @@ struct Conv3Geom {
   static constexpr int BN = 16 * NT * WN;
   static constexpr int TH = BM / 16;
   static constexpr int HPX = (TH + 2) * 18;
-  static constexpr int HS_FLOATS = HPX * LDS_LD;
+  // bf16: halo pixel rows of 64 bytes (no padding) in 24 slots per halo row, the 16-byte piece index XOR-ed by
+  // ((column >> 2) & 1) << 1: conflict-free ds_read_b128 fragments (tools/lds_layout.py) at 7 % more LDS instead of 2-way
+  // conflicts on every read; with 24 = 0 mod 8 slots per row the swizzle term depends on (lane, kx) only -> three per-lane
+  // address registers, rows and ky by immediate offsets.  fp32 keeps pitch 20 (its LDS arrays are 7 % busy).
+  static constexpr bool HSW = sizeof(T) == 2;
+  static constexpr int HCP = HSW ? 24 : 18;
+  static constexpr int HLD = HSW ? 16 : LDS_LD;
+  static constexpr int HS_FLOATS = (TH + 2) * HCP * HLD;
   static constexpr int BS_FLOATS = 2 * TPS * BN * BLD;
   static constexpr int LDS_BYTES = (HS_FLOATS + BS_FLOATS) * 4;
 };
@@ -61,6 +68,8 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && sizeof(T) == 4) ? 4 : 2) void 
   constexpr int H_IT = (HPX * 4 + NTHR - 1) / NTHR;  // float4 loads per thread per chunk (halo)
   constexpr int B_IT = (BN + RPP - 1) / RPP;
   constexpr int NG = 9 / TPS;                      // stages per chunk
+  constexpr bool HSW = G::HSW;
+  constexpr int HCP = G::HCP, HLD = G::HLD;
 
   // halo is single-buffered (one extra barrier per chunk) to keep LDS small -> 2-4 blocks/CU
   extern __shared__ __attribute__((aligned(16))) float c3_sm[];
@@ -100,7 +109,7 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && sizeof(T) == 4) ? 4 : 2) void 
     if (px < HPX) {
       const int hy = px / HC, hx = px - hy * HC;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      h_off[it] = px * LDS_LD + sub * 4;
+      h_off[it] = (hy * HCP + hx) * HLD + (HSW ? (sub ^ (((hx >> 2) & 1) << 1)) : sub) * 4;
       h_pix[it] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (b * p.H + iy) * p.W + ix : -1;
     } else {
       h_off[it] = -1;
@@ -199,6 +208,12 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && sizeof(T) == 4) ? 4 : 2) void 
   const int frow = lane & 15;
   const int fk = (lane >> 4) * 4;
   const int bcol = DMA ? (((lane >> 4) ^ w_swz(frow)) * 4) : fk;
+  int acol[3];                                     // per-lane float offset of the A fragment for kx = 0..2 (row 0 of this wave)
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int hx = frow + kx;
+    acol[kx] = (wm * MT * HCP + hx) * HLD + (HSW ? (((lane >> 4) ^ (((hx >> 2) & 1) << 1)) * 4) : fk);
+  }
 
   load_halo(0);
   load_w(0, 0, 0);
@@ -224,10 +239,14 @@ __global__ __launch_bounds__(64 * NW, (NW == 8 && sizeof(T) == 4) ? 4 : 2) void 
     f32x4 af[FS][MT], bf[FS][NT];
     auto read_frag = [&](int t, f32x4* a, f32x4* w_) {
       const int tap = tg * TPS + t;
-      const int ky = tap / 3, kx = tap - ky * 3;
+      const int ky = TPS == 3 ? tg : tap / 3, kx = TPS == 3 ? t : tap - ky * 3;
+      int ab;                                        // (TPS = 3: kx is a compile-time index into acol; else selected)
+      if constexpr (TPS == 3) ab = acol[t];
+      else ab = kx == 0 ? acol[0] : (kx == 1 ? acol[1] : acol[2]);
 #pragma unroll
       for (int i = 0; i < MT; ++i)
-        a[i] = *reinterpret_cast<const f32x4*>(Hs + (((wm * MT + i) + ky) * HC + frow + kx) * LDS_LD + fk);
+        if constexpr (HSW) a[i] = *reinterpret_cast<const f32x4*>(Hs + ab + (i + ky) * HCP * HLD);
+        else a[i] = *reinterpret_cast<const f32x4*>(Hs + (((wm * MT + i) + ky) * HC + frow + kx) * LDS_LD + fk);
 #pragma unroll
       for (int j = 0; j < NT; ++j)
         w_[j] = *reinterpret_cast<const f32x4*>(&Bs[((((s & 1) * TPS + t) * BN) + (wn * NT + j) * 16 + frow) * BLD + bcol]);
@@ -363,7 +382,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wreg_kernel(const IgemmParams 
     if (px < HPX) {
       const int hy = px / HC, hx = px - hy * HC;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      h_off[it] = px * LDS_LD + sub * 4;
+      h_off[it] = (hy * HCP + hx) * HLD + (HSW ? (sub ^ (((hx >> 2) & 1) << 1)) : sub) * 4;
       h_pix[it] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (b * p.H + iy) * p.W + ix : -1;
     } else {
       h_off[it] = -1;
