@@ -16,8 +16,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int A_IT = BM / 64;            // float4 loads per thread per stage (A)
   constexpr int B_IT = (BN + 63) / 64;     // float4 loads per thread per stage (W)
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+  constexpr bool SWZ = PanelLayout<T>::SWZ;     // bf16: unpadded, XOR-swizzled panels (conv_common.h)
+  constexpr int PLD = PanelLayout<T>::LD;
+  __shared__ __attribute__((aligned(16))) float As[2][BM][PLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][PLD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // ---- per-thread staging coordinates -------------------------------------------------------
   const int srow = tid >> 2;   // 0..63
   const int ssub = tid & 3;    // which 16-byte piece of the 64-byte stage row
+  const int scol = (SWZ ? (ssub ^ panel_swz(srow)) : ssub) * 4;       // staged piece -> (swizzled) float column
   const int chunk_in_stage = (ssub * E) >> 3;      // fp32: ssub>>1, bf16: ssub
   const int half = (ssub * E) & 7;                 // channel offset inside the 8-chunk: fp32 0|4, bf16 0
   const T* src0 = reinterpret_cast<const T*>(p.src0);
@@ -125,12 +128,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         if (a_b[it] == a_b[0]) v = gate_apply<T>(v, g_r0, g_r1);
         else v = apply_gate<T>(v, p.gate + (size_t)a_b[it] * p.c0 + g_ch);
       }
-      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = keep_if(v, (a_keep >> it) & 1u);
+      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][scol]) = keep_if(v, (a_keep >> it) & 1u);
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
-      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][scol]) = b_reg[it];
     }
   };
 
@@ -141,7 +144,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
-  const int fk = (lane >> 4) * 4;
+  const int fk = (SWZ ? ((lane >> 4) ^ panel_swz(frow)) : (lane >> 4)) * 4;
 
   load_stage(s_begin);
   store_stage(0);

@@ -32,7 +32,10 @@ struct PwGeom {
   // kernel): the staging registers of the NEXT tile's first stage stay live across the epilogue (persistent loop), and
   // with 4 pieces they push the 14-20 accumulator tiles over the 256-VGPR cap of 2 waves per SIMD (spills).
   static constexpr int KP = 2;
-  static constexpr int LDF = 16 * KP + 4;                                        // floats per staged row
+  // floats per staged row.  bf16: no padding, the 8 pieces of a row XOR-swizzled by (row >> 1) & 7 — conflict-free fragment
+  // reads (tools/lds_layout.py; pitch 36 makes every ds_read_b128 a 2-way conflict), see PanelLayout in conv_common.h
+  static constexpr bool SWZ = sizeof(T) == 2;
+  static constexpr int LDF = SWZ ? 16 * KP : 16 * KP + 4;
   static constexpr int OLD = BN + 4;                                             // floats per epilogue-tile row
   static constexpr int IC = (BM * OLD * 4 <= LDS_BUDGET) ? MT : MT / 2;          // MFMA row tiles per epilogue pass
   static constexpr int STAGE_BYTES = (BM + BN) * LDF * 4;
@@ -76,6 +79,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
   const int pc = tid % PPR;                   // 16-byte piece inside the staged row
   const int frow = lane & 15;
   const int fk = (lane >> 4) * 4;
+  constexpr bool SWZ = G::SWZ;
+  const int pcs = SWZ ? (pc ^ ((prow >> 1) & 7)) : pc;                  // staged piece -> (swizzled) slot; rows advance by 32
+  int fcol[KP];                                                          // fragment float column of 64-byte piece kp
+#pragma unroll
+  for (int kp = 0; kp < KP; ++kp) fcol[kp] = SWZ ? (((kp * 4 + (lane >> 4)) ^ ((frow >> 1) & 7)) * 4) : kp * 16 + fk;
   const int epix = lane & 15;
   const int en = (lane >> 4) * 4;
   f32x4 a_reg[A_IT], b_reg[B_IT];
@@ -138,12 +146,12 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
         if (m < g_mend) v = gate_apply<T>(v, g_r0, g_r1);                       // same sample as the thread's first row: the usual case
         else v = apply_gate<T>(v, p.gate + (size_t)(min(m, p.M - 1) / hw) * p.c0 + g_kc);
       }
-      *reinterpret_cast<f32x4*>(&As[(prow + it * (256 / PPR)) * LDF + pc * 4]) = keep_if(v, k_ok && ((row_ok >> it) & 1u));
+      *reinterpret_cast<f32x4*>(&As[(prow + it * (256 / PPR)) * LDF + (SWZ ? pcs : pc) * 4]) = keep_if(v, k_ok && ((row_ok >> it) & 1u));
     }
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = prow + it * (256 / PPR);
-      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[nrow * LDF + pc * 4]) = b_reg[it];
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[nrow * LDF + (SWZ ? pcs : pc) * 4]) = b_reg[it];
     }
   };
 
@@ -193,10 +201,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
         f32x4 af[MT], bf[NT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
-          af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * LDF + kp * 16 + fk]);
+          af[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * LDF + (SWZ ? fcol[kp] : kp * 16 + fk)]);
 #pragma unroll
         for (int j = 0; j < NT; ++j)
-          bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * LDF + kp * 16 + fk]);
+          bf[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * LDF + (SWZ ? fcol[kp] : kp * 16 + fk)]);
         if (sizeof(T) == 4) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)

@@ -43,8 +43,10 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
   constexpr int A_IT = BM / 64;
   constexpr int B_IT = (BN + 63) / 64;
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+  constexpr bool SWZ = PanelLayout<T>::SWZ;
+  constexpr int PLD = PanelLayout<T>::LD;
+  __shared__ __attribute__((aligned(16))) float As[2][BM][PLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][PLD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -85,6 +87,7 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
     a_x[it] = rem - a_y[it] * p.W1;
   }
   const int k0end = 4 * p.cpt0;      // chunks belonging to the low-res source
+  const int scol = (SWZ ? (ssub ^ panel_swz(srow)) : ssub) * 4;       // staged piece -> (swizzled) float column
 
   f32x4 a_reg[A_IT], b_reg[B_IT];
   unsigned wrow[B_IT];                      // stage-invariant byte offset of this lane's W piece per staged row (see igemm_kernel)
@@ -136,11 +139,11 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
   auto store_stage = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < A_IT; ++it)
-      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
+      *reinterpret_cast<f32x4*>(&As[buf][srow + 64 * it][scol]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
-      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][scol]) = b_reg[it];
     }
   };
 
@@ -151,7 +154,7 @@ __global__ __launch_bounds__(256) void upconv_kernel(const UpParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int frow = lane & 15;
-  const int fk = (lane >> 4) * 4;
+  const int fk = (SWZ ? ((lane >> 4) ^ panel_swz(frow)) : (lane >> 4)) * 4;
 
   load_stage(0);
   store_stage(0);
@@ -241,10 +244,18 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   constexpr int H_IT = (HPX * 4 + 255) / 256;
   constexpr int A_IT = BM / 64;
   constexpr int B_IT = (BN + 63) / 64;
-  constexpr int UROWS = (HPX > 2 * BM) ? HPX : 2 * BM;       // halo [HPX] rows  |  A stage [2][BM] rows
+  // Measured on the decoder shapes (tools/up_probe.py bf16, round 4): the swizzled W panel alone +3-5 % on the wide tiles (N >= 128),
+  // -5 % on the 32-column tile; the swizzled HALO (as in conv3x3_kernel, where it is worth 7-12 %) -8-12 % here — this kernel reads
+  // its fragments at the top of a one-tap stage and waits for them, it is not bound by LDS throughput.  So: W panel only, NT >= 2.
+  constexpr bool SWZ = false;                                    // halo + phase-B stage (Us): padded pitch 20
+  constexpr bool WSWZ = PanelLayout<T>::SWZ && NT >= 2;          // W panel (Bs): unpadded, XOR-swizzled
+  constexpr int PLD = SWZ ? 16 : LDS_LD;
+  constexpr int WLD = WSWZ ? 16 : LDS_LD;
+  constexpr int HCP = SWZ ? 24 : HC;                         // halo slots per row (bf16: see conv3x3_kernel)
+  constexpr int UROWS = (HR * HCP > 2 * BM) ? HR * HCP : 2 * BM;       // halo [HR][HCP] rows  |  A stage [2][BM] rows
 
-  __shared__ __attribute__((aligned(16))) float Us[UROWS][LDS_LD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDS_LD];
+  __shared__ __attribute__((aligned(16))) float Us[UROWS][PLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN][WLD];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -270,6 +281,8 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   const T* src1 = reinterpret_cast<const T*>(p.src1);
   const T* wp = reinterpret_cast<const T*>(p.w) + (size_t)par * p.Npad * p.Kpad;
   const int srow = tid >> 2, ssub = tid & 3;
+  const int scol = (SWZ ? (ssub ^ panel_swz(srow)) : ssub) * 4;        // staged piece -> (swizzled) float column
+  const int wscol = (WSWZ ? (ssub ^ panel_swz(srow)) : ssub) * 4;
 
   // ---- phase A staging coordinates (halo of the low-res source) --------------------------------
   int h_off[H_IT], h_pix[H_IT], h_sub[H_IT];
@@ -281,7 +294,7 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     if (pxl < HPX) {
       const int hy = pxl / HC, hx = pxl - hy * HC;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      h_off[it] = pxl * LDS_LD + sub * 4;
+      h_off[it] = (hy * HCP + hx) * PLD + (SWZ ? (sub ^ panel_swz(hx)) : sub) * 4;
       h_pix[it] = ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1) ? (b * p.H1 + iy) * p.W1 + ix : -1;
     } else {
       h_off[it] = -1;
@@ -322,7 +335,7 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
 #pragma unroll
     for (int it = 0; it < B_IT; ++it) {
       const int nrow = srow + 64 * it;
-      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][ssub * 4]) = b_reg[it];
+      if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[buf][nrow][wscol]) = b_reg[it];
     }
   };
 
@@ -332,13 +345,18 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
-  const int fk = (lane >> 4) * 4;
+  const int fk = (SWZ ? ((lane >> 4) ^ panel_swz(frow)) : (lane >> 4)) * 4;       // row-indexed panel (phase-B stage)
+  const int wfk = (WSWZ ? ((lane >> 4) ^ panel_swz(frow)) : (lane >> 4)) * 4;     // W panel
+  // halo fragment (phase A): per-lane float offset at column shift dv + px, dv = 0 / 1 (two plain registers: an indexed array
+  // here became a scratch array)
+  auto hcol_at = [&](int c) { return (wm * MT * HCP + frow + c) * PLD + (SWZ ? ((lane >> 4) ^ panel_swz(frow + c)) : (lane >> 4)) * 4; };
+  const int hdv0 = hcol_at(px) + py * (HCP * PLD), hdv1 = hcol_at(px + 1) + py * (HCP * PLD);
 
   auto mfma_block = [&](const f32x4* af, int wbuf) {
     f32x4 bf[NT];
 #pragma unroll
     for (int j = 0; j < NT; ++j)
-      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[wbuf][(wn * NT + j) * 16 + frow][fk]);
+      bf[j] = *reinterpret_cast<const f32x4*>(&Bs[wbuf][(wn * NT + j) * 16 + frow][wfk]);
     if (sizeof(T) == 4) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
@@ -365,8 +383,8 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     store_halo();
     store_w(0);
     __syncthreads();
-    int chunk = 0, tap = 0;
-    for (int s = 0; s < nstA; ++s) {
+    // one (chunk, tap) stage; `ab` = this lane's halo fragment offset for the tap (swizzled layout only)
+    auto stage_a = [&](int s, int chunk, int tap, int ab) {
       const bool more = s + 1 < nstA;
       int nchunk = chunk, ntap = tap + 1;
       if (ntap == 4) { ntap = 0; ++nchunk; }
@@ -378,9 +396,15 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
       }
       const int du = tap >> 1, dv = tap & 1;
       f32x4 af[MT];
+      if constexpr (SWZ) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&Us[0][0] + (((wm * MT + i) + du + py) * HC + frow + dv + px) * LDS_LD + fk);
+        for (int i = 0; i < MT; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(&Us[0][0] + ab + i * (HCP * PLD));
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(&Us[0][0] + (((wm * MT + i) + du + py) * HC + frow + dv + px) * LDS_LD + fk);
+      }
       mfma_block(af, wbuf);
       if (more) store_w(wbuf ^ 1);
       __syncthreads();
@@ -389,8 +413,18 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
         __syncthreads();
       }
       if (more) wbuf ^= 1;
-      chunk = nchunk;
-      tap = ntap;
+    };
+    // (swizzled layout) the fragment offset of a tap depends on the column shift dv + px through the XOR term: it is computed
+    // for the NEXT stage under the current stage's matrix work — computed at the top of a stage it put a chain of dependent
+    // selects in front of the stage's first ds_read (+7-20 % on these kernels)
+    auto tap_off = [&](int tap) { return ((tap & 1) ? hdv1 : hdv0) + (tap >> 1) * (HCP * PLD); };
+    int chunk = 0, tap = 0, ab = SWZ ? tap_off(0) : 0;
+    for (int s = 0; s < nstA; ++s) {
+      const int ntap = (tap + 1) & 3;
+      const int abn = SWZ ? tap_off(ntap) : 0;
+      stage_a(s, chunk, tap, ab);
+      ab = abn;
+      if (++tap == 4) { tap = 0; ++chunk; }
     }
   }
 
@@ -431,7 +465,7 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
     auto store_a = [&](int buf) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it)
-        *reinterpret_cast<f32x4*>(&Us[buf * BM + srow + 64 * it][ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
+        *reinterpret_cast<f32x4*>(&Us[buf * BM + srow + 64 * it][scol]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
     };
     // the halo is dead (phase A ended on a barrier); W buffer `wbuf` was the last one read
     load_a(0);

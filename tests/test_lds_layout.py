@@ -34,3 +34,37 @@ def test_weight_gradient_pitch_in_the_source_is_conflict_free():
         pitch = (width + 15) // 32 * 32 + 16
         assert pitch >= width and pitch % 32 == 16
         assert L.cycles("read_b32", L.wgrad_b32(pitch)) == (2, 2)
+
+
+def test_bf16_layouts_in_the_source_are_conflict_free():
+    """Round 4: the bf16 GEMM kernels stage unpadded, XOR-swizzled panels (conv_common.h PanelLayout / panel_swz), the bf16 3x3
+    halo is 64-byte pixel rows in 24 slots per halo row with the same swizzle on the halo column, the bf16 pointwise kernel has
+    8 pieces per row swizzled by (row >> 1) & 7.  Restated here from the source and checked against the lane-group model."""
+    common = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv_common.h")).read()
+    assert "__device__ __forceinline__ int panel_swz(int row) { return ((row >> 2) & 1) << 1; }" in common
+    assert "static constexpr int LD = SWZ ? 16 : LDS_LD;" in common
+    c3 = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv3x3_impl.h")).read()
+    assert "static constexpr int HCP = HSW ? 24 : 18;" in c3 and "(((hx >> 2) & 1) << 1)" in c3
+    pw = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv_pw_impl.h")).read()
+    assert "static constexpr int LDF = SWZ ? 16 * KP : 16 * KP + 4;" in pw and "((frow >> 1) & 7)" in pw
+    swz = lambda row: ((row >> 2) & 1) << 1
+    for base in range(0, 256, 16):                      # row-indexed panels: fragment rows 16 j + (lane & 15)
+        assert L.cycles("read_b128", L.fragment_b128(16, base=base, swizzle=swz)) == (4, 4)
+    # 3x3 halo: pixel (hy, hx) at slot hy * 24 + hx, fragment lanes at hx = (lane & 15) + kx, kx = 0..2, any halo row
+    for hy in range(6):
+        for kx in range(3):
+            def addr(lane, hy=hy, kx=kx):
+                hx = (lane % 16) + kx
+                return (hy * 24 + hx) * 16 + 4 * ((lane // 16) ^ swz(hx))
+            assert L.cycles("read_b128", addr) == (4, 4)
+    # pointwise kernel: rows of 32 floats (two 64-byte K pieces), piece index 4 kp + (lane >> 4) XOR (row >> 1) & 7
+    for kp in range(2):
+        for base in (0, 16, 48):
+            def addr(lane, kp=kp, base=base):
+                row = base + lane % 16
+                return row * 32 + 4 * ((4 * kp + lane // 16) ^ ((row >> 1) & 7))
+            assert L.cycles("read_b128", addr) == (4, 4)
+    # ... and what they replace: pitch 36 (pointwise) and pitch 20 are 2-way conflicts on every fragment read
+    assert L.cycles("read_b128", L.fragment_b128(36)) == (8, 4)
+    # staging writes of the swizzled panels: one row = 4 (8) contiguous pieces per lane group
+    assert L.cycles("write_b128", L.staging_b128(16, swizzle=swz)) == (8, 8)
