@@ -37,11 +37,13 @@ struct Conv3Geom {
   static constexpr int BN = 16 * NT * WN;
   static constexpr int TH = BM / 16;
   static constexpr int HPX = (TH + 2) * 18;
-  // bf16: halo pixel rows of 64 bytes (no padding) in 24 slots per halo row, the 16-byte piece index XOR-ed by
+  // Halo pixel rows of 64 bytes (no padding) in 24 slots per halo row, the 16-byte piece index XOR-ed by
   // ((column >> 2) & 1) << 1: conflict-free ds_read_b128 fragments (tools/lds_layout.py) at 7 % more LDS instead of 2-way
   // conflicts on every read; with 24 = 0 mod 8 slots per row the swizzle term depends on (lane, kx) only -> three per-lane
-  // address registers, rows and ky by immediate offsets.  fp32 keeps pitch 20 (its LDS arrays are 7 % busy).
-  static constexpr bool HSW = sizeof(T) == 2;
+  // address registers, rows and ky by immediate offsets.  (HSW = false is the round-3 layout: 18 slots of 80 bytes.)
+  // (the 8-wave fp32 form without W DMA — a fallback for column counts that are not a tile multiple — lives under a 128-VGPR
+  // cap and spills with the three extra address registers: it keeps the round-3 layout)
+  static constexpr bool HSW = !(NW == 8 && sizeof(T) == 4 && !DMA);
   static constexpr int HCP = HSW ? 24 : 18;
   static constexpr int HLD = HSW ? 16 : LDS_LD;
   static constexpr int HS_FLOATS = (TH + 2) * HCP * HLD;

@@ -154,13 +154,14 @@ struct IgemmParams {
 };
 
 constexpr int LDS_LD = 20;  // floats per staged row (16 + 4 pad); see DESIGN section 4 "LDS bank conflicts" for the measured pitch-24 variant
-// bf16 kernels (round 4): staged panels WITHOUT padding — pitch 16 floats = one 64-byte K chunk per row — and the 16-byte piece index
-// XOR-ed by panel_swz(row): conflict-free ds_read_b128 fragments for any window base (tools/lds_layout.py) and 20 % less LDS than
-// pitch 20, whose every fragment read is a 2-way conflict.  The bf16 matrix phases are 8x shorter than the fp32 ones for the same
-// fragment bytes, so the LDS arrays are what these kernels wait for; fp32 keeps pitch 20 (its arrays are ~7 % busy).  Fragment
-// rows are 16j + (lane & 15) and staging rows (tid >> 2) + 64 it, so the swizzle term is a per-lane constant in both.
+// Staged panels WITHOUT padding (round 4) — pitch 16 floats = one 64-byte K chunk per row — and the 16-byte piece index XOR-ed by
+// panel_swz(row): conflict-free ds_read_b128 fragments for any window base (tools/lds_layout.py, tests/test_lds_layout.py) and 20 % less
+// LDS than pitch 20 (LDS_LD, still used by the folded-deconv halo), whose every fragment read is a 2-way conflict.  The bf16 matrix
+// phases are 8x shorter than the fp32 ones for the same fragment bytes, so the LDS arrays are what the bf16 kernels wait for (3x3: +7-12 %
+// on isolated layers); fp32 gains 0.7 % on the whole forward (33.66 -> 33.44 ms, tools/gpu/ab_f32.sh).  Fragment rows are
+// 16j + (lane & 15) and staging rows (tid >> 2) + 64 it, so the swizzle term is a per-lane constant in both.
 template <typename T> struct PanelLayout {
-  static constexpr bool SWZ = sizeof(T) == 2;
+  static constexpr bool SWZ = true;
   static constexpr int LD = SWZ ? 16 : LDS_LD;
 };
 __device__ __forceinline__ int panel_swz(int row) { return ((row >> 2) & 1) << 1; }

@@ -32,9 +32,9 @@ struct PwGeom {
   // kernel): the staging registers of the NEXT tile's first stage stay live across the epilogue (persistent loop), and
   // with 4 pieces they push the 14-20 accumulator tiles over the 256-VGPR cap of 2 waves per SIMD (spills).
   static constexpr int KP = 2;
-  // floats per staged row.  bf16: no padding, the 8 pieces of a row XOR-swizzled by (row >> 1) & 7 — conflict-free fragment
+  // floats per staged row: no padding, the 8 pieces of a row XOR-swizzled by (row >> 1) & 7 — conflict-free fragment
   // reads (tools/lds_layout.py; pitch 36 makes every ds_read_b128 a 2-way conflict), see PanelLayout in conv_common.h
-  static constexpr bool SWZ = sizeof(T) == 2;
+  static constexpr bool SWZ = true;
   static constexpr int LDF = SWZ ? 16 * KP : 16 * KP + 4;
   static constexpr int OLD = BN + 4;                                             // floats per epilogue-tile row
   static constexpr int IC = (BM * OLD * 4 <= LDS_BUDGET) ? MT : MT / 2;          // MFMA row tiles per epilogue pass

@@ -37,16 +37,17 @@ def test_weight_gradient_pitch_in_the_source_is_conflict_free():
 
 
 def test_bf16_layouts_in_the_source_are_conflict_free():
-    """Round 4: the bf16 GEMM kernels stage unpadded, XOR-swizzled panels (conv_common.h PanelLayout / panel_swz), the bf16 3x3
-    halo is 64-byte pixel rows in 24 slots per halo row with the same swizzle on the halo column, the bf16 pointwise kernel has
+    """Round 4: the GEMM kernels (both storage types) stage unpadded, XOR-swizzled panels (conv_common.h PanelLayout / panel_swz), the 3x3
+    halo is 64-byte pixel rows in 24 slots per halo row with the same swizzle on the halo column, the pointwise kernel has
     8 pieces per row swizzled by (row >> 1) & 7.  Restated here from the source and checked against the lane-group model."""
     common = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv_common.h")).read()
     assert "__device__ __forceinline__ int panel_swz(int row) { return ((row >> 2) & 1) << 1; }" in common
     assert "static constexpr int LD = SWZ ? 16 : LDS_LD;" in common
     c3 = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv3x3_impl.h")).read()
-    assert "static constexpr int HCP = HSW ? 24 : 18;" in c3 and "(((hx >> 2) & 1) << 1)" in c3
+    assert "static constexpr bool SWZ = true;" in common
+    assert "static constexpr bool HSW = !(NW == 8 && sizeof(T) == 4 && !DMA);" in c3 and "static constexpr int HCP = HSW ? 24 : 18;" in c3 and "(((hx >> 2) & 1) << 1)" in c3
     pw = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv_pw_impl.h")).read()
-    assert "static constexpr int LDF = SWZ ? 16 * KP : 16 * KP + 4;" in pw and "((frow >> 1) & 7)" in pw
+    assert "static constexpr bool SWZ = true;" in pw and "static constexpr int LDF = SWZ ? 16 * KP : 16 * KP + 4;" in pw and "((frow >> 1) & 7)" in pw
     swz = lambda row: ((row >> 2) & 1) << 1
     for base in range(0, 256, 16):                      # row-indexed panels: fragment rows 16 j + (lane & 15)
         assert L.cycles("read_b128", L.fragment_b128(16, base=base, swizzle=swz)) == (4, 4)
