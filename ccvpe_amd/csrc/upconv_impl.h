@@ -527,6 +527,318 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
   CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
+// ---------------------------------------------------------------------------------------------
+// upconv_dma_kernel (round 4; bf16 only): phase A of upconv_halo_kernel in the stage structure of conv3x3_kernel.
+// In bf16 a one-tap stage of upconv_halo_kernel is 20 matrix instructions = 320 cycles, far less than the L2 round trip of the
+// W panel it waits for at its end (register-staged, requested at the start of the same stage): the traced kernels run at 24 %
+// of the matrix peak (5x the fp32 kernel where conv3x3_kernel gets 7x).  Here a stage is a PAIR of taps (du; dv = 0, 1) of a
+// 32-channel chunk: its two W panels arrive by LDS-DMA (requested at the start of the PREVIOUS stage, no VGPR round trip, no
+// ds_write), the fragments of the second tap are read while the first tap's matrix instructions run, and the halo uses the
+// conflict-free swizzled layout of conv3x3_kernel.  Phase B (the skip's 9 taps, 28-36 % of K) is the register-staged gather of
+// upconv_halo_kernel unchanged.  Needs Npad % BN == 0 (the DMA has no row guard) and W1 >= 16.
+// ---------------------------------------------------------------------------------------------
+template <typename T, int MT, int NT, int WN>
+struct UpDmaGeom {
+  static constexpr int WM = 4 / WN;
+  static constexpr int BM = 16 * MT * WM;
+  static constexpr int BN = 16 * NT * WN;
+  static constexpr int TH = BM / 16;
+  static constexpr int HR = TH + 2, HCP = 24, HLD = 16;
+  static constexpr int U_FLOATS = (HR * HCP * HLD > 2 * BM * LDS_LD) ? HR * HCP * HLD : 2 * BM * LDS_LD;   // halo | phase-B A stage
+  static constexpr int B_FLOATS = 2 * 2 * BN * 16;                                                           // [2][2 taps][BN][16] (phase B: [2][BN][16])
+  static constexpr int LDS_BYTES = (U_FLOATS + B_FLOATS) * 4;
+};
+
+template <typename T, int MT, int NT, int WN>
+__global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
+  using G = UpDmaGeom<T, MT, NT, WN>;
+  constexpr int E = ElemTraits<T>::E;
+  constexpr int SK = 4 * E;
+  constexpr int CPS = SK / 8;
+  constexpr int WM = G::WM, BM = G::BM, BN = G::BN, TH = G::TH, HR = G::HR, HCP = G::HCP, HLD = G::HLD;
+  constexpr int HC = 18, HPX = HR * HC;
+  constexpr int H_IT = (HPX * 4 + 255) / 256;
+  constexpr int A_IT = BM / 64;
+  constexpr int B_IT = (BN + 63) / 64;
+  constexpr int NSLOT = (BN / 16 + 3) / 4;
+
+  extern __shared__ __attribute__((aligned(16))) float up_sm[];
+  float* Us = up_sm;                               // halo [HR][HCP][HLD]  |  phase-B A stage [2][BM][LDS_LD]
+  float* Bs = up_sm + G::U_FLOATS;                 // phase A: [2][2][BN][16] by DMA; phase B: [2][BN][16]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = sgpr(tid >> 6);
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  const int tile = xcd_tile(blockIdx.x, p.tiles_total);
+  const int tn = tile % p.tiles_n;
+  const int par = (tile / p.tiles_n) & 3;
+  const int ts = tile / (p.tiles_n * 4);
+  const int tiles_x = (p.W1 + 15) / 16;
+  const int tiles_y = (p.H1 + TH - 1) / TH;
+  const int tx = ts % tiles_x;
+  const int ty = (ts / tiles_x) % tiles_y;
+  const int b = ts / (tiles_x * tiles_y);
+  const int py = par >> 1, px = par & 1;
+  const int y0 = ty * TH, x0 = tx * 16;
+  const int n0 = tn * BN;
+  const int H2 = 2 * p.H1, W2 = 2 * p.W1;
+
+  const T* src0 = reinterpret_cast<const T*>(p.src0);
+  const T* src1 = reinterpret_cast<const T*>(p.src1);
+  const T* wp = reinterpret_cast<const T*>(p.w) + (size_t)par * p.Npad * p.Kpad;
+  const int srow = tid >> 2, ssub = tid & 3;
+  const int wscol = (ssub ^ panel_swz(srow)) * 4;
+
+  // ---- halo staging coordinates ----------------------------------------------------------------
+  int h_off[H_IT], h_pix[H_IT], h_sub[H_IT];
+#pragma unroll
+  for (int it = 0; it < H_IT; ++it) {
+    const int idx = tid + 256 * it;
+    const int pxl = idx >> 2, sub = idx & 3;
+    h_sub[it] = sub;
+    if (pxl < HPX) {
+      const int hy = pxl / HC, hx = pxl - hy * HC;
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      h_off[it] = (hy * HCP + hx) * HLD + (sub ^ panel_swz(hx)) * 4;
+      h_pix[it] = ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1) ? (b * p.H1 + iy) * p.W1 + ix : -1;
+    } else {
+      h_off[it] = -1;
+      h_pix[it] = -1;
+    }
+  }
+  f32x4 h_reg[H_IT], b_reg[B_IT], a_reg[A_IT];
+  unsigned h_keep = 0, a_keep = 0;
+  const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
+  const bool small32 = (double)p.M * 4.0 * (double)(ld0s > ld1s ? ld0s : ld1s) * sizeof(T) < 4294967296.0;
+  auto load_halo = [&](int chunk) {         // raw loads from clamped addresses (STAGING RULE)
+    h_keep = 0;
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it) {
+      const int ch = chunk * SK + h_sub[it] * E;
+      const bool ok = h_pix[it] >= 0 && ch < p.c0;
+      if (small32) h_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src0) + (ok ? ((unsigned)h_pix[it] * (unsigned)ld0s + (unsigned)ch) * (unsigned)sizeof(T) : 0u));
+      else h_reg[it] = *reinterpret_cast<const f32x4*>(src0 + (ok ? (size_t)h_pix[it] * ld0s + ch : 0));
+      h_keep |= ok ? (1u << it) : 0u;
+    }
+  };
+  auto store_halo = [&]() {
+#pragma unroll
+    for (int it = 0; it < H_IT; ++it)
+      if (h_off[it] >= 0) *reinterpret_cast<f32x4*>(Us + h_off[it]) = keep_if(h_reg[it], (h_keep >> it) & 1u);
+  };
+
+  // ---- W by LDS-DMA (phase A): lane -> (row = lane >> 2 of a 16-row group, swizzled 16-byte piece), as conv3x3_kernel --------
+  unsigned wvoff[NSLOT];
+  {
+    const int rl = lane >> 2;
+    const int c = (lane & 3) ^ w_swz(rl);
+#pragma unroll
+    for (int q = 0; q < NSLOT; ++q) {
+      const int g = min(wave + 4 * q, BN / 16 - 1);
+      wvoff[q] = ((unsigned)(n0 + g * 16 + rl) * (unsigned)p.Kpad + (unsigned)(c * E)) * (unsigned)sizeof(T);
+    }
+  }
+  const unsigned bs_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float*)Bs;
+  const int kmax = p.Kpad - SK;                    // last K column a 64-byte panel row may start at (stay inside the W row)
+  auto dma_w = [&](int chunk, int du, int dbuf) {  // taps (du, 0), (du, 1) of `chunk` -> Bs[dbuf][0..1]
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // (a panel beyond the channel range meets zeroed halo pieces; clamped so that the last row's read stays inside W)
+      const int kcol = min((du * 2 + t) * p.c0 + chunk * SK, kmax);
+      const char* sbase = reinterpret_cast<const char*>(wp) + (size_t)kcol * sizeof(T);
+#pragma unroll
+      for (int q = 0; q < NSLOT; ++q) {
+        const int g = wave + 4 * q;
+        if (g < BN / 16) {
+          const unsigned lds = __builtin_amdgcn_readfirstlane(bs_lds + (unsigned)(((dbuf * 2 + t) * BN + g * 16) * 16 * 4));
+          asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(wvoff[q]), "s"(sbase) : "memory", "m0");
+        }
+      }
+    }
+  };
+  auto dma_wait = [&]() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+
+  f32x4 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15;
+  const int bcol = ((lane >> 4) ^ w_swz(frow)) * 4;                   // DMA panel (phase A)
+  const int fkb = ((lane >> 4) ^ panel_swz(frow)) * 4;                // register-staged W panel (phase B)
+  const int fka = (lane >> 4) * 4;                                    // phase-B A stage (pitch 20, unswizzled)
+  auto hcol_at = [&](int c) { return (wm * MT * HCP + frow + c) * HLD + ((lane >> 4) ^ panel_swz(frow + c)) * 4; };
+  const int hdv0 = hcol_at(px) + py * (HCP * HLD), hdv1 = hcol_at(px + 1) + py * (HCP * HLD);
+
+  // ================= phase A: low-res source, 2 stages (du = 0, 1) of 2 taps per 32-channel chunk =================
+  const int nchunks0 = (p.c0 + SK - 1) / SK;
+  const int nstA = nchunks0 * 2;
+  load_halo(0);
+  dma_w(0, 0, 0);
+  store_halo();
+  dma_wait();
+  __syncthreads();
+  auto stage_a = [&](int s, int chunk, auto du_tag) {
+    constexpr int du = decltype(du_tag)::value;
+    const bool more = s + 1 < nstA;
+    const bool next_halo = (du == 0) && (chunk + 1 < nchunks0);
+    f32x4 af[2][MT], bf[2][NT];
+    auto read_frag = [&](int t, f32x4* a, f32x4* w_) {
+      const int ab = (t ? hdv1 : hdv0) + du * (HCP * HLD);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[i] = *reinterpret_cast<const f32x4*>(Us + ab + i * (HCP * HLD));
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        w_[j] = *reinterpret_cast<const f32x4*>(&Bs[((((s & 1) * 2 + t) * BN) + (wn * NT + j) * 16 + frow) * 16 + bcol]);
+    };
+    read_frag(0, af[0], bf[0]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t == 0) {
+        read_frag(1, af[1], bf[1]);                       // second tap's fragments: in flight under the first tap's MFMAs
+        if (next_halo) load_halo(chunk + 1);
+        if (more) dma_w(du == 0 ? chunk : chunk + 1, du ^ 1, (s + 1) & 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[t][j], af[t][i], acc[i][j]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    dma_wait();
+    __syncthreads();
+    if (du == 1 && more) {                                // chunk boundary: every wave is done reading the halo -> overwrite it
+      store_halo();
+      __syncthreads();
+    }
+  };
+  for (int chunk = 0; chunk < nchunks0; ++chunk) {
+    stage_a(2 * chunk, chunk, std::integral_constant<int, 0>{});
+    stage_a(2 * chunk + 1, chunk, std::integral_constant<int, 1>{});
+  }
+
+  // ================= phase B: skip, 9 taps (stride 2, parity offset), gathered (as upconv_halo_kernel) ===================
+  const int chunksB = 9 * p.cpt1;
+  if (chunksB > 0) {
+    unsigned wrow[B_IT];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      wrow[it] = (unsigned)min(n0 + srow + 64 * it, p.Npad - 1) * (unsigned)p.Kpad * (unsigned)sizeof(T);
+    auto load_w = [&](int kcol) {
+      const char* wb = reinterpret_cast<const char*>(wp) + (size_t)kcol * sizeof(T);
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) b_reg[it] = *reinterpret_cast<const f32x4*>(wb + wrow[it]);
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it) {
+        const int nrow = srow + 64 * it;
+        if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + nrow) * 16 + wscol]) = b_reg[it];
+      }
+    };
+    const int stagesB = (chunksB + CPS - 1) / CPS;
+    const int chunk_in_stage = (ssub * E) >> 3;
+    const int half = (ssub * E) & 7;
+    const int kB0 = 4 * p.c0;
+    int a_pix[A_IT], a_yy[A_IT], a_xx[A_IT];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      const int ml = srow + 64 * it;
+      const int y1 = y0 + (ml >> 4), x1 = x0 + (ml & 15);
+      a_pix[it] = (y1 < p.H1 && x1 < p.W1) ? 1 : 0;
+      a_yy[it] = 2 * y1 + py - 1;
+      a_xx[it] = 2 * x1 + px - 1;
+    }
+    auto load_a = [&](int s) {
+      const int kc = CPS * s + chunk_in_stage;
+      const bool kvalid = kc < chunksB;
+      const int tapb = kc / p.cpt1;
+      const int ch = kvalid ? (kc - tapb * p.cpt1) * 8 + half : 0;
+      const int ky = tapb / 3, kx = tapb - 3 * ky;
+      a_keep = 0;
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        const int iy = a_yy[it] + ky, ix = a_xx[it] + kx;
+        const bool ok = kvalid && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+        const int pix = ok ? (b * H2 + iy) * W2 + ix : 0;
+        if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src1) + ((unsigned)pix * (unsigned)ld1s + (unsigned)ch) * (unsigned)sizeof(T));
+        else a_reg[it] = *reinterpret_cast<const f32x4*>(src1 + (size_t)pix * ld1s + ch);
+        a_keep |= ok ? (1u << it) : 0u;
+      }
+    };
+    auto store_a = [&](int buf) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        *reinterpret_cast<f32x4*>(&Us[(buf * BM + srow + 64 * it) * LDS_LD + ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
+    };
+    // the halo and the DMA panels are dead (phase A ended on a barrier)
+    load_a(0);
+    load_w(kB0 + ssub * E);
+    store_a(0);
+    store_w(0);
+    __syncthreads();
+    for (int s = 0; s < stagesB; ++s) {
+      const int buf = s & 1;
+      const bool more = s + 1 < stagesB;
+      if (more) {
+        load_a(s + 1);
+        load_w(kB0 + (s + 1) * SK + ssub * E);
+      }
+      f32x4 af[MT], bf[NT];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(&Us[(buf * BM + (wm * MT + i) * 16 + frow) * LDS_LD + fka]);
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + (wn * NT + j) * 16 + frow) * 16 + fkb]);
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
+      if (more) {
+        store_a(buf ^ 1);
+        store_w(buf ^ 1);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue (as upconv_halo_kernel) -----------------------------------------------------------
+  const int epix = lane & 15;
+  const int en = (lane >> 4) * 4;
+  IgemmParams ep{};
+  ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
+  const float one[4] = {1.f, 1.f, 1.f, 1.f};
+  const int x1 = x0 + epix;
+  auto epilogue = [&](auto act_tag) {
+  constexpr int ACT = decltype(act_tag)::value;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int y1 = y0 + wm * MT + i;
+    if (y1 >= p.H1 || x1 >= p.W1) continue;
+    const int Y = 2 * y1 + py, X = 2 * x1 + px;
+    const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
+    const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
+    const float* shp = p.shift9 + (size_t)(rc * 3 + cc) * p.N;
+    const size_t pix = (size_t)(b * H2 + Y) * W2 + X;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int n = n0 + (wn * NT + j) * 16 + en;
+      if (n >= p.N) continue;
+      float sh[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sh[q] = (n + q < p.N) ? shp[n + q] : 0.f;
+      store4<T, ACT>(ep, acc[i][j], n, pix * p.ldd + n, 0, one, sh);
+    }
+  }
+  };
+  CCVPE_ACT_DISPATCH(p.act, epilogue);
+}
+
 template <typename T, int MT, int NT, int WN>
 static int launch_up(const UpParams& p0, hipStream_t stream) {
   constexpr int WM = 4 / WN;
@@ -543,6 +855,16 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
   const long total = (long)p.tiles_m * p.tiles_n * 4;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "upconv: grid too large");
   p.tiles_total = (int)total;
+  if constexpr (sizeof(T) == 2) {
+    // bf16: pair-of-taps stages with W by LDS-DMA (see upconv_dma_kernel) where the DMA's preconditions hold
+    // (the 256 x 48 tile measured slower with it, 479 -> 531 us at N = 40: 169 VGPRs = one workgroup less per SIMD)
+    if (halo && p.Npad % BN == 0 && p.Kpad >= 4 * ElemTraits<T>::E && !(NT == 3 && WN == 1)) {
+      using G = UpDmaGeom<T, MT, NT, WN>;
+      static_assert(G::LDS_BYTES <= 64 * 1024, "upconv_dma_kernel: dynamic LDS over the default limit");
+      hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
+      return check_launch("upconv_dma_kernel");
+    }
+  }
   if (halo)
     hipLaunchKernelGGL((upconv_halo_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
   else
