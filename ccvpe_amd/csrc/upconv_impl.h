@@ -544,7 +544,8 @@ struct UpDmaGeom {
   static constexpr int BN = 16 * NT * WN;
   static constexpr int TH = BM / 16;
   static constexpr int HR = TH + 2, HCP = 24, HLD = 16;
-  static constexpr int U_FLOATS = (HR * HCP * HLD > 2 * BM * LDS_LD) ? HR * HCP * HLD : 2 * BM * LDS_LD;   // halo | phase-B A stage
+  static constexpr int SUBS = (WN == 2 && NT >= 3) ? 2 : 1;   // phase B: K stages per barrier (256-pixel tiles: no LDS for two; narrow tiles measured slower with two)
+  static constexpr int U_FLOATS = (HR * HCP * HLD > 2 * SUBS * BM * 16) ? HR * HCP * HLD : 2 * SUBS * BM * 16;   // halo | phase-B A stage [2][SUBS][BM][16]
   static constexpr int B_FLOATS = 2 * 2 * BN * 16;                                                           // [2][2 taps][BN][16] (phase B: [2][BN][16])
   static constexpr int LDS_BYTES = (U_FLOATS + B_FLOATS) * 4;
 };
@@ -555,16 +556,16 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;
   constexpr int CPS = SK / 8;
-  constexpr int WM = G::WM, BM = G::BM, BN = G::BN, TH = G::TH, HR = G::HR, HCP = G::HCP, HLD = G::HLD;
+  constexpr int BM = G::BM, BN = G::BN, TH = G::TH, HR = G::HR, HCP = G::HCP, HLD = G::HLD;
   constexpr int HC = 18, HPX = HR * HC;
   constexpr int H_IT = (HPX * 4 + 255) / 256;
   constexpr int A_IT = BM / 64;
-  constexpr int B_IT = (BN + 63) / 64;
   constexpr int NSLOT = (BN / 16 + 3) / 4;
+  constexpr int SUBS = G::SUBS;
 
   extern __shared__ __attribute__((aligned(16))) float up_sm[];
-  float* Us = up_sm;                               // halo [HR][HCP][HLD]  |  phase-B A stage [2][BM][LDS_LD]
-  float* Bs = up_sm + G::U_FLOATS;                 // phase A: [2][2][BN][16] by DMA; phase B: [2][BN][16]
+  float* Us = up_sm;                               // halo [HR][HCP][HLD]  |  phase-B A stage [2][SUBS][BM][16] (swizzled)
+  float* Bs = up_sm + G::U_FLOATS;                 // [2][2][BN][16] by DMA (phase B uses [2][SUBS])
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -590,7 +591,6 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   const T* src1 = reinterpret_cast<const T*>(p.src1);
   const T* wp = reinterpret_cast<const T*>(p.w) + (size_t)par * p.Npad * p.Kpad;
   const int srow = tid >> 2, ssub = tid & 3;
-  const int wscol = (ssub ^ panel_swz(srow)) * 4;
 
   // ---- halo staging coordinates ----------------------------------------------------------------
   int h_off[H_IT], h_pix[H_IT], h_sub[H_IT];
@@ -609,8 +609,8 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
       h_pix[it] = -1;
     }
   }
-  f32x4 h_reg[H_IT], b_reg[B_IT], a_reg[A_IT];
-  unsigned h_keep = 0, a_keep = 0;
+  f32x4 h_reg[H_IT];
+  unsigned h_keep = 0;
   const int ld0s = sgpr(p.ld0), ld1s = sgpr(p.ld1);
   const bool small32 = (double)p.M * 4.0 * (double)(ld0s > ld1s ? ld0s : ld1s) * sizeof(T) < 4294967296.0;
   auto load_halo = [&](int chunk) {         // raw loads from clamped addresses (STAGING RULE)
@@ -668,8 +668,7 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   const int frow = lane & 15;
   const int bcol = ((lane >> 4) ^ w_swz(frow)) * 4;                   // DMA panel (phase A)
-  const int fkb = ((lane >> 4) ^ panel_swz(frow)) * 4;                // register-staged W panel (phase B)
-  const int fka = (lane >> 4) * 4;                                    // phase-B A stage (pitch 20, unswizzled)
+  const int fkb = ((lane >> 4) ^ panel_swz(frow)) * 4;                // phase-B A stage (row-indexed, panel_swz)
   auto hcol_at = [&](int c) { return (wm * MT * HCP + frow + c) * HLD + ((lane >> 4) ^ panel_swz(frow + c)) * 4; };
   const int hdv0 = hcol_at(px) + py * (HCP * HLD), hdv1 = hcol_at(px + 1) + py * (HCP * HLD);
 
@@ -721,29 +720,20 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
     stage_a(2 * chunk + 1, chunk, std::integral_constant<int, 1>{});
   }
 
-  // ================= phase B: skip, 9 taps (stride 2, parity offset), gathered (as upconv_halo_kernel) ===================
+  // ================= phase B: skip, 9 taps (stride 2, parity offset), gathered =========================================
+  // K stages of 32 (tap, channel) columns as in upconv_halo_kernel, but SUBS of them per barrier: the A pieces of the next
+  // group are requested at the start of a group and written to LDS at its end, W arrives by DMA, the fragments of the second
+  // K stage are read under the first one's matrix instructions.
   const int chunksB = 9 * p.cpt1;
   if (chunksB > 0) {
-    unsigned wrow[B_IT];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      wrow[it] = (unsigned)min(n0 + srow + 64 * it, p.Npad - 1) * (unsigned)p.Kpad * (unsigned)sizeof(T);
-    auto load_w = [&](int kcol) {
-      const char* wb = reinterpret_cast<const char*>(wp) + (size_t)kcol * sizeof(T);
-#pragma unroll
-      for (int it = 0; it < B_IT; ++it) b_reg[it] = *reinterpret_cast<const f32x4*>(wb + wrow[it]);
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-      for (int it = 0; it < B_IT; ++it) {
-        const int nrow = srow + 64 * it;
-        if (nrow < BN) *reinterpret_cast<f32x4*>(&Bs[(buf * BN + nrow) * 16 + wscol]) = b_reg[it];
-      }
-    };
     const int stagesB = (chunksB + CPS - 1) / CPS;
+    const int ngroups = (stagesB + SUBS - 1) / SUBS;
     const int chunk_in_stage = (ssub * E) >> 3;
     const int half = (ssub * E) & 7;
     const int kB0 = 4 * p.c0;
+    const int scola = (ssub ^ panel_swz(srow)) * 4;
+    f32x4 a_reg[SUBS][A_IT];
+    unsigned a_keep[SUBS];
     int a_pix[A_IT], a_yy[A_IT], a_xx[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
@@ -753,56 +743,84 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
       a_yy[it] = 2 * y1 + py - 1;
       a_xx[it] = 2 * x1 + px - 1;
     }
-    auto load_a = [&](int s) {
-      const int kc = CPS * s + chunk_in_stage;
+    auto load_a = [&](int s2, int sub) {           // K stage s2 -> a_reg[sub] (sub: compile-time after unrolling)
+      const int kc = CPS * s2 + chunk_in_stage;
       const bool kvalid = kc < chunksB;
       const int tapb = kc / p.cpt1;
       const int ch = kvalid ? (kc - tapb * p.cpt1) * 8 + half : 0;
       const int ky = tapb / 3, kx = tapb - 3 * ky;
-      a_keep = 0;
+      a_keep[sub] = 0;
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         const int iy = a_yy[it] + ky, ix = a_xx[it] + kx;
         const bool ok = kvalid && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
         const int pix = ok ? (b * H2 + iy) * W2 + ix : 0;
-        if (small32) a_reg[it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src1) + ((unsigned)pix * (unsigned)ld1s + (unsigned)ch) * (unsigned)sizeof(T));
-        else a_reg[it] = *reinterpret_cast<const f32x4*>(src1 + (size_t)pix * ld1s + ch);
-        a_keep |= ok ? (1u << it) : 0u;
+        if (small32) a_reg[sub][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src1) + ((unsigned)pix * (unsigned)ld1s + (unsigned)ch) * (unsigned)sizeof(T));
+        else a_reg[sub][it] = *reinterpret_cast<const f32x4*>(src1 + (size_t)pix * ld1s + ch);
+        a_keep[sub] |= ok ? (1u << it) : 0u;
       }
     };
     auto store_a = [&](int buf) {
 #pragma unroll
-      for (int it = 0; it < A_IT; ++it)
-        *reinterpret_cast<f32x4*>(&Us[(buf * BM + srow + 64 * it) * LDS_LD + ssub * 4]) = keep_if(a_reg[it], (a_keep >> it) & 1u);
+      for (int sub = 0; sub < SUBS; ++sub)
+#pragma unroll
+        for (int it = 0; it < A_IT; ++it)
+          *reinterpret_cast<f32x4*>(&Us[((buf * SUBS + sub) * BM + srow + 64 * it) * 16 + scola]) = keep_if(a_reg[sub][it], (a_keep[sub] >> it) & 1u);
     };
-    // the halo and the DMA panels are dead (phase A ended on a barrier)
-    load_a(0);
-    load_w(kB0 + ssub * E);
+    auto dma_wb = [&](int grp, int dbuf) {          // the SUBS K stages of group `grp` -> Bs[dbuf][0..SUBS)
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub) {
+        const int kcol = min(kB0 + (grp * SUBS + sub) * SK, kmax);      // (past the last stage: any panel, its A pieces are zero)
+        const char* sbase = reinterpret_cast<const char*>(wp) + (size_t)kcol * sizeof(T);
+#pragma unroll
+        for (int q = 0; q < NSLOT; ++q) {
+          const int g = wave + 4 * q;
+          if (g < BN / 16) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane(bs_lds + (unsigned)(((dbuf * 2 + sub) * BN + g * 16) * 16 * 4));
+            asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(wvoff[q]), "s"(sbase) : "memory", "m0");
+          }
+        }
+      }
+    };
+    // the halo and phase A's panels are dead (phase A ended on a barrier)
+#pragma unroll
+    for (int sub = 0; sub < SUBS; ++sub) load_a(sub, sub);
+    dma_wb(0, 0);
     store_a(0);
-    store_w(0);
+    dma_wait();
     __syncthreads();
-    for (int s = 0; s < stagesB; ++s) {
-      const int buf = s & 1;
-      const bool more = s + 1 < stagesB;
-      if (more) {
-        load_a(s + 1);
-        load_w(kB0 + (s + 1) * SK + ssub * E);
+    for (int grp = 0; grp < ngroups; ++grp) {
+      const int buf = grp & 1;
+      const bool more = grp + 1 < ngroups;
+      f32x4 af[SUBS][MT], bf[SUBS][NT];
+      auto read_frag = [&](int sub, f32x4* a, f32x4* w_) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+          a[i] = *reinterpret_cast<const f32x4*>(&Us[((buf * SUBS + sub) * BM + (wm * MT + i) * 16 + frow) * 16 + fkb]);
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          w_[j] = *reinterpret_cast<const f32x4*>(&Bs[((buf * 2 + sub) * BN + (wn * NT + j) * 16 + frow) * 16 + bcol]);
+      };
+      read_frag(0, af[0], bf[0]);
+#pragma unroll
+      for (int sub = 0; sub < SUBS; ++sub) {
+        if (sub == 0) {
+          if (SUBS > 1) read_frag(SUBS - 1, af[SUBS - 1], bf[SUBS - 1]);
+          if (more) {
+#pragma unroll
+            for (int s2 = 0; s2 < SUBS; ++s2) load_a((grp + 1) * SUBS + s2, s2);
+            dma_wb(grp + 1, buf ^ 1);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[sub][j], af[sub][i], acc[i][j]);
       }
-      f32x4 af[MT], bf[NT];
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-        af[i] = *reinterpret_cast<const f32x4*>(&Us[(buf * BM + (wm * MT + i) * 16 + frow) * LDS_LD + fka]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-        bf[j] = *reinterpret_cast<const f32x4*>(&Bs[(buf * BN + (wn * NT + j) * 16 + frow) * 16 + fkb]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[j], af[i], acc[i][j]);
-      if (more) {
-        store_a(buf ^ 1);
-        store_w(buf ^ 1);
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) store_a(buf ^ 1);
+      dma_wait();
       __syncthreads();
     }
   }
@@ -860,7 +878,13 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
     // (the 256 x 48 tile measured slower with it, 479 -> 531 us at N = 40: 169 VGPRs = one workgroup less per SIMD)
     if (halo && p.Npad % BN == 0 && p.Kpad >= 4 * ElemTraits<T>::E && !(NT == 3 && WN == 1)) {
       using G = UpDmaGeom<T, MT, NT, WN>;
-      static_assert(G::LDS_BYTES <= 64 * 1024, "upconv_dma_kernel: dynamic LDS over the default limit");
+      static_assert(G::LDS_BYTES <= 80 * 1024, "upconv_dma_kernel: two workgroups per CU");
+      static bool attr_set = false;                 // per (T, tile) instantiation of this launcher
+      if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)upconv_dma_kernel<T, MT, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "upconv_dma_kernel: set smem attr: %s", hipGetErrorString(e));
+        attr_set = true;
+      }
       hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
       return check_launch("upconv_dma_kernel");
     }
