@@ -537,27 +537,27 @@ __global__ __launch_bounds__(256) void upconv_halo_kernel(const UpParams p) {
 // conflict-free swizzled layout of conv3x3_kernel.  Phase B (the skip's 9 taps, 28-36 % of K) is the register-staged gather of
 // upconv_halo_kernel unchanged.  Needs Npad % BN == 0 (the DMA has no row guard) and W1 >= 16.
 // ---------------------------------------------------------------------------------------------
-template <typename T, int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN, bool PAIR = false>
 struct UpDmaGeom {
   static constexpr int WM = 4 / WN;
   static constexpr int BM = 16 * MT * WM;
   static constexpr int BN = 16 * NT * WN;
   static constexpr int TH = BM / 16;
-  static constexpr int HR = TH + 2, HCP = 24, HLD = 16;
+  static constexpr int HR = TH + 2, HCP = PAIR ? 32 : 24, HLD = 16;
   static constexpr int SUBS = (WN == 2 && NT >= 3) ? 2 : 1;   // phase B: K stages per barrier (256-pixel tiles: no LDS for two; narrow tiles measured slower with two)
   static constexpr int U_FLOATS = (HR * HCP * HLD > 2 * SUBS * BM * 16) ? HR * HCP * HLD : 2 * SUBS * BM * 16;   // halo | phase-B A stage [2][SUBS][BM][16]
   static constexpr int B_FLOATS = 2 * 2 * BN * 16;                                                           // [2][2 taps][BN][16] (phase B: [2][BN][16])
   static constexpr int LDS_BYTES = (U_FLOATS + B_FLOATS) * 4;
 };
 
-template <typename T, int MT, int NT, int WN>
+template <typename T, int MT, int NT, int WN, bool PAIR = false>
 __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
-  using G = UpDmaGeom<T, MT, NT, WN>;
+  using G = UpDmaGeom<T, MT, NT, WN, PAIR>;
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;
   constexpr int CPS = SK / 8;
   constexpr int BM = G::BM, BN = G::BN, TH = G::TH, HR = G::HR, HCP = G::HCP, HLD = G::HLD;
-  constexpr int HC = 18, HPX = HR * HC;
+  constexpr int HC = PAIR ? 20 : 18, HPX = HR * HC;   // staged halo columns (PAIR: two 10-column halos)
   constexpr int H_IT = (HPX * 4 + 255) / 256;
   constexpr int A_IT = BM / 64;
   constexpr int NSLOT = (BN / 16 + 3) / 4;
@@ -577,11 +577,15 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   const int tn = tile % p.tiles_n;
   const int par = (tile / p.tiles_n) & 3;
   const int ts = tile / (p.tiles_n * 4);
-  const int tiles_x = (p.W1 + 15) / 16;
-  const int tiles_y = (p.H1 + TH - 1) / TH;
+  // PAIR (8 x 8 low-res images, level 6): a tile is TWO images side by side — pixel columns 0-7 = image 2 ts, 8-15 = image
+  // 2 ts + 1; their 10-column halos sit at slots 0-9 and 16-25 of a 32-slot halo row (the gap of 8 keeps the swizzled
+  // fragment reads conflict-free: tests/test_lds_layout.py).  Otherwise one TH x 16 tile of one image.
+  const int tiles_x = PAIR ? 1 : (p.W1 + 15) / 16;
+  const int tiles_y = PAIR ? 1 : (p.H1 + TH - 1) / TH;
   const int tx = ts % tiles_x;
   const int ty = (ts / tiles_x) % tiles_y;
-  const int b = ts / (tiles_x * tiles_y);
+  const int b = PAIR ? 2 * ts : ts / (tiles_x * tiles_y);
+  const int nbatch = p.M / (p.H1 * p.W1);
   const int py = par >> 1, px = par & 1;
   const int y0 = ty * TH, x0 = tx * 16;
   const int n0 = tn * BN;
@@ -600,10 +604,12 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
     const int pxl = idx >> 2, sub = idx & 3;
     h_sub[it] = sub;
     if (pxl < HPX) {
-      const int hy = pxl / HC, hx = pxl - hy * HC;
-      const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+      const int hy = pxl / HC, hc = pxl - hy * HC;
+      const int img = PAIR ? hc / 10 : 0;
+      const int lx = hc - 10 * img, hx = lx + 16 * img;              // column inside the image's halo, slot in the halo row
+      const int iy = y0 - 1 + hy, ix = x0 - 1 + lx;
       h_off[it] = (hy * HCP + hx) * HLD + (sub ^ panel_swz(hx)) * 4;
-      h_pix[it] = ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1) ? (b * p.H1 + iy) * p.W1 + ix : -1;
+      h_pix[it] = ((unsigned)iy < (unsigned)p.H1 && (unsigned)ix < (unsigned)p.W1 && b + img < nbatch) ? ((b + img) * p.H1 + iy) * p.W1 + ix : -1;
     } else {
       h_off[it] = -1;
       h_pix[it] = -1;
@@ -669,7 +675,10 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   const int frow = lane & 15;
   const int bcol = ((lane >> 4) ^ w_swz(frow)) * 4;                   // DMA panel (phase A)
   const int fkb = ((lane >> 4) ^ panel_swz(frow)) * 4;                // phase-B A stage (row-indexed, panel_swz)
-  auto hcol_at = [&](int c) { return (wm * MT * HCP + frow + c) * HLD + ((lane >> 4) ^ panel_swz(frow + c)) * 4; };
+  auto hcol_at = [&](int c) {
+    const int hx = frow + c + (PAIR ? 8 * (frow >> 3) : 0);
+    return (wm * MT * HCP + hx) * HLD + ((lane >> 4) ^ panel_swz(hx)) * 4;
+  };
   const int hdv0 = hcol_at(px) + py * (HCP * HLD), hdv1 = hcol_at(px + 1) + py * (HCP * HLD);
 
   // ================= phase A: low-res source, 2 stages (du = 0, 1) of 2 taps per 32-channel chunk =================
@@ -734,12 +743,14 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
     const int scola = (ssub ^ panel_swz(srow)) * 4;
     f32x4 a_reg[SUBS][A_IT];
     unsigned a_keep[SUBS];
-    int a_pix[A_IT], a_yy[A_IT], a_xx[A_IT];
+    int a_pix[A_IT], a_yy[A_IT], a_xx[A_IT], a_bb[A_IT];
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       const int ml = srow + 64 * it;
-      const int y1 = y0 + (ml >> 4), x1 = x0 + (ml & 15);
-      a_pix[it] = (y1 < p.H1 && x1 < p.W1) ? 1 : 0;
+      const int col = ml & 15;
+      const int y1 = y0 + (ml >> 4), x1 = PAIR ? (col & 7) : x0 + col;
+      a_bb[it] = PAIR ? b + (col >> 3) : b;
+      a_pix[it] = (y1 < p.H1 && x1 < p.W1 && a_bb[it] < nbatch) ? 1 : 0;
       a_yy[it] = 2 * y1 + py - 1;
       a_xx[it] = 2 * x1 + px - 1;
     }
@@ -754,7 +765,7 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
       for (int it = 0; it < A_IT; ++it) {
         const int iy = a_yy[it] + ky, ix = a_xx[it] + kx;
         const bool ok = kvalid && a_pix[it] && (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
-        const int pix = ok ? (b * H2 + iy) * W2 + ix : 0;
+        const int pix = ok ? (a_bb[it] * H2 + iy) * W2 + ix : 0;
         if (small32) a_reg[sub][it] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(src1) + ((unsigned)pix * (unsigned)ld1s + (unsigned)ch) * (unsigned)sizeof(T));
         else a_reg[sub][it] = *reinterpret_cast<const f32x4*>(src1 + (size_t)pix * ld1s + ch);
         a_keep[sub] |= ok ? (1u << it) : 0u;
@@ -831,18 +842,19 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   IgemmParams ep{};
   ep.N = p.N; ep.act = p.act; ep.residual = nullptr; ep.dst = p.dst; ep.out_f32 = p.out_f32;
   const float one[4] = {1.f, 1.f, 1.f, 1.f};
-  const int x1 = x0 + epix;
+  const int x1 = PAIR ? (epix & 7) : x0 + epix;
+  const int eb = PAIR ? b + (epix >> 3) : b;
   auto epilogue = [&](auto act_tag) {
   constexpr int ACT = decltype(act_tag)::value;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
     const int y1 = y0 + wm * MT + i;
-    if (y1 >= p.H1 || x1 >= p.W1) continue;
+    if (y1 >= p.H1 || x1 >= p.W1 || eb >= nbatch) continue;
     const int Y = 2 * y1 + py, X = 2 * x1 + px;
     const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
     const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
     const float* shp = p.shift9 + (size_t)(rc * 3 + cc) * p.N;
-    const size_t pix = (size_t)(b * H2 + Y) * W2 + X;
+    const size_t pix = (size_t)(eb * H2 + Y) * W2 + X;
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       const int n = n0 + (wn * NT + j) * 16 + en;
@@ -875,18 +887,29 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
   p.tiles_total = (int)total;
   if constexpr (sizeof(T) == 2) {
     // bf16: pair-of-taps stages with W by LDS-DMA (see upconv_dma_kernel) where the DMA's preconditions hold
-    // (the 256 x 48 tile measured slower with it, 479 -> 531 us at N = 40: 169 VGPRs = one workgroup less per SIMD)
-    if (halo && p.Npad % BN == 0 && p.Kpad >= 4 * ElemTraits<T>::E && !(NT == 3 && WN == 1)) {
-      using G = UpDmaGeom<T, MT, NT, WN>;
+    // (the 256 x 48 tile measured slower with it, 479 -> 531 us at N = 40, also with three workgroups per SIMD forced: 505)
+    const bool dma_ok = p.Npad % BN == 0 && p.Kpad >= 4 * ElemTraits<T>::E && !(NT == 3 && WN == 1);
+    auto go = [&](auto pair_tag) -> int {
+      constexpr bool PAIR = decltype(pair_tag)::value;
+      using G = UpDmaGeom<T, MT, NT, WN, PAIR>;
       static_assert(G::LDS_BYTES <= 80 * 1024, "upconv_dma_kernel: two workgroups per CU");
-      static bool attr_set = false;                 // per (T, tile) instantiation of this launcher
+      static bool attr_set = false;                 // per (T, tile, PAIR) instantiation
       if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)upconv_dma_kernel<T, MT, NT, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute((const void*)upconv_dma_kernel<T, MT, NT, WN, PAIR>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
         if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "upconv_dma_kernel: set smem attr: %s", hipGetErrorString(e));
         attr_set = true;
       }
-      hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
+      hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN, PAIR>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
       return check_launch("upconv_dma_kernel");
+    };
+    if (halo && dma_ok) return go(std::false_type{});
+    if constexpr (MT == 4 && NT == 5 && WN == 2) {
+      // level 6 (8 x 8 low-res images): two images per 8 x 16 tile instead of the linear-M gather kernel
+      if (dma_ok && p.W1 == 8 && p.H1 == TH) {
+        p.tiles_m = (batch + 1) / 2;
+        p.tiles_total = p.tiles_m * p.tiles_n * 4;
+        return go(std::true_type{});
+      }
     }
   }
   if (halo)

@@ -69,3 +69,20 @@ def test_bf16_layouts_in_the_source_are_conflict_free():
     assert L.cycles("read_b128", L.fragment_b128(36)) == (8, 4)
     # staging writes of the swizzled panels: one row = 4 (8) contiguous pieces per lane group
     assert L.cycles("write_b128", L.staging_b128(16, swizzle=swz)) == (8, 8)
+
+
+def test_paired_level6_halo_is_conflict_free_with_a_gap_of_eight_slots():
+    """upconv_dma_kernel PAIR form: lanes 0-7 of a fragment read image A's halo (slots c .. c + 7), lanes 8-15 image B's (slots
+    16 + c ..): with the swizzle keyed on the slot, a gap of 8 keeps the read conflict-free, gaps of 2 / 4 / 6 do not."""
+    up = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "upconv_impl.h")).read()
+    assert "const int hx = frow + c + (PAIR ? 8 * (frow >> 3) : 0);" in up and "HCP = PAIR ? 32 : 24" in up
+    swz = lambda row: ((row >> 2) & 1) << 1
+    def cyc(gap, c):
+        def addr(lane):
+            frow = lane % 16
+            hx = frow + c + gap * (frow >> 3)
+            return hx * 16 + 4 * ((lane // 16) ^ swz(hx))
+        return L.cycles("read_b128", addr)
+    for c in range(3):
+        assert cyc(8, c) == (4, 4)
+        assert cyc(2, c) == (8, 4)

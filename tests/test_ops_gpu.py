@@ -240,6 +240,30 @@ def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf1
     close(nchw(got).float(), want, 2e-2 if bf16 else 1e-4, "upconv cp=%d" % cp)
 
 
+@pytest.mark.parametrize("b", [3, 4])
+def test_upconv_level6_bf16_packs_two_images_per_tile(ops, b):
+    """Level 6 in bf16 (8 x 8 low-res images, N = 640): upconv_dma_kernel's PAIR form puts two images side by side in one 8 x 16
+    tile (their halos 16 slots apart); an odd batch leaves the last tile half empty.  Against the torch composition, per image."""
+    from ccvpe_amd.models import _pack_upconv
+    cp, cref, cd, c1, co, h1, w1 = 1304, 1281, 1024, 320, 640, 8, 8
+    dt = torch.bfloat16
+    rnd = (lambda t: t.to(dt).float())
+    x = rnd(synth.normal((b, cp, h1, w1), 650 + b))
+    x[:, cref:] = 0
+    skip = rnd(synth.normal((b, c1, 2 * h1, 2 * w1), 651))
+    wd = synth.normal((cref, cd, 2, 2), 652, (1.0 / cref) ** 0.5)
+    bd = synth.normal((cd,), 653, 0.3)
+    w3 = synth.normal((co, cd + c1, 3, 3), 654, (1.0 / (9 * (cd + c1))) ** 0.5)
+    b3 = synth.normal((co,), 655, 0.1)
+    d = F.conv_transpose2d(x[:, :cref], wd, bd, stride=2)
+    want = F.relu(F.conv2d(torch.cat([d, skip], 1), w3, b3, padding=1))
+    fw, fshift = _pack_upconv(wd.cuda(), bd.cuda(), [(0, 0, cref)], cp, w3.cuda(), b3.cuda(), dt)
+    got = ops.upconv3x3(nhwc(x).to(dt).cuda().contiguous(), cp, fw, fshift, co, batch=b, h1=h1, w1=w1,
+                        src1=nhwc(skip).to(dt).cuda().contiguous(), c1=c1, act=ops.ACT_RELU)
+    for i in range(b):
+        close(nchw(got).float()[i], want[i], 2e-2, "level-6 pair, image %d" % i)
+
+
 @pytest.mark.parametrize("cp,cref,cout,h1,w1,bf16", [
     (48, 41, 1, 32, 48, False),      # VIGOR loc level 1: [X/|X| 40 | max score | pad], fp32 (the arg-max decides here)
     (32, 32, 2, 16, 32, False),      # ori level 1, fp32
