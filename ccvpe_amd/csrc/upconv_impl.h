@@ -652,7 +652,7 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   auto dma_w = [&](int chunk, int du, int dbuf) {  // taps (du, 0), (du, 1) of `chunk` -> Bs[dbuf][0..1]
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      // (a panel beyond the channel range meets zeroed halo pieces; clamped so that the last row's read stays inside W)
+      // (a panel beyond the channel range meets zeroed halo pieces; the launcher guarantees kcol <= kmax for every stage)
       const int kcol = min((du * 2 + t) * p.c0 + chunk * SK, kmax);
       const char* sbase = reinterpret_cast<const char*>(wp) + (size_t)kcol * sizeof(T);
 #pragma unroll
@@ -711,10 +711,20 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
         if (more) dma_w(du == 0 ? chunk : chunk + 1, du ^ 1, (s + 1) & 1);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if constexpr (sizeof(T) == 4) {                     // (fp32: the k-step-outer order of the other fp32 kernels)
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[t][j], af[t][i], acc[i][j]);
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[t][j][kk], af[t][i][kk], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[t][j], af[t][i], acc[i][j]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
     dma_wait();
@@ -824,10 +834,20 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
           }
         }
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (sizeof(T) == 4) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+          for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[sub][j], af[sub][i], acc[i][j]);
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+              for (int j = 0; j < NT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[sub][j][kk], af[sub][i][kk], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) acc[i][j] = mfma_stage<T>(bf[sub][j], af[sub][i], acc[i][j]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       if (more) store_a(buf ^ 1);
@@ -885,10 +905,15 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
   const long total = (long)p.tiles_m * p.tiles_n * 4;
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "upconv: grid too large");
   p.tiles_total = (int)total;
-  if constexpr (sizeof(T) == 2) {
-    // bf16: pair-of-taps stages with W by LDS-DMA (see upconv_dma_kernel) where the DMA's preconditions hold
+  {
+    // bf16: pair-of-taps stages with W by LDS-DMA (see upconv_dma_kernel) where the DMA's preconditions hold; fp32 (where the
+    // kernel measured the same as upconv_halo_kernel, +-3 %) only for level 6, whose alternative is the linear-M gather kernel
     // (the 256 x 48 tile measured slower with it, 479 -> 531 us at N = 40, also with three workgroups per SIMD forced: 505)
-    const bool dma_ok = p.Npad % BN == 0 && p.Kpad >= 4 * ElemTraits<T>::E && !(NT == 3 && WN == 1);
+    // Every 64-byte panel row the DMA reads must lie inside its W row: phase A reads K columns up to 3 c0 + ceil32(c0) (the last
+    // tap's last, partly empty chunk: with c1 = 0 and c0 % 32 != 0 that crosses the row end — the reads of VALID K columns would
+    // then have to be shifted, so such shapes stay on upconv_halo_kernel); phase B starts at 4 c0 = 0 mod 32 and ends inside Kpad.
+    constexpr int SKL = 4 * ElemTraits<T>::E;
+    const bool dma_ok = p.Npad % BN == 0 && 3 * p.c0 + (p.c0 + SKL - 1) / SKL * SKL <= p.Kpad && !(NT == 3 && WN == 1);
     auto go = [&](auto pair_tag) -> int {
       constexpr bool PAIR = decltype(pair_tag)::value;
       using G = UpDmaGeom<T, MT, NT, WN, PAIR>;
@@ -902,7 +927,9 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
       hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN, PAIR>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
       return check_launch("upconv_dma_kernel");
     };
-    if (halo && dma_ok) return go(std::false_type{});
+    if constexpr (sizeof(T) == 2) {
+      if (halo && dma_ok) return go(std::false_type{});
+    }
     if constexpr (MT == 4 && NT == 5 && WN == 2) {
       // level 6 (8 x 8 low-res images): two images per 8 x 16 tile instead of the linear-M gather kernel
       if (dma_ok && p.W1 == 8 && p.H1 == TH) {

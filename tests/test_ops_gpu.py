@@ -218,6 +218,9 @@ def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
     (168, 161, 80, 24, 80, 9, 20, True),
     (648, 641, 320, 112, 320, 5, 16, True),
     (64, 64, 32, 16, 32, 19, 35, True),
+    (48, 41, 16, 0, 16, 17, 33, True),        # no skip, c0 % 32 != 0: the DMA kernel's W-row precondition fails -> halo kernel
+    (328, 321, 160, 40, 160, 7, 17, True),    # level 4 in bf16 (DMA kernel, two K stages per barrier in phase B)
+    (256, 256, 128, 40, 128, 6, 16, True),    # ori level 4 in bf16, <4,4,2>
 ])
 def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf16):
     """relu(conv3x3(cat[deconv2x2s2(x)+b, skip])+b)  ==  the folded per-parity GEMM (incl. borders)."""
@@ -240,13 +243,13 @@ def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf1
     close(nchw(got).float(), want, 2e-2 if bf16 else 1e-4, "upconv cp=%d" % cp)
 
 
-@pytest.mark.parametrize("b", [3, 4])
-def test_upconv_level6_bf16_packs_two_images_per_tile(ops, b):
-    """Level 6 in bf16 (8 x 8 low-res images, N = 640): upconv_dma_kernel's PAIR form puts two images side by side in one 8 x 16
+@pytest.mark.parametrize("b,bf16", [(3, True), (4, True), (3, False)])
+def test_upconv_level6_packs_two_images_per_tile(ops, b, bf16):
+    """Level 6 (8 x 8 low-res images, N = 640): upconv_dma_kernel's PAIR form puts two images side by side in one 8 x 16
     tile (their halos 16 slots apart); an odd batch leaves the last tile half empty.  Against the torch composition, per image."""
     from ccvpe_amd.models import _pack_upconv
     cp, cref, cd, c1, co, h1, w1 = 1304, 1281, 1024, 320, 640, 8, 8
-    dt = torch.bfloat16
+    dt = torch.bfloat16 if bf16 else torch.float32
     rnd = (lambda t: t.to(dt).float())
     x = rnd(synth.normal((b, cp, h1, w1), 650 + b))
     x[:, cref:] = 0
@@ -261,7 +264,7 @@ def test_upconv_level6_bf16_packs_two_images_per_tile(ops, b):
     got = ops.upconv3x3(nhwc(x).to(dt).cuda().contiguous(), cp, fw, fshift, co, batch=b, h1=h1, w1=w1,
                         src1=nhwc(skip).to(dt).cuda().contiguous(), c1=c1, act=ops.ACT_RELU)
     for i in range(b):
-        close(nchw(got).float()[i], want[i], 2e-2, "level-6 pair, image %d" % i)
+        close(nchw(got).float()[i], want[i], 2e-2 if bf16 else 1e-4, "level-6 pair, image %d" % i)
 
 
 @pytest.mark.parametrize("cp,cref,cout,h1,w1,bf16", [
