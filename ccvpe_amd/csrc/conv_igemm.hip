@@ -380,6 +380,18 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
   const bool is3x3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
                      d->out_mode == CCVPE_OUT_NHWC && !d->gate;
+  // bf16 3x3 on images >= 16 columns wide with at least 128 halo tiles: the LDS-DMA 3x3 kernel UN-split beats the split-K gather
+  // kernel + its second pass (tools/conv3_probe.py bf16, 16 x 16 images: B = 32 257 -> 166 us at 1344 -> 640 and 140 -> 82 us at
+  // 640 -> 640, B = 16 equal, B = 8 slower), so the planning call reports "no split" there.  fp32 keeps the split (its 3x3 kernel
+  // needs two workgroups per CU to cover its own latencies).
+  if (want_floats && sizeof(T) == 2 && is3x3 && p.W >= 16) {
+    const int th = c.mt * (4 / c.wn), bn = 16 * c.nt * c.wn;
+    const long tiles = (long)d->batch * ((p.H + th - 1) / th) * ((p.W + 15) / 16) * ((p.Npad + bn - 1) / bn);
+    if (tiles >= 128) {
+      *want_floats = 0;
+      return CCVPE_OK;
+    }
+  }
   // split-K mode (planning or with scratch): everything, 3x3 included, goes through the generic gather kernel
   const bool sk = scratch != nullptr || want_floats != nullptr;
   if (scratch && !aligned16(scratch)) return fail(CCVPE_EINVAL, "conv_igemm: scratch must be 16-byte aligned");

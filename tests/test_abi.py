@@ -166,6 +166,12 @@ def test_planning_entry_points_without_a_gpu():
     assert want > 0 and want % (256 * 640) == 0 and 2 <= want // (256 * 640) <= 32
     d.batch = 64                                                            # B = 64: 512 tiles -> one pass
     assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0) == 0
+    # bf16 3x3 with >= 128 halo tiles stays UN-split (the LDS-DMA 3x3 kernel wins there); fp32 and smaller batches still split
+    d.batch, d.kpad = 32, 9 * 1344
+    assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 1) == 0          # 32 x 2 x 1 x 4 = 256 tiles
+    assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0) > 0           # fp32: 256 gather tiles < 320 -> split
+    d.batch = 8
+    assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 1) > 0           # 64 tiles: split
     d.batch, d.c0 = 1, 1343
     assert lib.ccvpe_conv_igemm_splitk_floats(ctypes.byref(d), 0) == EINVAL
     assert lib.ccvpe_conv_igemm_splitk_f32(ctypes.byref(d), None, None) == EINVAL      # no scratch
