@@ -48,6 +48,30 @@ HBM_PEAK_GBS = 8000.0
 # algorithmic forward work per image pair (2 x MACs of every conv / deconv / linear; N_rot = 20 / 16)
 GFLOP_PER_PAIR = {"vigor": 56.37, "kitti": 54.45}
 MB_PER_PAIR_FP32 = {"vigor": 888.0, "kitti": 944.0}
+# per-CONFIGURATION work (FoV 180 halves the ground encoder, ...): profiles/algo_work.json, written by tools/algo_work.py with
+# BASELINE.md §3's rule (hooked B = 1 oracle forward).  Its byte totals are 1.5 % above BASELINE.md's for the two models priced
+# there (901.2 vs 888 MB, 959.6 vs 944), so they are scaled to BASELINE.md's: the published constants stay the yardstick and a
+# configuration is priced by its RATIO to the FoV-360 model of its family.
+WORK_KEY = {"prior0": "vigor_prior0", "vigor20": "vigor20", "prior180_fov180": "vigor_prior180_fov180", "kitti": "kitti",
+            "oxford": "oxford"}
+_ALGO = None
+
+
+def algo_work(work_key):
+    """(GFLOP per pair, fp32 activation MB per pair) of a benched configuration, or None."""
+    global _ALGO
+    if _ALGO is None:
+        try:
+            _ALGO = json.load(open(os.path.join(ROOT, "profiles", "algo_work.json")))
+        except Exception:
+            _ALGO = {}
+    d = _ALGO.get(work_key)
+    if not d:
+        return None
+    fam = "kitti" if work_key == "kitti" else "vigor"
+    ref = _ALGO.get("kitti" if fam == "kitti" else "vigor20")
+    mb = d["mb_per_pair_fp32"] * (MB_PER_PAIR_FP32[fam] / ref["mb_per_pair_fp32"]) if ref else d["mb_per_pair_fp32"]
+    return d["gflop_per_pair"], mb
 
 
 def parse():
@@ -164,18 +188,21 @@ def _traffic(name, workload):
     return d.get(name), src
 
 
-def whole_step_roof(precision, batch, kind, ms_step, train=False):
+def whole_step_roof(precision, batch, kind, ms_step, train=False, work_key=None):
     """The whole step against the governing roof (forward GFLOP / activation MB per pair; fwd+bwd =
-    3 x forward FLOPs).  Needs only the wall time of a step: also available for hipGraph replays."""
-    gf = GFLOP_PER_PAIR.get(kind)
+    3 x forward FLOPs).  Needs only the wall time of a step: also available for hipGraph replays.  `work_key` prices the step
+    with ITS configuration's work (profiles/algo_work.json) instead of the family's FoV-360 constants."""
+    aw = algo_work(work_key) if work_key else None
+    gf = aw[0] if aw else GFLOP_PER_PAIR.get(kind)
+    mb32 = aw[1] if aw else MB_PER_PAIR_FP32.get(kind)
     if gf is None or not ms_step:
         return None
     mult = 3.0 if train else 1.0
     step_tf = mult * gf * batch / ms_step          # GFLOP / ms = TFLOP/s
     ws = {"algorithmic_tflop_per_step": round(mult * gf * batch / 1e3, 3), "achieved_tflops": round(step_tf, 2)}
     if precision == "bf16":
-        step_gbs = MB_PER_PAIR_FP32[kind] / 2 * batch / ms_step        # MB / ms = GB/s
-        ws.update(bound="hbm", algorithmic_gb_per_step=round(MB_PER_PAIR_FP32[kind] / 2 * batch / 1e3, 2),
+        step_gbs = mb32 / 2 * batch / ms_step        # MB / ms = GB/s
+        ws.update(bound="hbm", algorithmic_gb_per_step=round(mb32 / 2 * batch / 1e3, 2),
                   achieved_GBps=round(step_gbs, 1), frac=round(step_gbs / HBM_PEAK_GBS, 4),
                   mfma_bf16_frac=round(step_tf / BF16_MATRIX_PEAK_TFLOPS, 4))
     else:
@@ -183,11 +210,13 @@ def whole_step_roof(precision, batch, kind, ms_step, train=False):
     return ws
 
 
-def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False):
+def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False, work_key=None):
     """summ: ops.LaunchRecorder.summary() (None / empty for a hipGraph replay: events cannot be recorded inside one — the
     roofline then prices the whole step only).  Dominant kernel = the largest total time among the recorded dense launches.
     Returns (roofline dict, per-kernel table or None)."""
-    ws = whole_step_roof(precision, batch, kind, ms_step, train)
+    ws = whole_step_roof(precision, batch, kind, ms_step, train, work_key)
+    if ws is not None and work_key:
+        ws["work"] = work_key
     if not summ:
         if ws is None:
             return None, None
@@ -253,38 +282,36 @@ LEG_KEY = {"fwd_bwd_vigor_b64": "fwd_bwd_vigor_b64", "C2_bf16": "c2_bf16", "C1_b
 
 
 def compact(tag, entry):
-    """Driver-visible summary of a side measurement: FLAT scalar keys `<leg>_<field>` directly under `config` (the driver's
-    record keeps the scalars of `config` and drops nested objects)."""
+    """Driver-visible summary of a side measurement: FLAT scalar keys `<leg>_<field>` directly under `config`.  The driver's
+    record keeps the first 24 scalars of `config` and drops nested objects, so a leg gets exactly three — `_pairs_per_s`,
+    `_ms`, `_frac` (whole step against its governing roof, priced with the leg's own algorithmic work) — plus the CPU figure
+    of the fwd+bwd leg; everything else about the leg goes to stderr (`emit_leg_details`)."""
     k = LEG_KEY.get(tag, tag.lower())
     if "error" in entry:
         return {k + "_error": entry["error"][:300]}
-    out = {k + "_ms": entry["ms_per_step"], k + "_pairs_per_s": entry["value"], k + "_batch_per_gpu": entry.get("batch_per_gpu"),
-           k + "_dtype": entry.get("dtype")}
-    if entry.get("n_gpus", 1) != 1:
-        out[k + "_n_gpus"] = entry["n_gpus"]
-    r = entry.get("roofline") or {}
-    ws = r.get("whole_step") or {}
-    if ws:
-        out[k + "_bound"] = ws.get("bound")
-        out[k + "_frac"] = ws.get("frac")                   # whole step against the governing roof
-    if r.get("kernel"):
-        out[k + "_kernel"], out[k + "_kernel_frac"] = r["kernel"], r.get("frac")
+    out = {k + "_pairs_per_s": entry["value"], k + "_ms": entry["ms_per_step"]}
+    ws = (entry.get("roofline") or {}).get("whole_step") or {}
+    out[k + "_frac"] = ws.get("frac")
     cb = entry.get("cpu_baseline")
     if cb:
         out[k + "_cpu_pairs_per_s"] = round(cb["value"], 3)
-        out[k + "_cpu_cores"] = cb["cores"]
-        out[k + "_cpu_sample"] = cb["sample"]
-    for f, short in (("loss_after_last_step", "loss"), ("peak_hbm_gib", "peak_hbm_gib"), ("launch", "launch")):
-        if f in entry:
-            out[k + "_" + short] = entry[f]
     return out
 
 
+def emit_leg_details(tag, entry):
+    """Everything `compact` leaves out (batch, dtype, bound, dominant kernel and its fraction, CPU sample, loss, peak HBM,
+    launch mode) -> stderr as one JSON object, prefix "[bench leg]"."""
+    d = {k: v for k, v in entry.items() if k not in ("roofline",)}
+    r = entry.get("roofline") or {}
+    d["roofline"] = {k: v for k, v in r.items()}
+    print("[bench leg] " + json.dumps({LEG_KEY.get(tag, tag.lower()): d}), file=sys.stderr)
+    sys.stderr.flush()
+
+
 def flat_collective(coll):
-    return {"collective_backend": coll["backend"], "collective_world_size_env": coll["world_size_env"],
-            "collective_ranks": coll["ranks_counted_by_allreduce"],
-            "collective_calls_per_step": coll["allreduce_calls_per_step"], "collective_bytes_per_step": coll["bytes_per_step"],
-            "collective_op": coll["op"]}
+    """Four scalars (a data-parallel line has 4 + 4 legs x 3 + 1 + 4 = 21 scalar config keys)."""
+    return {"collective_ranks": coll["ranks_counted_by_allreduce"], "collective_calls_per_step": coll["allreduce_calls_per_step"],
+            "collective_bytes_per_step": coll["bytes_per_step"], "collective_backend": coll["backend"]}
 
 
 def per_layer_table(rec, steps):
@@ -383,7 +410,8 @@ def train_entry(net, kind, grd, sat, dev, batch, steps, warmup, rank, world, n_r
            "value": round(batch * world * steps / m["elapsed"], 2), "unit": "img-pairs/s", "n_gpus": world,
            "batch_per_gpu": batch, "ms_per_step": round(ms, 3), "steps": steps, "warmup": warmup, "dtype": "f32",
            "loss_after_last_step": round(m["loss"], 5), "peak_hbm_gib": round(m["peak_gib"], 2)}
-    roof, table = roofline_from(m["rec"].summary() if m["rec"] is not None else None, steps, "fp32", batch, kind, ms, train=True)
+    roof, table = roofline_from(m["rec"].summary() if m["rec"] is not None else None, steps, "fp32", batch, kind, ms, train=True,
+                                work_key="kitti" if kind == "kitti" else "vigor20")
     out["roofline"] = roof
     if rank == 0:
         emit_kernel_table(tag, table)
@@ -431,18 +459,88 @@ def launch_ranks(n, argv, script=None, timeout=None):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), script] + list(argv)
     print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd)), file=sys.stderr)
     sys.stderr.flush()
-    res = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True, timeout=timeout)
-    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
-    for l in res.stdout.splitlines():
+    # The launcher gets its own session (= process group): on a timeout or an interrupt the WHOLE group is killed — killing only
+    # torch.distributed.run would leave the GPU rank processes (its grandchildren) alive and holding the GPUs.  stdout goes to a
+    # temporary file, not a pipe: nothing is buffered in this process while the ranks run.
+    import signal
+    import tempfile
+    with tempfile.TemporaryFile(mode="w+") as out:
+        proc = subprocess.Popen(cmd, env=env, stdout=out, text=True, start_new_session=True)
+        try:
+            rc = proc.wait(timeout=timeout)
+        except (subprocess.TimeoutExpired, KeyboardInterrupt) as ex:
+            # torch.distributed.run starts every rank in a session of its OWN, so the launcher's process group does not contain
+            # them: collect the descendants first, ask the launcher to stop (its SIGTERM handler stops its workers), then kill
+            # whatever is still alive — launcher group and every rank by exact pid
+            ranks = _descendants(proc.pid)
+            try:
+                os.killpg(proc.pid, signal.SIGTERM)
+            except ProcessLookupError:
+                pass
+            try:
+                proc.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+            for pid in [proc.pid] + ranks:
+                for kill in (os.killpg, os.kill):
+                    try:
+                        kill(pid, signal.SIGKILL)
+                    except (ProcessLookupError, PermissionError):
+                        pass
+            proc.wait()
+            print("bench.py: %s: killed the launcher and its %d rank process(es)" % (type(ex).__name__, len(ranks)), file=sys.stderr)
+            return 124
+        out.seek(0)
+        stdout = out.read()
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    for l in stdout.splitlines():
         if not l.startswith("{"):
             print(l, file=sys.stderr)
     if lines:
         print(lines[-1])
         sys.stdout.flush()
-    if res.returncode == 0 and not lines:
+    if rc == 0 and not lines:
         print("bench.py: the ranks exited 0 without printing a line", file=sys.stderr)
         return 1
-    return res.returncode
+    return rc
+
+
+def _descendants(root):
+    """pids of every live descendant of `root` (from /proc: ppid chains), children before grandchildren."""
+    kids = {}
+    for d in os.listdir("/proc"):
+        if d.isdigit():
+            try:
+                with open("/proc/%s/stat" % d) as f:
+                    ppid = int(f.read().rsplit(")", 1)[1].split()[1])
+            except (OSError, ValueError, IndexError):
+                continue
+            kids.setdefault(ppid, []).append(int(d))
+    out, todo = [], [root]
+    while todo:
+        for k in kids.get(todo.pop(0), []):
+            out.append(k)
+            todo.append(k)
+    return out
+
+
+def _count_gpus_without_hip():
+    """GPUs of this node WITHOUT loading the HIP runtime in this (parent) process: the KFD topology lists one node per agent,
+    GPUs are the nodes with SIMDs.  None if the topology is not readable (then the ranks themselves will fail loudly)."""
+    if os.environ.get("CCVPE_BENCH_FAKE_GPUS"):                 # tests only (CPU boxes have no KFD topology)
+        return int(os.environ["CCVPE_BENCH_FAKE_GPUS"])
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for d in os.listdir(top):
+            with open(os.path.join(top, d, "properties")) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError):
+        return None
 
 
 def check_world(args, world):
@@ -456,10 +554,9 @@ def check_world(args, world):
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and "RANK" not in os.environ and args.gpus > 1:
-        # nothing in this process has touched the GPU yet (device_count() does not create a context)
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus:
+        # nothing in this process touches the GPU (not even the HIP runtime is loaded: the GPUs are counted from sysfs)
+        have = _count_gpus_without_hip()
+        if have is not None and have < args.gpus:
             print("bench.py: --gpus %d but this node shows %d GPU(s)" % (args.gpus, have), file=sys.stderr)
             sys.exit(2)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
@@ -576,17 +673,18 @@ def main():
                                     "oxford": "CVM_OxfordRobotCar eval forward (SURVEY 8(f)-3), grd 3x154x231 + sat "
                                               "3x512x512, N_rot=20"}[args.model],
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
-                       "parallelism": "replicas x%d (no data-path collective)" % world,
-                       "launch": "hipGraph replay" if args.graph else "eager (one C-ABI call per kernel)",
-                       "weights": "seeded random init, reference state_dict layout"},
+                       "parallelism": "replicas x%d (no data-path collective)" % world},
         }
+        # (the driver's record keeps 24 scalars of `config`: launch mode and weights join the workload text)
+        line["config"]["workload"] += "; %s; seeded random-init weights in the reference state_dict layout" % (
+            "hipGraph replay" if args.graph else "eager launches (one C-ABI call per kernel)")
         if args.model == "oxford" and args.batch == 1 and world == 1:
             # the reference's only published rate for this path family: "14 FPS" per-frame pose estimation with the Oxford
             # RobotCar variant, hardware not stated (/root/reference/README.md:21)
             line["vs_baseline"] = round(value / 14.0, 2)
             line["config"]["baseline"] = "14 FPS per frame (reference README, hardware not stated)"
         line["roofline"], table = roofline_from(rec.summary() if rec is not None else None, args.steps, args.precision,
-                                                args.batch, kind, ms_step)
+                                                args.batch, kind, ms_step, work_key=WORK_KEY.get(args.model))
         emit_kernel_table("headline", table)
         if rec is not None and args.per_layer:
             per_layer_table(rec, args.steps)
@@ -654,7 +752,9 @@ def main():
                 if record and not graph:
                     _, r2 = forward_measure(f2, g2, s2, dev, 3, 1, True)
                 if rank == 0:
-                    roof, table = roofline_from(r2.summary() if r2 is not None else None, 3, "bf16", b2, "vigor", 1e3 * e2 / ns2)
+                    roof, table = roofline_from(r2.summary() if r2 is not None else None, 3, "bf16", b2, "vigor", 1e3 * e2 / ns2,
+                                                work_key={"C2_bf16": "vigor20", "C1_bf16": "vigor_prior0",
+                                                          "C4_bf16_graph_b256": "vigor_prior180_fov180"}[tag])
                     emit_kernel_table(tag, table)
                     legs[tag] = {"workload": what, "value": round(b2 * world * ns2 / e2, 2), "n_gpus": world, "batch_per_gpu": b2,
                                  "ms_per_step": round(1e3 * e2 / ns2, 3), "steps": ns2, "dtype": "bf16", "roofline": roof,
@@ -694,8 +794,20 @@ def main():
             if rank == 0 and coll is not None:
                 line["config"].update(flat_collective(coll))
         if rank == 0:
-            for tag, ent in legs.items():
-                line["config"].update(compact(tag, ent))
+            # order = the order the driver's 24 config scalars are spent in: BASELINE's literal metric first, then the bf16 legs,
+            # then (N > 1) the data-parallel step and what the collective layer did
+            coll_flat = {k: line["config"].pop(k) for k in list(line["config"]) if k.startswith("collective_")}
+            for tag in ("fwd_bwd_vigor_b64", "C1_bf16", "C2_bf16", "C4_bf16_graph_b256", "train_dp_kitti_b64"):
+                if tag in legs:
+                    line["config"].update(compact(tag, legs[tag]))
+                    emit_leg_details(tag, legs[tag])
+            line["config"].update(coll_flat)
+            # the literal BASELINE metric's dominant kernel, flat, beside the headline's roofline (nested objects are dropped)
+            fb = (legs.get("fwd_bwd_vigor_b64") or {}).get("roofline") or {}
+            if fb.get("kernel"):
+                line["roofline"].update({"fwd_bwd_kernel": fb["kernel"], "fwd_bwd_kernel_achieved": fb.get("achieved"),
+                                         "fwd_bwd_kernel_frac": fb.get("frac"), "fwd_bwd_kernel_avg_launch_ms": fb.get("avg_launch_ms"),
+                                         "fwd_bwd_kernel_traffic": fb.get("traffic")})
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()

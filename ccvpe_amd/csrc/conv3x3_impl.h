@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wreg_kernel(const IgemmParams 
     if (px < HPX) {
       const int hy = px / HC, hx = px - hy * HC;
       const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-      h_off[it] = (hy * HCP + hx) * HLD + (HSW ? (sub ^ (((hx >> 2) & 1) << 1)) : sub) * 4;
+      h_off[it] = px * LDS_LD + sub * 4;         // this experiment keeps the round-3 halo layout: [HPX][LDS_LD], no swizzle
       h_pix[it] = ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) ? (b * p.H + iy) * p.W + ix : -1;
     } else {
       h_off[it] = -1;

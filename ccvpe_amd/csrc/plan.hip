@@ -89,13 +89,13 @@ struct Reader {
   bool ok = true;
   template <typename T> T get() {
     T v{};
-    if (p + sizeof(T) > end) { ok = false; return v; }
+    if (sizeof(T) > (size_t)(end - p)) { ok = false; return v; }
     std::memcpy(&v, p, sizeof(T));
     p += sizeof(T);
     return v;
   }
   const unsigned char* bytes(size_t n) {
-    if (p + n > end) { ok = false; return nullptr; }
+    if (n > (size_t)(end - p)) { ok = false; return nullptr; }
     const unsigned char* q = p;
     p += n;
     return q;
@@ -129,7 +129,7 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
     o.off = r.get<uint64_t>(); o.bytes = r.get<uint64_t>(); o.dtype = r.get<uint32_t>(); o.ndim = r.get<uint32_t>();
     for (int k = 0; k < 4; ++k) o.dims[k] = (long long)r.get<uint64_t>();
     for (int k = 0; k < 4; ++k) o.strides[k] = (long long)r.get<uint64_t>();
-    if (o.off + o.bytes > c->workspace_bytes) return bail(CCVPE_EINVAL, "output outside the workspace");
+    if (o.off > c->workspace_bytes || o.bytes > c->workspace_bytes - o.off) return bail(CCVPE_EINVAL, "output outside the workspace");   // (no uint64 wrap)
     c->outputs.push_back(o);
   }
   struct Reloc { uint32_t blob, field, kind; uint64_t value; };
@@ -138,7 +138,7 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
     const uint32_t nb = r.get<uint32_t>(), nr = r.get<uint32_t>();
     for (uint32_t k = 0; k < nr; ++k) {
       Reloc q{i, r.get<uint32_t>(), r.get<uint32_t>(), r.get<uint64_t>()};
-      if (q.field + 8 > nb) return bail(CCVPE_EINVAL, "relocation outside its blob");
+      if ((uint64_t)q.field + 8 > (uint64_t)nb) return bail(CCVPE_EINVAL, "relocation outside its blob");       // 64-bit: field = 0xFFFFFFFC must not wrap
       relocs.push_back(q);
     }
     const unsigned char* d = r.bytes((nb + 7) & ~7u);
@@ -177,7 +177,7 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
   // the weights blob: 256-byte aligned from the start of the plan
   size_t woff = (size_t)(r.p - reinterpret_cast<const unsigned char*>(plan));
   woff = (woff + 255) & ~(size_t)255;
-  if (woff + c->weights_bytes > (size_t)n_bytes) return bail(CCVPE_EINVAL, "truncated weights");
+  if (woff > (size_t)n_bytes || c->weights_bytes > (uint64_t)((size_t)n_bytes - woff)) return bail(CCVPE_EINVAL, "truncated weights");
   // device memory: the caller's (torch-owned in the Python binding) or the library's own
   if (weights_dev) c->weights = reinterpret_cast<char*>(weights_dev);
   else {
@@ -203,11 +203,11 @@ extern "C" int ccvpe_ctx_create(const void* plan, long long n_bytes, void* weigh
     switch (kind) {
       case K_INT: case K_FLT: return v;
       case K_NULL: return 0;
-      case K_WEIGHTS: bad = v > c->weights_bytes; return (uint64_t)(uintptr_t)(c->weights + v);
-      case K_WORKSPACE: bad = v > c->workspace_bytes; return (uint64_t)(uintptr_t)(c->workspace + v);
+      case K_WEIGHTS: bad = v >= c->weights_bytes; return (uint64_t)(uintptr_t)(c->weights + v);
+      case K_WORKSPACE: bad = v >= c->workspace_bytes; return (uint64_t)(uintptr_t)(c->workspace + v);
       case K_BLOB: bad = v >= c->blobs.size(); return bad ? 0 : (uint64_t)(uintptr_t)c->blobs[v].data();
-      case K_GRD: bad = v > c->grd_bytes; dynamic = true; return 0;
-      case K_SAT: bad = v > c->sat_bytes; dynamic = true; return 0;
+      case K_GRD: bad = v >= c->grd_bytes; dynamic = true; return 0;
+      case K_SAT: bad = v >= c->sat_bytes; dynamic = true; return 0;
       case K_STREAM: dynamic = true; return 0;
       default: bad = true; return 0;
     }

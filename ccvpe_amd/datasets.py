@@ -11,7 +11,7 @@ the JPEG decode (PIL, like the reference; on a thread pool, PIL releases the GIL
 uint8 images (3-6 MB per pair) plus three scalars per sample to the device, where the rest runs as kernels.
 
     pairs = VIGORPairs(root, split="samearea", train=False, ori_noise=180, random_orientation="samearea_orientation_test.npy")
-    for batch in DeviceBatches(pairs, batch_size=64, device="cuda", rank=rank, world=world):
+    for batch in DeviceBatches(pairs, batch_size=64, device="cuda", rank=rank, world=world, shard="exact"):   # evaluation
         out = net(batch.grd, batch.sat)                     # batch.gt, batch.gt_flat, batch.gt_ori, batch.labels for training
 
 KITTI (datasets.py:354-640, train_KITTI.py:46-100): `KITTIPairs(root, file, ...)` reads the split file, the OXTS heading and
@@ -29,7 +29,7 @@ ascending_bins=True)`.
 
 Sharding: DeviceBatches gives rank r a contiguous shard of the index list (after the optional seeded shuffle, identical on
 every rank).  Evaluation (`shard="exact"`): harness.shard_indices — no sample is seen twice, no collective is needed, ranks
-may differ by one batch.  Training (`shard="pad"`, the default with targets and world > 1): every rank iterates the SAME
+may differ by one batch.  Training (`shard="pad"`, the default for a training split and world > 1): every rank iterates the SAME
 number of batches (short shards wrap around, as torch's DistributedSampler pads), because each step all-reduces gradients.
 A sample's random choices (`pairs.draw(i)`) are drawn in index order on the producer thread, decoding runs on the pool.
 """
@@ -352,6 +352,19 @@ def shard_positions(n, world, rank, mode="exact"):
     raise ValueError("shard must be 'exact', 'pad' or 'truncate'")
 
 
+def pairs_is_training(pairs):
+    """True / False when the index object says which split it holds (VIGORPairs.train, KITTIPairs.test, OxfordPairs.split),
+    None otherwise.  DeviceBatches keys its default shard mode on it: an EVALUATION set must never be padded (wrapped-around
+    samples would be counted twice in the gathered metrics), whatever `targets` is."""
+    if isinstance(getattr(pairs, "train", None), bool):
+        return pairs.train
+    if isinstance(getattr(pairs, "test", None), bool):
+        return not pairs.test
+    if isinstance(getattr(pairs, "split", None), str):
+        return pairs.split == "train"
+    return None
+
+
 class Batch(object):
     """One device batch: grd [B,3,h,w_fov], sat [B,3,H,W] (normalised fp32), angle_deg [B], center [B,2], cities, indices and —
     with targets — gt [B,1,H,W], gt_flat [B,H*W], gt_ori [B,2,H,W], labels (six max-pooled orientation-binned maps)."""
@@ -369,8 +382,9 @@ class DeviceBatches(object):
     "pad" = every rank gets ceil(n / world) samples, the short shards wrap around to the start of the index list
     (torch's DistributedSampler rule); "truncate" = every rank gets floor(n / world).  With "pad" / "truncate" len(self) is
     the same on every rank BY CONSTRUCTION — required for training, where each step all-reduces gradients inside the
-    backward and a rank with one batch more would wait for its peers until the RCCL timeout.  Default: "pad" when targets
-    are produced (training) and world > 1, else "exact"."""
+    backward and a rank with one batch more would wait for its peers until the RCCL timeout.  Default: "pad" for a TRAINING
+    split (`pairs_is_training`; an index object that does not say: when targets are produced) and world > 1, else "exact" —
+    a test split is never padded by default, with or without targets."""
 
     def __init__(self, pairs, batch_size, device="cuda", indices=None, shuffle=False, seed=0, rank=0, world=1, workers=8,
                  prefetch=2, grd_hw=(320, 640), sat_hw=(512, 512), fov=360, targets=True, n_bins=20, drop_last=False,
@@ -380,7 +394,10 @@ class DeviceBatches(object):
         if shuffle:
             idx = idx[np.random.default_rng(seed).permutation(len(idx))]      # same permutation on every rank
         if shard is None:
-            shard = "pad" if (targets and world > 1) else "exact"
+            training = pairs_is_training(pairs)
+            if training is None:                      # an index object that does not say: ground truth requested = training
+                training = bool(targets)
+            shard = "pad" if (training and world > 1) else "exact"
         self.shard = shard
         self.indices = idx[shard_positions(len(idx), world, rank, shard)]
         self.workers, self.prefetch = int(workers), int(prefetch)

@@ -71,8 +71,31 @@ class _Arena(object):
             del fr[lo]
 
 
+def _tensor_ranges(obj, out=None, seen=None):
+    """[start, end) byte ranges of every tensor reachable from `obj` (the packed-weights object of a model: nested plain
+    objects / dicts / lists / tuples of tensors)."""
+    out = [] if out is None else out
+    seen = set() if seen is None else seen
+    if id(obj) in seen:
+        return out
+    seen.add(id(obj))
+    if isinstance(obj, torch.Tensor):
+        if obj.is_cuda and obj.numel():
+            st = obj.untyped_storage()
+            out.append((st.data_ptr(), st.data_ptr() + st.nbytes()))
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _tensor_ranges(v, out, seen)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _tensor_ranges(v, out, seen)
+    elif hasattr(obj, "__dict__"):
+        _tensor_ranges(vars(obj), out, seen)
+    return out
+
+
 class _Recorder(object):
-    def __init__(self, device, arena_bytes, grd, sat, side_fraction=0.45):
+    def __init__(self, device, arena_bytes, grd, sat, side_fraction=0.45, constants=None):
         self.ws = torch.empty((arena_bytes,), dtype=torch.uint8, device=device)
         self.base = self.ws.data_ptr()
         # two regions: [0, split) for tensors allocated under the main stream, [split, size) for the side stream
@@ -83,6 +106,10 @@ class _Recorder(object):
         self.calls, self.blobs = [], []
         self.weights, self.weights_bytes = {}, 0         # data_ptr -> (offset, tensor)
         self.seen = {}                                   # data_ptr -> tensor, for every NON-workspace tensor handed to ops._ptr()
+        # byte ranges that may be frozen into the weights blob: the packed weights as they existed BEFORE the recording forward.
+        # Anything else outside the workspace / inputs is an input-dependent intermediate that bypassed ops._empty (torch.empty,
+        # torch.cat, .contiguous() inside the forward): freezing it would replay the recording inputs' values silently.
+        self.constants = sorted(constants) if constants is not None else None
         self.main = torch.cuda.current_stream().cuda_stream
         self.quarantine = []                             # (region, off, size): released under the other stream, free at the next join
         self.n_waits = 0
@@ -135,7 +162,25 @@ class _Recorder(object):
         tensor would keep its bytes from being handed out again."""
         p = t.data_ptr()
         if not (self.base <= p < self.base + self.size):
+            self._check_constant(p, t.numel() * t.element_size())
             self.seen[p] = t
+
+    def _is_input(self, addr):
+        for t in (self.grd, self.sat):
+            p = t.data_ptr()
+            if p <= addr < p + t.numel() * t.element_size():
+                return True
+        return False
+
+    def _check_constant(self, addr, nbytes=1):
+        if self.constants is None or self._is_input(addr):
+            return
+        import bisect
+        i = bisect.bisect_right(self.constants, (addr, float("inf"))) - 1
+        if i >= 0 and self.constants[i][0] <= addr and addr + max(nbytes, 1) <= self.constants[i][1]:
+            return
+        raise RuntimeError("plan: pointer 0x%x (%d bytes) is neither workspace, nor an input, nor part of the weights packed before "
+                           "recording: an intermediate allocated outside ops._empty would be frozen as a constant" % (addr, nbytes))
 
     def classify(self, addr):
         if addr is None or addr == 0:
@@ -149,6 +194,7 @@ class _Recorder(object):
         return K_WEIGHTS, self._weight_offset(addr)
 
     def _weight_offset(self, addr):
+        self._check_constant(addr)
         if addr in self.weights:
             return self.weights[addr][0]
         t = self.seen.get(addr)
@@ -300,11 +346,11 @@ def record(net, grd, sat, arena_bytes=None):
             net(grd, sat)
             torch.cuda.synchronize(dev)
             arena_bytes = int(1.5 * (torch.cuda.max_memory_allocated(dev) - before)) + (64 << 20)
-        net._packed()                                # the packed weights exist before recording starts
+        constants = _tensor_ranges([net._packed(), net])   # packed weights (+ tables cached on the model) exist BEFORE recording: nothing else may be frozen
     lib = _lib.load()
     saved = (ops._record, _lib.load, torch.cuda.Stream.wait_stream)
     for attempt in range(4):
-        rec = _Recorder(dev, arena_bytes, grd, sat)
+        rec = _Recorder(dev, arena_bytes, grd, sat, constants=constants)
         orig_wait = saved[2]
 
         def wait_stream(self, other, _rec=rec, _orig=orig_wait):

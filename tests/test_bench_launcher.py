@@ -30,16 +30,16 @@ sys.exit(3 if os.environ.get("CCVPE_STUB_FAIL") == "1" else 0)
 def _bench(tmp_path, argv, fake_gpus, extra_env=None):
     stub = tmp_path / "stub_rank.py"
     stub.write_text(STUB)
-    # the parent only counts devices; on this CPU box the count is faked through a sitecustomize-free hook: a tiny wrapper
-    # that patches torch.cuda.device_count before running bench.main()
+    # the parent only counts devices (from sysfs, without loading the HIP runtime); on this CPU box the count is faked
     wrapper = tmp_path / "run_bench.py"
-    wrapper.write_text("import sys, runpy, torch\n"
-                       "torch.cuda.device_count = lambda: %d\n"
+    wrapper.write_text("import sys, runpy\n"
                        "sys.argv = [%r] + sys.argv[1:]\n"
-                       "runpy.run_path(%r, run_name='__main__')\n" % (fake_gpus, os.path.join(ROOT, "bench.py"),
-                                                                      os.path.join(ROOT, "bench.py")))
+                       "runpy.run_path(%r, run_name='__main__')\n"
+                       "assert 'torch' not in sys.modules, 'the parent must not load torch / HIP'\n"
+                       % (os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "bench.py")))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
     env["CCVPE_BENCH_CHILD"] = str(stub)
+    env["CCVPE_BENCH_FAKE_GPUS"] = str(fake_gpus)          # the parent counts GPUs from sysfs (no HIP): faked here
     env.update(extra_env or {})
     return subprocess.run([sys.executable, str(wrapper)] + argv, capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
 
@@ -58,6 +58,39 @@ def test_child_failure_is_the_parents_exit_code_and_the_line_still_comes_through
     res = _bench(tmp_path, ["--gpus", "2", "--steps", "1", "--warmup", "0"], fake_gpus=2, extra_env={"CCVPE_STUB_FAIL": "1"})
     assert res.returncode != 0
     assert json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])["ranks"] == 2
+
+
+def test_eight_ranks_one_relayed_line(tmp_path):
+    """The SCALE driver's largest form, `--gpus 8`, through the launcher path on CPU (gloo): ONE line on stdout, the all-reduce
+    counts 8 ranks, and the whole thing is over in bounded time."""
+    import time
+    t0 = time.time()
+    res = _bench(tmp_path, ["--gpus", "8", "--steps", "3", "--warmup", "1"], fake_gpus=8, extra_env={"OMP_NUM_THREADS": "1"})
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-3000:]
+    out = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(out) == 1
+    assert json.loads(out[0]) == {"metric": "stub", "n_gpus": 8, "ranks": 8, "gpus_arg": 8, "steps": 3, "warmup": 1}
+    assert res.stderr.count("noise from rank") == 8
+    assert time.time() - t0 < 240
+
+
+def test_timeout_kills_the_whole_rank_group(tmp_path):
+    """A hung rank must not outlive the parent's timeout: the launcher runs in its own process group and the group is killed
+    (killing torch.distributed.run alone would leave the rank processes holding their GPUs)."""
+    import time
+    import bench
+    marker = tmp_path / "pids"
+    hang = tmp_path / "hang_rank.py"
+    hang.write_text("import os, time\nopen(%r, 'a').write('%%d\\n' %% os.getpid())\ntime.sleep(600)\n" % str(marker))
+    t0 = time.time()
+    rc = bench.launch_ranks(2, ["--gpus", "2"], script=str(hang), timeout=20)
+    assert rc == 124 and time.time() - t0 < 60
+    time.sleep(1.0)
+    pids = [int(x) for x in marker.read_text().split()]
+    assert len(pids) == 2
+    for pid in pids:
+        alive = os.path.exists("/proc/%d" % pid) and "Z" not in open("/proc/%d/stat" % pid).read().split()[2]
+        assert not alive, "rank process %d survived the timeout" % pid
 
 
 def test_more_gpus_than_the_node_has_is_refused(tmp_path):
@@ -84,5 +117,24 @@ def test_side_legs_are_flat_scalars():
     assert flat["fwd_bwd_vigor_b64_ms"] == 171.5 and flat["fwd_bwd_vigor_b64_pairs_per_s"] == 373.2
     assert flat["fwd_bwd_vigor_b64_frac"] == 0.4 and flat["fwd_bwd_vigor_b64_cpu_pairs_per_s"] == 0.69
     assert all(not isinstance(v, (dict, list)) for v in flat.values())
+    assert set(flat) == {"fwd_bwd_vigor_b64_pairs_per_s", "fwd_bwd_vigor_b64_ms", "fwd_bwd_vigor_b64_frac", "fwd_bwd_vigor_b64_cpu_pairs_per_s"}
     assert set(bench.compact("C2_bf16", {"error": "x"})) == {"c2_bf16_error"}
-    assert "c4_graph_b256_ms" in bench.compact("C4_bf16_graph_b256", dict(ent, launch="hipGraph replay"))
+    c4 = bench.compact("C4_bf16_graph_b256", dict(ent, launch="hipGraph replay", cpu_baseline=None))
+    assert set(c4) == {"c4_graph_b256_pairs_per_s", "c4_graph_b256_ms", "c4_graph_b256_frac"}
+    # a data-parallel line: 4 descriptive keys + 3 + 1 (fwd+bwd) + 3 x 3 (bf16 legs) + 3 (dp) + 4 (collective) = 24 scalars
+    assert 4 + len(flat) + 3 * len(c4) + 3 + len(bench.flat_collective(
+        {"ranks_counted_by_allreduce": 8, "allreduce_calls_per_step": 3.0, "bytes_per_step": 1, "backend": "nccl (RCCL)"})) <= 24
+
+
+def test_per_configuration_work_prices_fov180_below_fov360():
+    """C4 (ground 320 x 320) must not be priced with the FoV-360 bytes (profiles/algo_work.json, tools/algo_work.py)."""
+    import bench
+    g360, mb360 = bench.algo_work("vigor20")
+    g180, mb180 = bench.algo_work("vigor_prior180_fov180")
+    assert abs(g360 - 56.37) < 0.01 and abs(mb360 - 888.0) < 0.5            # BASELINE.md section 3 stays the yardstick
+    assert 0.80 < mb180 / mb360 < 0.92 and 54.0 < g180 < 55.5
+    gk, mbk = bench.algo_work("kitti")
+    assert abs(gk - 54.45) < 0.01 and abs(mbk - 944.0) < 0.5
+    ws360 = bench.whole_step_roof("bf16", 256, "vigor", 44.0, work_key="vigor20")
+    ws180 = bench.whole_step_roof("bf16", 256, "vigor", 44.0, work_key="vigor_prior180_fov180")
+    assert ws180["frac"] < ws360["frac"] and ws180["bound"] == "hbm"

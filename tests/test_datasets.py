@@ -188,6 +188,17 @@ def test_training_shards_run_the_same_number_of_batches_on_every_rank():
     assert [it.shard for it in ev] == ["exact", "exact"] and [len(it) for it in ev] == [2, 1]
     assert sorted(np.concatenate([it.indices for it in ev]).tolist()) == list(range(129))
     assert DS.DeviceBatches(Fake(7), 2, device="cpu", fov=70).keep_w == int(640 * 70 / 360)     # train_VIGOR.py:177
+    # the default follows the SPLIT, not `targets`: a test split with ground truth (validation loss) is still never padded
+    class FakeSplit(Fake):
+        def __init__(self, n, **kw):
+            Fake.__init__(self, n)
+            self.__dict__.update(kw)
+    for kw, want in ((dict(train=False), "exact"), (dict(train=True), "pad"), (dict(test=True), "exact"), (dict(test=False), "pad"),
+                     (dict(split="val"), "exact"), (dict(split="train"), "pad")):
+        its = [DS.DeviceBatches(FakeSplit(129, **kw), 64, device="cpu", rank=r, world=2, targets=True) for r in range(2)]
+        assert [it.shard for it in its] == [want, want], kw
+        if want == "exact":
+            assert sorted(np.concatenate([it.indices for it in its]).tolist()) == list(range(129))     # no sample twice
 
 
 def test_seeded_draws_do_not_depend_on_the_decode_threads(tmp_path):

@@ -77,3 +77,20 @@ def test_product_library_reads_no_environment_switches():
                 depth = 0                     # the product branch of an #ifdef CCVPE_ABLATE / #else pair
             code = line.split("//")[0]
             assert depth or "getenv(" not in code, "%s:%d reads the environment in the product build" % (os.path.basename(path), n)
+
+
+def test_diagnostics_build_still_compiles():
+    """`make EXTRA=-DCCVPE_ABLATE` (tools/gpu/ablate_*.sh) compiles code the product build never sees: the experiment kernels and
+    their switches.  A syntax-only pass over the translation units that carry `#ifdef CCVPE_ABLATE` blocks keeps an edit of
+    the shared kernel code from breaking them unnoticed (~2 s per file, no code generation)."""
+    import subprocess
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    units = [p for p in sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+             if "CCVPE_ABLATE" in open(p).read()
+             or any("CCVPE_ABLATE" in open(os.path.join(CSRC, h)).read()
+                    for h in re.findall(r'#include "(\w+\.h)"', open(p).read()) if os.path.isfile(os.path.join(CSRC, h)))]
+    assert any(os.path.basename(u).startswith("conv3x3_") for u in units) and len(units) >= 3
+    for u in units:
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-DCCVPE_ABLATE", "-fsyntax-only", u],
+                           capture_output=True, text=True, cwd=CSRC)
+        assert r.returncode == 0, "%s does not compile with -DCCVPE_ABLATE:\n%s" % (os.path.basename(u), r.stderr[-2000:])

@@ -35,6 +35,34 @@ def test_ctx_create_rejects_foreign_bytes():
     assert lib.ccvpe_ctx_destroy(None) == 0
 
 
+def test_ctx_create_bounds_arithmetic_does_not_wrap():
+    """A plan FILE is untrusted bytes (tools/plan_run.cpp): a relocation field of 0xFFFFFFFC, an output whose off + bytes
+    wraps around 2^64 and a weights size beyond the file must be rejected by the parser — all before any device call."""
+    import struct
+    lib = _lib.load()
+    abi = lib.ccvpe_abi_version()
+
+    def plan_bytes(outputs=b"", n_out=0, blobs=b"", n_blobs=0, weights_bytes=0, ws=4096):
+        head = b"CCVPLAN1" + struct.pack("<II", abi, 0) + struct.pack("<QQQQ", ws, weights_bytes, 64, 64)
+        head += struct.pack("<IIII", 0, n_blobs, n_out, 0) + outputs + blobs
+        return head + b"\0" * ((-len(head)) % 256) + b"\0" * 256
+
+    def create(data):
+        ctx = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(data, len(data))
+        rc = lib.ccvpe_ctx_create(ctypes.cast(buf, ctypes.c_void_p), len(data), None, None, ctypes.byref(ctx))
+        return rc, lib.ccvpe_last_error()
+
+    reloc = struct.pack("<II", 16, 1) + struct.pack("<IIQ", 0xFFFFFFFC, plan.K_WORKSPACE, 0) + b"\0" * 16
+    rc, err = create(plan_bytes(blobs=reloc, n_blobs=1))
+    assert rc != 0 and b"relocation outside its blob" in err
+    out = struct.pack("<QQII4Q4Q", 2 ** 64 - 8, 16, 0, 1, 4, 1, 1, 1, 1, 0, 0, 0)
+    rc, err = create(plan_bytes(outputs=out, n_out=1))
+    assert rc != 0 and b"output outside the workspace" in err
+    rc, err = create(plan_bytes(weights_bytes=2 ** 64 - 64))
+    assert rc != 0 and b"truncated weights" in err
+
+
 def test_plan_launch_list_matches_the_c_registry():
     """Every entry point plan.py may record is one csrc/plan.hip replays (and the other way round)."""
     import os
