@@ -76,10 +76,12 @@ PROTOTYPES = {
     "ccvpe_conv_igemm_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p]),
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
+    "ccvpe_set_narrow_kernels": (c_int, [c_int]),
     "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "ccvpe_upconv3x3_f32": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
     "ccvpe_upconv3x3_bf16": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),
+    "ccvpe_upconv3x3_route": (c_int, [ctypes.POINTER(UpconvDesc), c_int]),
     "ccvpe_stem_conv_f32": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "ccvpe_dwconv_nblk": (c_int, [c_int] * 4),
     "ccvpe_dwconv_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),

@@ -268,5 +268,12 @@ static int pick_cfg(int npad16) {
 // is a row of kCfgs; the functions return CCVPE_EINVAL for a tile they do not instantiate.
 template <typename T> int pw_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream);        // conv_pw_*.hip
 template <typename T> int conv3x3_dispatch(const IgemmParams& p, int batch, int mt, int nt, int wn, hipStream_t stream);   // conv3x3_*.hip
+// narrow_bf16.hip: bf16 3x3 layers with few channels on large images — weights resident in registers, persistent workgroups
+extern bool g_use_narrow;                                 // ccvpe_set_narrow_kernels (conv_igemm.hip)
+int c3n_supported(const IgemmParams& p, int batch);      // 0 = not served, else an instantiation id
+int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream);
+int up2_supported(int c0, int c1, int n, int kpad, int h1, int w1, int batch);
+int up2_dispatch(const void* src0, const void* src1, const void* w, const float* shift9, void* dst, int c0, int ld0, int c1, int ld1,
+                 int h1, int w1, int n, int kpad, int ldd, int act, int batch, hipStream_t stream);
 
 }  // namespace ccvpe

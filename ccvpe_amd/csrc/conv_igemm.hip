@@ -329,6 +329,13 @@ static const bool g_use_pw = !(getenv("CCVPE_PW_GEMM") && getenv("CCVPE_PW_GEMM"
 #else
 constexpr bool g_use_pw = true;
 #endif
+// CCVPE_NARROW=0 (any build: an A/B switch kept for the evidence runs) sends the narrow 3x3 layers back to conv3x3_kernel
+namespace ccvpe { bool g_use_narrow = true; }
+extern "C" int ccvpe_set_narrow_kernels(int on) {
+  const int prev = ccvpe::g_use_narrow ? 1 : 0;
+  ccvpe::g_use_narrow = on != 0;
+  return prev;
+}
 
 // route (optional): filled with the kernel family + tile the dispatcher picks for `d` (CCVPE_ROUTE_* | MT << 8 | NT << 12 |
 // WN << 16) and NOTHING is launched — ccvpe_conv_igemm_route(); tests and bench.py's launch recorder read it instead of
@@ -409,7 +416,8 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   if (route) {
     const bool pw_tile = 16 * c.nt * c.wn > 48;      // (the 256 x 80 tile is re-routed to 128 x 96 below)
     int mt = c.mt, nt = c.nt, wn = c.wn, fam = CCVPE_ROUTE_IGEMM;
-    if (is3x3) fam = CCVPE_ROUTE_CONV3X3;
+    if (is3x3 && sizeof(T) == 2 && g_use_narrow && c3n_supported(p, d->batch)) fam = CCVPE_ROUTE_C3N;
+    else if (is3x3) fam = CCVPE_ROUTE_CONV3X3;
     else if (is_pw && pw_tile) {
       fam = CCVPE_ROUTE_PW_GEMM;
       if (mt == 4 && nt == 5 && wn == 1) { nt = 3; wn = 2; }
@@ -418,6 +426,9 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     return CCVPE_OK;
   }
   if (!sk) {
+    if constexpr (sizeof(T) == 2) {
+      if (is3x3 && g_use_narrow && c3n_supported(p, d->batch)) return c3n_dispatch(p, d->batch, st);
+    }
     if (is3x3) return conv3x3_dispatch<T>(p, d->batch, c.mt, c.nt, c.wn, st);
     if (is_pw && 16 * c.nt * c.wn > 48) {
       if (c.mt == 4 && c.nt == 5 && c.wn == 1) return pw_dispatch<T>(p, 4, 3, 2, st);

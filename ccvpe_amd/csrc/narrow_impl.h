@@ -11,55 +11,159 @@
 //   * the weights of the layer — 12 k-steps x 3 column tiles x 4 registers = 144 VGPRs for 40 -> 40 — are loaded ONCE per
 //     workgroup into registers as MFMA operands (one wave per SIMD, up to 512 registers per lane) and stay there: no W traffic,
 //     no W panel barriers, LDS carries activations only;
-//   * workgroups are PERSISTENT (one per CU) and walk the tiles; the halo tile of the NEXT tile is requested by LDS-DMA
-//     (global_load_lds_dwordx4, lane-linear: the LDS image is [pixel][octet] in DMA piece order) at the start of a tile into the
-//     other of two buffers; pieces outside the image are zeroed by the lane that would have requested them;
-//   * one barrier per tile.
+//   * workgroups are PERSISTENT (one per CU) and walk the tiles; the halo tile of the tile after next is requested by LDS-DMA
+//     (global_load_lds_dwordx4, lane-linear: the LDS image is [pixel][octet] in DMA piece order) right after the barrier that
+//     frees its buffer, a whole tile of matrix work before it is needed; pieces outside the image are zeroed by the lane that
+//     would have requested them;
+//   * one barrier per tile, and the epilogue of a tile runs AFTER it: its stores are in flight under the next tile's matrix work
+//     (waited for at the barrier, they were the largest single cost of the first version);
+//   * the tile loop is BRANCH-FREE for interior tiles: output type and channel count are compile-time, tile coordinates come from
+//     multiply-shift divisions, the epilogue pairs column tiles through v_permlane32_swap so that a lane stores 16 bytes.  (First
+//     version, ablation build: with halo requests, stores, matrix instructions and fragment reads all removed the 40 -> 40 layer
+//     still took 114 of 286 us — ~1 000 instructions of per-element branches and integer divisions per tile.)
 #pragma once
 #include "conv_common.h"
 
 namespace ccvpe {
 
-struct NarrowParams {
-  const void* src;     // [B,H,W,ld] bf16, first 8*CPT channels used
-  const void* w;       // packed [Npad][Kpad] bf16, k = tap * (8 CPT) + channel (models._pack_conv)
-  const float* shift;  // bias [N] or nullptr
-  void* dst;           // [B,H,W,ldd] bf16 or fp32
-  int out_f32;
-  int H, W, ld, N, Kpad, ldd, act;
-  int tiles_x, tiles_y, tiles_total;
+// ---- exact unsigned division by a runtime constant: q = (n * m) >> 32 with m = ceil(2^32 / d), exact for n * d < 2^32 ---------
+struct FastDiv { unsigned d, m; };
+static inline FastDiv make_fastdiv(unsigned d) { return FastDiv{d, d > 1 ? (unsigned)((0x100000000ull + d - 1) / d) : 0u}; }
+__device__ __forceinline__ unsigned fd_div(unsigned n, FastDiv f) { return f.d > 1 ? __umulhi(n, f.m) : n; }
+
+struct TileIndex {                     // tile t (XCD-aware order) -> (sample, tile row, tile column)
+  FastDiv dx, dy;                      // tiles per row, tile rows per sample
+  int total, q8, r8;                   // xcd_tile(): total / 8, total % 8
 };
+static inline TileIndex make_tile_index(int tiles_x, int tiles_y, int total) {
+  return TileIndex{make_fastdiv((unsigned)tiles_x), make_fastdiv((unsigned)tiles_y), total, total / 8, total % 8};
+}
+__device__ __forceinline__ void tile_decode(const TileIndex& ti, int t, int& b, int& ty, int& tx) {
+  const int xcd = t & 7, loc = t >> 3;
+  const unsigned ts = (unsigned)((xcd < ti.r8 ? xcd * (ti.q8 + 1) : ti.r8 * (ti.q8 + 1) + (xcd - ti.r8) * ti.q8) + loc);
+  const unsigned r = fd_div(ts, ti.dx);
+  tx = (int)(ts - r * ti.dx.d);
+  const unsigned bb = fd_div(r, ti.dy);
+  ty = (int)(r - bb * ti.dy.d);
+  b = (int)bb;
+}
 
 // one LDS-DMA request of 64 x 16 bytes: lane l's 16 bytes from sbase + voff land at lds + 16 l (lds wave-uniform)
 __device__ __forceinline__ void dma16(unsigned lds, unsigned voff, const char* sbase) {
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 
+// Pixel pitch of a halo image in 16-byte slots: ODD (an even channel-octet count gets one unused slot per pixel).  The 16 lanes of
+// a fragment that read the same octet of 16 consecutive pixels then hit 16 different slots mod 16 for any window base, and the two
+// lane sets a ds_read_b128 group mixes ({0-3, 12-15} of one octet, {4-11} of another) are complementary halves of the 16 (measured
+// with the even pitch of 32 / 64 channels: 4- / 8-way conflicts, the kernel slower than the tiled one).
+constexpr int odd_pitch(int cpt) { return cpt | 1; }
+
+// Output channel of MFMA row rho = 4 q + r of column tile t.  NOT 16 t + rho: lane groups q and q ^ 2 (lanes 32 apart) hold
+// ADJACENT channel quads, so that one v_permlane32_swap per register gives a lane 8 consecutive channels = one 16-byte bf16 store.
+__device__ __forceinline__ int chan_of_row(int t, int rho) { return 16 * t + 8 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
+__device__ __forceinline__ int chan_of_quad(int t, int q) { return 16 * t + 8 * (q & 1) + 4 * (q >> 1); }
+
+#ifdef CCVPE_ABLATE
+#define CCVPE_NARROW_ABL(p) const int abl = (p).ablate
+static int narrow_ablate_env() { const char* e = getenv("CCVPE_NARROW_ABLATE"); return e ? atoi(e) : 0; }
+#else
+#define CCVPE_NARROW_ABL(p) constexpr int abl = 0
+static int narrow_ablate_env() { return 0; }
+#endif
+
+// Epilogue stores of one pixel row: acc[n] (this lane's quad of column tile n, bias / shift and activation already applied).
+// bf16: column tiles are paired through v_permlane32_swap — lanes q < 2 store 8 channels of the even tile, lanes q >= 2 8 channels
+// of the odd tile; an unpaired last tile is stored by the lanes q < 2.  fp32: one 16-byte store per quad.  N % 8 == 0.
+template <int NT, bool F32OUT>
+__device__ __forceinline__ void store_row(void* dst, size_t o, const f32x4* v, int q, int N) {
+  if constexpr (F32OUT) {
+    float* dp = reinterpret_cast<float*>(dst) + o;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const int ch = chan_of_quad(n, q);
+      if (ch < N) *reinterpret_cast<f32x4*>(dp + ch) = v[n];
+    }
+  } else {
+    bf16_t* dp = reinterpret_cast<bf16_t*>(dst) + o;
+#pragma unroll
+    for (int n = 0; n + 1 < NT; n += 2) {
+      // after the swaps: 8 consecutive channels (lo, hi) of tile n (q < 2) / n + 1 (q >= 2).  Plain float scalars on purpose:
+      // __builtin_bit_cast on an ELEMENT of an ext_vector_type compiled to code that used component 0 for every r
+      // (tools/micro/store_row_check.hip caught it; the same compiler defect as the masked-select note in DESIGN section 4)
+      float lo[4], hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float a = v[n][r], b = v[n + 1][r];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+        lo[r] = __uint_as_float(sw[0]);
+        hi[r] = __uint_as_float(sw[1]);
+      }
+      bf16x8 ob;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ob[r] = (bf16_t)lo[r]; ob[r + 4] = (bf16_t)hi[r]; }
+      const int ch = 16 * (n + (q >> 1)) + 8 * (q & 1);
+      if (ch < N) *reinterpret_cast<bf16x8*>(dp + ch) = ob;
+    }
+    if constexpr (NT & 1) {
+      constexpr int n = NT - 1;
+      float own[4], hi[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        own[r] = v[n][r];
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(own[r]), __float_as_uint(own[r]), false, false);
+        hi[r] = __uint_as_float(sw[1]);               // lanes q < 2: the partner's (q + 2) quad = channels + 4 .. + 7
+      }
+      bf16x8 ob;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { ob[r] = (bf16_t)own[r]; ob[r + 4] = (bf16_t)hi[r]; }
+      const int ch = 16 * n + 8 * (q & 1);
+      if (q < 2 && ch < N) *reinterpret_cast<bf16x8*>(dp + ch) = ob;
+    }
+  }
+}
+
+// =====================================================================================================================
+// c3n_kernel: 3x3 stride 1 pad 1 convolution, ONE source of 8 CPT channels, N <= 16 NT output channels (N % 8 == 0), bias +
+// optional ReLU.  Tile = (4 MT) rows x 16 columns; wave w owns rows w MT .. w MT + MT - 1.  Needs H % (4 MT) == 0, W % 16 == 0.
+// =====================================================================================================================
+struct NarrowParams {
+  const void* src;     // [B,H,W,ld] bf16, first 8*CPT channels used
+  const void* w;       // packed [Npad][Kpad] bf16, k = tap * (8 CPT) + channel (models._pack_conv)
+  const float* shift;  // bias [N] or nullptr
+  void* dst;           // [B,H,W,ldd] bf16 or fp32
+  int H, W, ld, N, Kpad, ldd;
+  float act_floor;     // 0 for ReLU, -inf for none: v = max(v, act_floor)
+  TileIndex ti;
+  int ablate;          // diagnostics builds only (-DCCVPE_ABLATE, tools/gpu/ablate_narrow.sh): 1 = no halo requests after the first two tiles,
+                       // 2 = no epilogue stores, 4 = no matrix instructions, 8 = no fragment reads, 16 = no barrier / DMA wait
+};
+
 template <int CPT, int NT, int MT>
 struct C3nGeom {
   static constexpr int TH = 4 * MT, HR = TH + 2, HC = 18;
-  static constexpr int PIECES = HR * HC * CPT;                 // 16-byte pieces of a halo tile
+  static constexpr int PP = odd_pitch(CPT);                    // slots per pixel
+  static constexpr int PIECES = HR * HC * PP;                  // 16-byte slots of a halo tile (DMA piece order)
   static constexpr int NDMA = (PIECES + 255) / 256;            // requests per thread per tile
   static constexpr int BUF_BYTES = NDMA * 256 * 16;
   static constexpr int LDS_BYTES = 2 * BUF_BYTES;
   static constexpr int NCH = (9 * CPT + 3) / 4;                // 32-wide k-steps
 };
 
-// 3x3 stride 1 pad 1 convolution, ONE source of 8 CPT channels, N <= 16 NT output channels, bias + optional ReLU.
-// Tile = (4 MT) rows x 16 columns; wave w owns rows w MT .. w MT + MT - 1.  Needs H % (4 MT) == 0, W % 16 == 0.
-template <int CPT, int NT, int MT>
+template <int CPT, int NT, int MT, bool F32OUT>
 __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   using G = C3nGeom<CPT, NT, MT>;
-  constexpr int HC = G::HC, NCH = G::NCH, NDMA = G::NDMA;
-  constexpr int XP = CPT * 16;                                  // pixel pitch in the halo image (bytes)
+  constexpr int HC = G::HC, NCH = G::NCH, NDMA = G::NDMA, PP = G::PP;
+  constexpr int XP = PP * 16;                                   // pixel pitch in the halo image (bytes)
   extern __shared__ __attribute__((aligned(16))) char nsm[];
+  CCVPE_NARROW_ABL(p);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = sgpr(tid >> 6);
   const int f = lane & 15, q = lane >> 4;
 
-  // ---- the layer's weights: MFMA "A" operands (rows = output channels), resident for the whole kernel -------------------
+  // ---- the layer's weights: MFMA "A" operands (rows = output channels, permuted: chan_of_row), resident for the whole kernel ---
   f32x4 wreg[NCH][NT];
   {
     const bf16_t* wp = reinterpret_cast<const bf16_t*>(p.w);
@@ -67,8 +171,16 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        wreg[j][t] = *reinterpret_cast<const f32x4*>(wp + (size_t)(16 * t + f) * p.Kpad + 32 * j + 8 * q);
+        wreg[j][t] = *reinterpret_cast<const f32x4*>(wp + (size_t)chan_of_row(t, f) * p.Kpad + 32 * j + 8 * q);
   }
+  f32x4 bias[NT];                                               // this lane's quads (no loads inside the tile loop)
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ch = chan_of_quad(n, q) + r;
+      bias[n][r] = (p.shift && ch < p.N) ? p.shift[ch] : 0.f;
+    }
 
   // ---- per-lane halo offsets of the pixel fragments: k-step j, lane group q -> octet 4 j + q = (tap, channel octet) ------
   int aoff[NCH];
@@ -82,55 +194,51 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   }
   const bool tail_ok = 4 * (NCH - 1) + q < 9 * CPT;            // the last k-step may end in octets that do not exist (W is zero there)
 
-  // ---- DMA pieces of this thread (tile-invariant): piece -> (halo pixel, octet) ---------------------------------------------
+  // ---- DMA pieces of this thread (tile-invariant): piece -> (halo pixel, octet).  The pad slot of an even octet count re-fetches
+  // octet 0 (never read): every lane of a request takes part, no exec masking in the interior path -------------------------------
   unsigned voff[NDMA];
   int hyx[NDMA];
 #pragma unroll
   for (int k = 0; k < NDMA; ++k) {
-    const int pidx = k * 256 + tid;
-    if (pidx < G::PIECES) {
-      const int pix = pidx / CPT, oct = pidx - pix * CPT;
-      const int hy = pix / HC, hx = pix - hy * HC;
-      voff[k] = (unsigned)(((hy * p.W + hx) * p.ld + oct * 8) * 2);
-      hyx[k] = (hy << 8) | hx;
-    } else {
-      voff[k] = 0;
-      hyx[k] = -1;
-    }
+    const int pidx = min(k * 256 + tid, G::PIECES - 1);
+    const int pix = pidx / PP, oct = pidx - pix * PP;
+    const int hy = pix / HC, hx = pix - hy * HC;
+    voff[k] = (unsigned)(((hy * p.W + hx) * p.ld + (oct < CPT ? oct : 0) * 8) * 2);
+    hyx[k] = (hy << 8) | hx;
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)nsm;
   const int Hs = sgpr(p.H), Ws = sgpr(p.W), lds_ = sgpr(p.ld);
 
-  auto tile_xy = [&](int t, int& b, int& y0, int& x0) {
-    const int ts = xcd_tile(t, p.tiles_total);
-    const int tx = ts % p.tiles_x;
-    const int r = ts / p.tiles_x;
-    const int ty = r % p.tiles_y;
-    b = r / p.tiles_y;
-    y0 = ty * G::TH;
-    x0 = tx * 16;
-  };
   auto stage = [&](int t, int buf) {                         // request tile t's halo into buffer `buf`
-    int b, y0, x0;
-    tile_xy(t, b, y0, x0);
+    int b, ty, tx;
+    tile_decode(p.ti, t, b, ty, tx);
+    const int y0 = ty * G::TH, x0 = tx * 16;
     const char* sbase = reinterpret_cast<const char*>(p.src) + ((long)(b * Hs + y0 - 1) * Ws + (x0 - 1)) * (long)(lds_ * 2);
+    const bool interior = y0 > 0 && y0 + G::TH < Hs && x0 > 0 && x0 + 16 < Ws;        // wave-uniform
+    if (interior) {
 #pragma unroll
-    for (int k = 0; k < NDMA; ++k) {
-      if (hyx[k] >= 0) {
-        const int iy = y0 - 1 + (hyx[k] >> 8), ix = x0 - 1 + (hyx[k] & 255);
-        const bool ok = (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
+      for (int k = 0; k < NDMA; ++k) {
         const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + (k * 256 + wave * 64) * 16));
-        if (ok) dma16(ldsw, voff[k], sbase);
-        else *reinterpret_cast<f32x4*>(nsm + buf * G::BUF_BYTES + (k * 256 + tid) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if ((k + 1) * 256 <= G::PIECES || k * 256 + tid < G::PIECES) dma16(ldsw, voff[k], sbase);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDMA; ++k) {
+        if ((k + 1) * 256 <= G::PIECES || k * 256 + tid < G::PIECES) {
+          const int iy = y0 - 1 + (hyx[k] >> 8), ix = x0 - 1 + (hyx[k] & 255);
+          const bool ok = (unsigned)iy < (unsigned)Hs && (unsigned)ix < (unsigned)Ws;
+          const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + (k * 256 + wave * 64) * 16));
+          if (ok) dma16(ldsw, voff[k], sbase);
+          else *reinterpret_cast<f32x4*>(nsm + buf * G::BUF_BYTES + (k * 256 + tid) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
       }
     }
   };
 
-  const int en = q * 4;
-  auto compute = [&](auto buf_tag, int t) {
+  f32x4 acc[MT][NT];
+  auto compute = [&](auto buf_tag) {
     constexpr int BUF = decltype(buf_tag)::value;
     const char* hb = nsm + BUF * G::BUF_BYTES;
-    f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -141,7 +249,7 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
       const int cur = j & 1;
-      if (j + 1 < NCH) {
+      if (j + 1 < NCH && !(abl & 8)) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[cur ^ 1][i] = *reinterpret_cast<const f32x4*>(hb + aoff[j + 1] + i * (HC * XP));
       }
@@ -150,97 +258,363 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) a[cur][i] = keep_if(a[cur][i], tail_ok);
       }
+      if (!(abl & 4)) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int n = 0; n < NT; ++n) acc[i][n] = mfma_stage<bf16_t>(wreg[j][n], a[cur][i], acc[i][n]);
+          for (int n = 0; n < NT; ++n) acc[i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[i][n]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    // ---- epilogue: lane = pixel column f of row i, channels 16 n + 4 q .. + 3 ---------------------------------------------
-    int b, y0, x0;
-    tile_xy(t, b, y0, x0);
-    const size_t pix0 = ((size_t)(b * Hs + y0 + wave * MT) * Ws + x0 + f);
+  };
+  // ---- epilogue: lane = pixel column f of row i.  Runs AFTER the tile's closing barrier and the next halo request: its stores are
+  // in flight under the next tile's matrix work instead of being waited for at the barrier -----------------------------------------
+  auto epilogue = [&](int t) {
+    int b, ty, tx;
+    tile_decode(p.ti, t, b, ty, tx);
+    const size_t pix0 = ((size_t)(b * Hs + ty * G::TH + wave * MT) * Ws + tx * 16 + f);
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const int ch = 16 * n + en;
-      if (ch >= p.N) continue;
-      f32x4 sh = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (p.shift) {
+    for (int i = 0; i < MT; ++i) {
+      f32x4 v[NT];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sh[r] = ch + r < p.N ? p.shift[ch + r] : 0.f;
+      for (int n = 0; n < NT; ++n) {
+        v[n] = acc[i][n] + bias[n];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
       }
+      if (abl & 2) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        f32x4 v = acc[i][n] + sh;
-        if (p.act == CCVPE_ACT_RELU) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
-        }
-        const size_t o = (pix0 + (size_t)i * Ws) * p.ldd + ch;
-        if (ch + 3 < p.N) {
-          if (p.out_f32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.dst) + o) = v;
-          else {
-            bf16x4 ob;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) ob[r] = (bf16_t)v[r];
-            *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.dst) + o) = ob;
-          }
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; ++r)
-            if (ch + r < p.N) {
-              if (p.out_f32) reinterpret_cast<float*>(p.dst)[o + r] = v[r];
-              else reinterpret_cast<bf16_t*>(p.dst)[o + r] = (bf16_t)v[r];
-            }
-        }
+        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
+        continue;
       }
+      store_row<NT, F32OUT>(p.dst, (pix0 + (size_t)i * Ws) * p.ldd, v, q, p.N);
     }
   };
-  auto tile_end = [&]() {                                     // next tile's halo has landed (this wave's requests) + everyone is done reading
+  auto tile_end = [&]() {                                     // this wave's halo requests have landed + everyone is done reading
+    if (abl & 16) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   };
 
+  // tile t computes from buffer (t's position in this workgroup's sequence) & 1; the halo of tile s+1 is requested right after the
+  // barrier that ends tile s-1's reads of that buffer, i.e. a whole tile of matrix work before it is needed
   int t = blockIdx.x;
   const int step = gridDim.x;
-  if (t >= p.tiles_total) return;
+  const int total = p.ti.total;
+  if (t >= total) return;
   stage(t, 0);
+  if (t + step < total) stage(t + step, 1);
   tile_end();
   while (true) {
-    int t1 = t + step;
-    if (t1 < p.tiles_total) stage(t1, 1);
-    compute(std::integral_constant<int, 0>{}, t);
+    compute(std::integral_constant<int, 0>{});
+    tile_end();                                               // buffer 0 free, buffer 1 complete
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+    epilogue(t);
+    t += step;
+    if (t >= total) break;
+    compute(std::integral_constant<int, 1>{});
     tile_end();
-    t = t1;
-    if (t >= p.tiles_total) break;
-    t1 = t + step;
-    if (t1 < p.tiles_total) stage(t1, 0);
-    compute(std::integral_constant<int, 1>{}, t);
-    tile_end();
-    t = t1;
-    if (t >= p.tiles_total) break;
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 1);
+    epilogue(t);
+    t += step;
+    if (t >= total) break;
   }
 }
 
 int num_cus();   // narrow_bf16.hip
 
 template <int CPT, int NT, int MT>
-static int launch_c3n(NarrowParams p, int batch, hipStream_t stream) {
+static int launch_c3n(NarrowParams p, int batch, bool f32out, hipStream_t stream) {
   using G = C3nGeom<CPT, NT, MT>;
-  p.tiles_x = p.W / 16;
-  p.tiles_y = p.H / G::TH;
-  const long total = (long)p.tiles_x * p.tiles_y * batch;
-  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "c3n: grid too large");
-  p.tiles_total = (int)total;
+  const int tiles_x = p.W / 16, tiles_y = p.H / G::TH;
+  const long total = (long)tiles_x * tiles_y * batch;
+  if (total > 0x7fffffffL || total * (tiles_x > tiles_y ? tiles_x : tiles_y) >= (1L << 32)) return fail(CCVPE_EINVAL, "c3n: grid too large");
+  p.ti = make_tile_index(tiles_x, tiles_y, (int)total);
+  p.ablate = narrow_ablate_env();
+  static bool attr_set[2] = {false, false};
+  auto kern = f32out ? c3n_kernel<CPT, NT, MT, true> : c3n_kernel<CPT, NT, MT, false>;
+  if (!attr_set[f32out]) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "c3n_kernel: set smem attr: %s", hipGetErrorString(e));
+    attr_set[f32out] = true;
+  }
+  const int grid = (int)(total < num_cus() ? total : num_cus());
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, stream, p);
+  return check_launch("c3n_kernel");
+}
+
+// =====================================================================================================================
+// up2_kernel: ConvTranspose2d(k2,s2) folded into the following 3x3 conv (the math of upconv_impl.h) for the NARROW levels.
+// The tiled kernels give every output parity its own workgroup, so the low-res halo is fetched four times and the 9 skip
+// taps are gathered per parity: at level 2 (81 -> 40 channels at 256 x 256) that is ~180 KB of L2 -> CU traffic per 20 KB of
+// output, and the kernel ran at the L2's bandwidth (481 us at B = 64: 0.35 PF, 5 x off the HBM roof).  Here ONE workgroup
+// computes all four parities of a MT x 16 low-res tile from ONE low-res halo and ONE skip halo in LDS: wave w owns parity
+// (py, px) = (w >> 1, w & 1) and keeps THAT parity's folded weights in registers (the structure of tail512_kernel, with the flat
+// (tap, octet) K order of c3n_kernel above).  Persistent workgroups, LDS-DMA halos, one barrier per tile, epilogue after it.
+// LDS images (DMA piece order): low-res halo [row][18 columns][odd pitch of CPT0 octets]; skip halo [row][column parity][octet]
+// [17 columns] (column parity planes: a fragment's 16 pixels are 16 CONSECUTIVE 16-byte slots).
+// =====================================================================================================================
+struct Up2Params {
+  const void* src0;    // [B,H1,W1,ld0] bf16
+  const void* src1;    // [B,2H1,2W1,ld1] bf16
+  const void* w;       // [4][Npad][Kpad] bf16 (models._pack_upconv)
+  const float* shift9; // [9][N]
+  void* dst;           // [B,2H1,2W1,ldd] bf16
+  int H1, W1, ld0, ld1, N, Npad, Kpad, ldd;
+  float act_floor;
+  TileIndex ti;
+  int ablate;          // see NarrowParams
+};
+
+template <int CPT0, int CPT1, int NT, int MT>
+struct Up2Geom {
+  static constexpr int HR = MT + 2, HC = 18;
+  static constexpr int PP0 = odd_pitch(CPT0);
+  static constexpr int PX = HR * HC * PP0;
+  static constexpr int NDX = (PX + 255) / 256;
+  static constexpr int SR = 2 * MT + 2;
+  static constexpr int SLINE = 17 * 16;                          // bytes of one (row, column parity, octet) line
+  static constexpr int PS = SR * 2 * CPT1 * 17;
+  static constexpr int NDS = (PS + 255) / 256;
+  static constexpr int SKIP_BASE = NDX * 4096;
+  static constexpr int BUF_BYTES = (NDX + NDS) * 4096;
+  static constexpr int SHIFT_BASE = 2 * BUF_BYTES;               // shift9 [9][16 NT] floats in quad order (epilogue reads it by ds_read: no vmcnt traffic)
+  static constexpr int LDS_BYTES = 2 * BUF_BYTES + 9 * 16 * NT * 4;
+  static constexpr int NCHX = CPT0;                              // 4 taps x CPT0 octets = CPT0 k-steps exactly
+  static constexpr int NCHS = (9 * CPT1 + 3) / 4;
+  static constexpr int NCH = NCHX + NCHS;
+};
+
+template <int CPT0, int CPT1, int NT, int MT>
+__global__ __launch_bounds__(256, 1) void up2_kernel(const Up2Params p) {
+  using G = Up2Geom<CPT0, CPT1, NT, MT>;
+  constexpr int HC = G::HC, NCH = G::NCH, NCHX = G::NCHX, NCHS = G::NCHS, NDX = G::NDX, NDS = G::NDS;
+  constexpr int XP = G::PP0 * 16;
+  constexpr int XROW = HC * XP;                                  // one low-res halo row
+  constexpr int SROW2 = 2 * (2 * CPT1 * G::SLINE);               // two skip halo rows (one low-res row step)
+  extern __shared__ __attribute__((aligned(16))) char nsm[];
+  CCVPE_NARROW_ABL(p);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = sgpr(tid >> 6);
+  const int py = wave >> 1, px = wave & 1;
+  const int f = lane & 15, q = lane >> 4;
+
+  // ---- this parity's folded weights, resident --------------------------------------------------------------------------
+  f32x4 wreg[NCH][NT];
+  {
+    const bf16_t* wp = reinterpret_cast<const bf16_t*>(p.w) + (size_t)wave * p.Npad * p.Kpad;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        wreg[j][t] = *reinterpret_cast<const f32x4*>(wp + (size_t)chan_of_row(t, f) * p.Kpad + 32 * j + 8 * q);
+  }
+
+  // ---- fragment offsets --------------------------------------------------------------------------------------------------
+  int aoff[NCH];
+#pragma unroll
+  for (int j = 0; j < NCHX; ++j) {
+    const int o = 4 * j + q;
+    const int tap = o / CPT0, c = o - tap * CPT0;
+    const int du = tap >> 1, dv = tap & 1;
+    aoff[j] = ((du + py) * HC + f + dv + px) * XP + c * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < NCHS; ++j) {
+    const int o = 4 * j + q;
+    const int oo = o < 9 * CPT1 ? o : 0;
+    const int tap = oo / CPT1, c = oo - tap * CPT1;
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int cpar = (px + kx) & 1, chh = f + ((px + kx) >> 1);
+    aoff[NCHX + j] = G::SKIP_BASE + (((py + ky) * 2 + cpar) * CPT1 + c) * G::SLINE + chh * 16;
+  }
+  const bool tail_ok = 4 * (NCHS - 1) + q < 9 * CPT1;
+
+  // ---- DMA pieces (tile-invariant) ----------------------------------------------------------------------------------------
+  const int W2 = 2 * p.W1, H2 = 2 * p.H1;
+  unsigned xv[NDX], sv[NDS];
+  int xh[NDX], shh[NDS];
+#pragma unroll
+  for (int k = 0; k < NDX; ++k) {
+    const int pidx = min(k * 256 + tid, G::PX - 1);
+    const int pix = pidx / G::PP0, oct = pidx - pix * G::PP0;
+    const int hy = pix / HC, hx = pix - hy * HC;
+    xv[k] = (unsigned)(((hy * p.W1 + hx) * p.ld0 + (oct < CPT0 ? oct : 0) * 8) * 2);
+    xh[k] = (hy << 8) | hx;
+  }
+#pragma unroll
+  for (int k = 0; k < NDS; ++k) {
+    const int pidx = min(k * 256 + tid, G::PS - 1);
+    const int line = pidx / 17, chh = pidx - line * 17;          // line = (row * 2 + cpar) * CPT1 + oct
+    const int oct = line % CPT1, rc = line / CPT1;
+    const int cpar = rc & 1, row = rc >> 1;
+    const int hc = 2 * chh + cpar;
+    sv[k] = (unsigned)(((row * W2 + hc) * p.ld1 + oct * 8) * 2);
+    shh[k] = (row << 8) | hc;
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)nsm;
+  const int H1s = sgpr(p.H1), W1s = sgpr(p.W1);
+  {                                                              // the nine shift vectors -> LDS in QUAD order, zero-padded
+    float* st = reinterpret_cast<float*>(nsm + G::SHIFT_BASE);
+    for (int e = tid; e < 9 * 16 * NT; e += 256) {
+      const int cls = e / (16 * NT), rem = e - cls * (16 * NT);  // rem = (n * 4 + q) * 4 + r
+      const int ch = chan_of_quad(rem >> 4, (rem >> 2) & 3) + (rem & 3);
+      st[e] = ch < p.N ? p.shift9[cls * p.N + ch] : 0.f;
+    }
+  }
+
+  auto stage = [&](int t, int buf) {
+    int b, ty, tx;
+    tile_decode(p.ti, t, b, ty, tx);
+    const int y0 = ty * MT, x0 = tx * 16;
+    const char* sb0 = reinterpret_cast<const char*>(p.src0) + ((long)(b * H1s + y0 - 1) * W1s + (x0 - 1)) * (long)(p.ld0 * 2);
+    const char* sb1 = reinterpret_cast<const char*>(p.src1) + ((long)(b * H2 + 2 * y0 - 1) * W2 + (2 * x0 - 1)) * (long)(p.ld1 * 2);
+    const bool interior = y0 > 0 && y0 + MT < H1s && x0 > 0 && x0 + 16 < W1s;       // wave-uniform
+    if (interior) {
+#pragma unroll
+      for (int k = 0; k < NDX; ++k) {
+        const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + (k * 256 + wave * 64) * 16));
+        if ((k + 1) * 256 <= G::PX || k * 256 + tid < G::PX) dma16(ldsw, xv[k], sb0);
+      }
+#pragma unroll
+      for (int k = 0; k < NDS; ++k) {
+        const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + G::SKIP_BASE + (k * 256 + wave * 64) * 16));
+        if ((k + 1) * 256 <= G::PS || k * 256 + tid < G::PS) dma16(ldsw, sv[k], sb1);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NDX; ++k) {
+        if ((k + 1) * 256 <= G::PX || k * 256 + tid < G::PX) {
+          const int iy = y0 - 1 + (xh[k] >> 8), ix = x0 - 1 + (xh[k] & 255);
+          const bool ok = (unsigned)iy < (unsigned)H1s && (unsigned)ix < (unsigned)W1s;
+          const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + (k * 256 + wave * 64) * 16));
+          if (ok) dma16(ldsw, xv[k], sb0);
+          else *reinterpret_cast<f32x4*>(nsm + buf * G::BUF_BYTES + (k * 256 + tid) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < NDS; ++k) {
+        if ((k + 1) * 256 <= G::PS || k * 256 + tid < G::PS) {
+          const int iy = 2 * y0 - 1 + (shh[k] >> 8), ix = 2 * x0 - 1 + (shh[k] & 255);
+          const bool ok = (unsigned)iy < (unsigned)H2 && (unsigned)ix < (unsigned)W2;
+          const unsigned ldsw = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(buf * G::BUF_BYTES + G::SKIP_BASE + (k * 256 + wave * 64) * 16));
+          if (ok) dma16(ldsw, sv[k], sb1);
+          else *reinterpret_cast<f32x4*>(nsm + buf * G::BUF_BYTES + G::SKIP_BASE + (k * 256 + tid) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  auto compute = [&](auto buf_tag) {
+    constexpr int BUF = decltype(buf_tag)::value;
+    const char* hb = nsm + BUF * G::BUF_BYTES;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2][MT];
+    auto rd = [&](int j, f32x4* dst) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+        dst[i] = *reinterpret_cast<const f32x4*>(hb + aoff[j] + i * (j < NCHX ? XROW : SROW2));
+    };
+    rd(0, a[0]);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int cur = j & 1;
+      if (j + 1 < NCH && !(abl & 8)) rd(j + 1, a[cur ^ 1]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (j == NCH - 1 && (9 * CPT1) % 4 != 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[cur][i] = keep_if(a[cur][i], tail_ok);
+      }
+      if (!(abl & 4)) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int n = 0; n < NT; ++n) acc[i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[i][n]);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // ---- epilogue (after the tile's closing barrier, see c3n_kernel): pixel (2 (y0 + i) + py, 2 (x0 + f) + px); shift by the
+  // pixel's border class ---------------------------------------------------------------------------------------------------
+  auto epilogue = [&](int t) {
+    int b, ty, tx;
+    tile_decode(p.ti, t, b, ty, tx);
+    const int y0 = ty * MT, x0 = tx * 16;
+    const int X = 2 * (x0 + f) + px;
+    const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int Y = 2 * (y0 + i) + py;
+      const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
+      const char* shp = nsm + G::SHIFT_BASE + ((rc * 3 + cc) * 16 * NT + q * 4) * 4;
+      f32x4 v[NT];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        v[n] = acc[i][n] + *reinterpret_cast<const f32x4*>(shp + 64 * n);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
+      }
+      if (abl & 2) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
+        continue;
+      }
+      store_row<NT, false>(p.dst, ((size_t)(b * H2 + Y) * W2 + X) * p.ldd, v, q, p.N);
+    }
+  };
+  auto tile_end = [&]() {
+    if (abl & 16) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+
+  int t = blockIdx.x;
+  const int step = gridDim.x;
+  const int total = p.ti.total;
+  if (t >= total) return;
+  stage(t, 0);
+  if (t + step < total) stage(t + step, 1);
+  tile_end();
+  while (true) {
+    compute(std::integral_constant<int, 0>{});
+    tile_end();
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+    epilogue(t);
+    t += step;
+    if (t >= total) break;
+    compute(std::integral_constant<int, 1>{});
+    tile_end();
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 1);
+    epilogue(t);
+    t += step;
+    if (t >= total) break;
+  }
+}
+
+template <int CPT0, int CPT1, int NT, int MT>
+static int launch_up2(Up2Params p, int batch, hipStream_t stream) {
+  using G = Up2Geom<CPT0, CPT1, NT, MT>;
+  static_assert(G::LDS_BYTES <= 160 * 1024, "up2_kernel: LDS");
+  const int tiles_x = p.W1 / 16, tiles_y = p.H1 / MT;
+  const long total = (long)tiles_x * tiles_y * batch;
+  if (total > 0x7fffffffL || total * (tiles_x > tiles_y ? tiles_x : tiles_y) >= (1L << 32)) return fail(CCVPE_EINVAL, "up2: grid too large");
+  p.ti = make_tile_index(tiles_x, tiles_y, (int)total);
+  p.ablate = narrow_ablate_env();
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)c3n_kernel<CPT, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
-    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "c3n_kernel: set smem attr: %s", hipGetErrorString(e));
+    hipError_t e = hipFuncSetAttribute((const void*)up2_kernel<CPT0, CPT1, NT, MT>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "up2_kernel: set smem attr: %s", hipGetErrorString(e));
     attr_set = true;
   }
   const int grid = (int)(total < num_cus() ? total : num_cus());
-  hipLaunchKernelGGL((c3n_kernel<CPT, NT, MT>), dim3(grid), dim3(256), G::LDS_BYTES, stream, p);
-  return check_launch("c3n_kernel");
+  hipLaunchKernelGGL((up2_kernel<CPT0, CPT1, NT, MT>), dim3(grid), dim3(256), G::LDS_BYTES, stream, p);
+  return check_launch("up2_kernel");
 }
 
 }  // namespace ccvpe

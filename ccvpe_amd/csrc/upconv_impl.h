@@ -889,8 +889,9 @@ __global__ __launch_bounds__(256, 2) void upconv_dma_kernel(const UpParams p) {
   CCVPE_ACT_DISPATCH(p.act, epilogue);
 }
 
+// route (optional): CCVPE_UPROUTE_* | MT << 8 | NT << 12 | WN << 16 of the kernel that WOULD run; nothing is launched
 template <typename T, int MT, int NT, int WN>
-static int launch_up(const UpParams& p0, hipStream_t stream) {
+static int launch_up(const UpParams& p0, hipStream_t stream, int* route = nullptr) {
   constexpr int WM = 4 / WN;
   constexpr int BM = 16 * MT * WM;
   constexpr int BN = 16 * NT * WN;
@@ -927,17 +928,23 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
       hipLaunchKernelGGL((upconv_dma_kernel<T, MT, NT, WN, PAIR>), dim3(p.tiles_total), dim3(256), G::LDS_BYTES, stream, p);
       return check_launch("upconv_dma_kernel");
     };
+    const int tile_bits = (MT << 8) | (NT << 12) | (WN << 16);
     if constexpr (sizeof(T) == 2) {
-      if (halo && dma_ok) return go(std::false_type{});
+      if (halo && dma_ok) {
+        if (route) { *route = CCVPE_UPROUTE_DMA | tile_bits; return CCVPE_OK; }
+        return go(std::false_type{});
+      }
     }
     if constexpr (MT == 4 && NT == 5 && WN == 2) {
       // level 6 (8 x 8 low-res images): two images per 8 x 16 tile instead of the linear-M gather kernel
       if (dma_ok && p.W1 == 8 && p.H1 == TH) {
+        if (route) { *route = CCVPE_UPROUTE_DMA_PAIR | tile_bits; return CCVPE_OK; }
         p.tiles_m = (batch + 1) / 2;
         p.tiles_total = p.tiles_m * p.tiles_n * 4;
         return go(std::true_type{});
       }
     }
+    if (route) { *route = (halo ? CCVPE_UPROUTE_HALO : CCVPE_UPROUTE_GATHER) | tile_bits; return CCVPE_OK; }
   }
   if (halo)
     hipLaunchKernelGGL((upconv_halo_kernel<T, MT, NT, WN>), dim3(p.tiles_total), dim3(256), 0, stream, p);
@@ -947,8 +954,10 @@ static int launch_up(const UpParams& p0, hipStream_t stream) {
 }
 
 
+int upconv_route_f32(const ccvpe_upconv_desc* d, int* route);     // upconv_f32.hip (the fp32 instantiations live there)
+
 template <typename T>
-static int upconv_any(const ccvpe_upconv_desc* d, void* stream) {
+static int upconv_any(const ccvpe_upconv_desc* d, void* stream, int* route = nullptr) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;
   constexpr int CPS = SK / 8;
@@ -975,9 +984,18 @@ static int upconv_any(const ccvpe_upconv_desc* d, void* stream) {
   p.M = (int)M;
   p.tiles_n = p.tiles_m = p.tiles_total = 0;
   hipStream_t st = (hipStream_t)stream;
+  if constexpr (sizeof(T) == 2) {
+    // the narrow levels: all four parities of a low-res tile in one workgroup, weights in registers (narrow_impl.h)
+    if (g_use_narrow && d->c1 > 0 && d->ldd % 8 == 0 && d->n % 8 == 0 && (d->act == CCVPE_ACT_NONE || d->act == CCVPE_ACT_RELU) &&
+        up2_supported(d->c0, d->c1, d->n, d->kpad, d->h1, d->w1, d->batch)) {
+      if (route) { *route = CCVPE_UPROUTE_UP2; return CCVPE_OK; }
+      return up2_dispatch(d->src0, d->src1, d->w, d->shift9, d->dst, d->c0, d->ld0, d->c1, d->ld1, d->h1, d->w1, d->n, d->kpad,
+                          d->ldd, d->act, d->batch, st);
+    }
+  }
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
 #define CCVPE_CASE(MT_, NT_, WN_) \
-  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) return launch_up<T, MT_, NT_, WN_>(p, st);
+  if (c.mt == MT_ && c.nt == NT_ && c.wn == WN_) return launch_up<T, MT_, NT_, WN_>(p, st, route);
   CCVPE_CASE(4, 5, 2) CCVPE_CASE(4, 4, 2) CCVPE_CASE(4, 3, 2) CCVPE_CASE(4, 2, 2) CCVPE_CASE(4, 1, 2)
   CCVPE_CASE(4, 5, 1) CCVPE_CASE(4, 3, 1) CCVPE_CASE(4, 1, 1) CCVPE_CASE(2, 7, 1)
 #undef CCVPE_CASE

@@ -73,7 +73,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-ROUTE_FAMILIES = {0: "igemm", 1: "pw_gemm", 2: "conv3x3"}
+ROUTE_FAMILIES = {0: "igemm", 1: "pw_gemm", 2: "conv3x3", 3: "c3n"}
 
 
 def conv_route(desc, is_bf16, out_f32=False):
@@ -85,8 +85,30 @@ def conv_route(desc, is_bf16, out_f32=False):
     return ROUTE_FAMILIES[r & 0xff], (r >> 8) & 0xf, (r >> 12) & 0xf, (r >> 16) & 0xf
 
 
+UPROUTE_KERNELS = {0: "upconv_kernel", 1: "upconv_halo_kernel", 2: "upconv_dma_kernel", 3: "upconv_dma_kernel", 4: "up2_kernel"}
+
+
+def upconv_route(desc, is_bf16):
+    """(kernel, MT, NT, WN, pair) ccvpe_upconv3x3_f32 / _bf16 runs for `desc` (nothing is launched)."""
+    r = _lib.load().ccvpe_upconv3x3_route(ctypes.byref(desc), int(bool(is_bf16)))
+    if r < 0:
+        check(int(r), "ccvpe_upconv3x3_route")
+    return UPROUTE_KERNELS[r & 0xff], (r >> 8) & 0xf, (r >> 12) & 0xf, (r >> 16) & 0xf, (r & 0xff) == 3
+
+
+def upconv_route_name(desc, is_bf16):
+    """Kernel name as rocprofv3 prints it (minus namespace): the key of profiles/pmc_traffic.json."""
+    k, mt, nt, wn, pair = upconv_route(desc, is_bf16)
+    ty = "bf16" if is_bf16 else "f32"
+    if k == "up2_kernel":
+        return "up2_kernel<bf16,%d>" % desc.n
+    return "%s<%s,%d,%d,%d%s>" % (k, ty, mt, nt, wn, ",pair" if pair else "")
+
+
 def conv_route_name(desc, is_bf16, out_f32=False, f32_names=False):
     fam, mt, nt, wn = conv_route(desc, is_bf16, out_f32)
+    if fam == "c3n":
+        return "c3n_f32_kernel<%d>" % desc.n
     return "%s_f32_kernel<%d,%d,%d>" % (fam, mt, nt, wn)
 
 
@@ -200,7 +222,7 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
     return dst
 
 
-def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, act=ACT_NONE, algo_flops=None):
+def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, act=ACT_NONE, algo_flops=None, route_only=False):
     """ConvTranspose2d(k2,s2) folded into the following 3x3 conv (ccvpe_upconv3x3_f32 / _bf16).
     src0 [B,h1,w1,ld0] low-res, src1 [B,2h1,2w1,ld1] skip; returns [B,2h1,2w1,n]."""
     lib = _lib.load()
@@ -214,6 +236,8 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
     d.c0, d.ld0, d.c1, d.ld1 = c0, src0.shape[-1], c1, (src1.shape[-1] if src1 is not None else 0)
     d.batch, d.h1, d.w1 = batch, h1, w1
     d.n, d.kpad, d.ldd, d.act = n, w_packed.shape[-1], n, act
+    if route_only:
+        return upconv_route(d, dt != torch.float32)
     rec = _recorder
     ev0 = rec.begin() if rec is not None else None
     fn = lib.ccvpe_upconv3x3_f32 if dt == torch.float32 else lib.ccvpe_upconv3x3_bf16
@@ -224,8 +248,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
         flops = algo_flops if algo_flops is not None else 2.0 * m * n * k_eff
         esz = 4.0 if dt == torch.float32 else 2.0
         nbytes = esz * (batch * h1 * w1 * c0 + m * c1 + m * n + 4 * n * k_eff)
-        kname = "upconv_halo_kernel" if w1 >= 16 else "upconv_kernel"     # mirrors launch_up() in csrc/upconv_impl.h
-        name = igemm_tile(n).replace("igemm_f32_kernel<", "%s<%s," % (kname, "f32" if dt == torch.float32 else "bf16"))
+        name = upconv_route_name(d, dt != torch.float32)                  # the library's own dispatch (ccvpe_upconv3x3_route)
         rec.end(name, "up3x3 M%d N%d Keff%d" % (m, n, k_eff), flops, nbytes, ev0)
     return dst
 

@@ -100,7 +100,11 @@ int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* desc, int is_bf16);
 #define CCVPE_ROUTE_IGEMM 0   /* generic gather kernel */
 #define CCVPE_ROUTE_PW_GEMM 1 /* deep-stage pointwise kernel (1x1, stride 1, one source) */
 #define CCVPE_ROUTE_CONV3X3 2 /* LDS-halo 3x3 kernel */
+#define CCVPE_ROUTE_C3N 3     /* bf16 narrow 3x3 kernel: weights in registers, persistent workgroups (csrc/narrow_impl.h) */
 int ccvpe_conv_igemm_route(const ccvpe_conv_desc* desc, int is_bf16, int out_f32);
+/* A/B switch for measurements (process-wide, default on): 0 sends the narrow bf16 decoder layers (CCVPE_ROUTE_C3N, and the
+ * narrow form of ccvpe_upconv3x3_bf16) back to the tiled kernels.  Returns the previous setting. */
+int ccvpe_set_narrow_kernels(int on);
 int ccvpe_conv_igemm_splitk_f32(const ccvpe_conv_desc* desc, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------
@@ -128,6 +132,14 @@ typedef struct ccvpe_upconv_desc {
 
 int ccvpe_upconv3x3_f32(const ccvpe_upconv_desc* desc, void* stream);
 int ccvpe_upconv3x3_bf16(const ccvpe_upconv_desc* desc, void* stream);
+/* Which kernel ccvpe_upconv3x3_f32 / _bf16 run for `desc`; launches nothing.  Returns CCVPE_UPROUTE_* | MT << 8 | NT << 12 |
+ * WN << 16 (tile bits zero for CCVPE_UPROUTE_UP2), or a negative error code.  For tests and bench.py's per-kernel accounting. */
+#define CCVPE_UPROUTE_GATHER 0   /* upconv_kernel: linear-M gather (low-res images narrower than 16 pixels) */
+#define CCVPE_UPROUTE_HALO 1     /* upconv_halo_kernel: low-res halo in LDS, skip gathered, W through registers */
+#define CCVPE_UPROUTE_DMA 2      /* upconv_dma_kernel (bf16): pair-of-taps stages, W by LDS-DMA */
+#define CCVPE_UPROUTE_DMA_PAIR 3 /* upconv_dma_kernel, two 8 x 8 images per tile (level 6) */
+#define CCVPE_UPROUTE_UP2 4      /* up2_kernel (bf16, narrow levels): four parities per workgroup, weights in registers */
+int ccvpe_upconv3x3_route(const ccvpe_upconv_desc* desc, int is_bf16);
 
 /* -------------------------------------------------------------------------------------------
  * The whole 512 x 512 level of a decoder in one launch (csrc/tail512.hip):

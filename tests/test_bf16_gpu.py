@@ -103,6 +103,37 @@ def test_conv3x3_bf16_two_sources(ops, c0, c1, cout, hw):
     close(nchw(got), want, 1e-2, "bf16 3x3 %d+%d->%d" % (c0, c1, cout))
 
 
+@pytest.mark.parametrize("c,cout,hw,b,act,f32out", [(40, 40, 256, 2, True, False), (40, 40, 256, 3, False, True),
+                                                    (32, 32, 256, 2, True, False), (64, 64, 128, 8, True, False),
+                                                    (40, 40, 272, 2, True, False)])
+def test_narrow_conv3x3_weights_in_registers(ops, c, cout, hw, b, act, f32out):
+    """c3n_kernel (csrc/narrow_impl.h): the narrow last-level 3x3 layers with the weights resident in registers, flat (tap, octet)
+    K, persistent workgroups and LDS-DMA halo tiles.  Enough tiles that the dispatcher picks it (route checked), several tiles
+    per workgroup, image borders on every side, odd batch, an image of 17 x 17 tiles, fp32 output; also compared with conv3x3_kernel's
+    result class (same operands, other summation order) through the A/B switch."""
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    a = r(synth.normal((b, c, hw, hw), 10 + c))
+    wt = r(synth.normal((cout, c, 3, 3), 12, (1.0 / (9 * c)) ** 0.5))
+    bias = synth.normal((cout,), 13, 0.1)
+    want = F.conv2d(a, wt, bias, padding=1)
+    want = F.relu(want) if act else want
+    kw = dict(batch=b, in_h=hw, in_w=hw, kh=3, kw=3, pad=1, shift=dev(bias, torch.float32),
+              act=ops.ACT_RELU if act else ops.ACT_NONE, out_f32=f32out)
+    x, wp = dev(nhwc(a)), dev(pack(wt))
+    assert ops.conv_igemm(x, c, wp, cout, route_only=True, **kw)[0] == "c3n"
+    got = ops.conv_igemm(x, c, wp, cout, **kw)
+    assert got.dtype == (torch.float32 if f32out else BF)
+    close(nchw(got), want, 1e-2 if not f32out else 2e-3, "narrow 3x3 %d->%d" % (c, cout))
+    prev = lib.ccvpe_set_narrow_kernels(0)
+    try:
+        assert ops.conv_igemm(x, c, wp, cout, route_only=True, **kw)[0] == "conv3x3"
+        ref = ops.conv_igemm(x, c, wp, cout, **kw)
+    finally:
+        lib.ccvpe_set_narrow_kernels(prev)
+    close(nchw(got), nchw(ref).float().cpu(), 1e-2 if not f32out else 1e-5, "narrow vs tiled 3x3")
+
+
 def test_igemm_bf16_2x2s2_and_deconv(ops):
     from ccvpe_amd.models import _pack_deconv
     b, c, n = 2, 64, 48

@@ -221,6 +221,11 @@ def test_igemm_deconv_pixel_shuffle(ops, cin, cout, hw):
     (48, 41, 16, 0, 16, 17, 33, True),        # no skip, c0 % 32 != 0: the DMA kernel's W-row precondition fails -> halo kernel
     (328, 321, 160, 40, 160, 7, 17, True),    # level 4 in bf16 (DMA kernel, two K stages per barrier in phase B)
     (256, 256, 128, 40, 128, 6, 16, True),    # ori level 4 in bf16, <4,4,2>
+    # up2_kernel (csrc/narrow_impl.h; bf16, >= 2 tiles per CU): level 2 of both decoders and KITTI's localisation level 2 — four
+    # parities per workgroup, weights in registers, LDS-DMA halos, several tiles per persistent workgroup, every image border
+    (88, 81, 40, 16, 40, 128, 256, True),
+    (64, 64, 32, 16, 32, 128, 256, True),
+    (136, 129, 32, 16, 32, 64, 512, True),
 ])
 def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf16):
     """relu(conv3x3(cat[deconv2x2s2(x)+b, skip])+b)  ==  the folded per-parity GEMM (incl. borders)."""
@@ -238,9 +243,20 @@ def test_upconv_folds_deconv_into_conv3x3(ops, cp, cref, cd, c1, co, h1, w1, bf1
     d = F.conv_transpose2d(x[:, :cref], wd, bd, stride=2)
     want = F.relu(F.conv2d(torch.cat([d, skip], 1) if c1 else d, w3, b3, padding=1))
     fw, fshift = _pack_upconv(wd.cuda(), bd.cuda(), [(0, 0, cref)], cp, w3.cuda(), b3.cuda(), dt)
-    got = ops.upconv3x3(nhwc(x).to(dt).cuda().contiguous(), cp, fw, fshift, co, batch=b, h1=h1, w1=w1,
-                        src1=nhwc(skip).to(dt).cuda().contiguous() if c1 else None, c1=c1, act=ops.ACT_RELU)
+    xd, sk = nhwc(x).to(dt).cuda().contiguous(), (nhwc(skip).to(dt).cuda().contiguous() if c1 else None)
+    got = ops.upconv3x3(xd, cp, fw, fshift, co, batch=b, h1=h1, w1=w1, src1=sk, c1=c1, act=ops.ACT_RELU)
     close(nchw(got).float(), want, 2e-2 if bf16 else 1e-4, "upconv cp=%d" % cp)
+    if h1 * w1 >= 128 * 256:                                # the narrow-level kernel must be the one that ran, and agree with the tiled one
+        from ccvpe_amd import _lib
+        lib = _lib.load()
+        assert ops.upconv3x3(xd, cp, fw, fshift, co, batch=b, h1=h1, w1=w1, src1=sk, c1=c1, act=ops.ACT_RELU, route_only=True)[0] == "up2_kernel"
+        prev = lib.ccvpe_set_narrow_kernels(0)
+        try:
+            assert ops.upconv3x3(xd, cp, fw, fshift, co, batch=b, h1=h1, w1=w1, src1=sk, c1=c1, act=ops.ACT_RELU, route_only=True)[0] != "up2_kernel"
+            ref = ops.upconv3x3(xd, cp, fw, fshift, co, batch=b, h1=h1, w1=w1, src1=sk, c1=c1, act=ops.ACT_RELU)
+        finally:
+            lib.ccvpe_set_narrow_kernels(prev)
+        close(nchw(got).float(), nchw(ref).float().cpu(), 1e-2, "up2 vs tiled upconv")
 
 
 @pytest.mark.parametrize("b,bf16", [(3, True), (4, True), (3, False)])
