@@ -197,6 +197,8 @@ def load():
         fn = getattr(lib, name)       # AttributeError if the symbol is missing: loud by design
         fn.restype = res
         fn.argtypes = args
+    if os.environ.get("CCVPE_NARROW") == "0" and hasattr(lib, "ccvpe_set_narrow_kernels"):
+        lib.ccvpe_set_narrow_kernels(0)           # A/B runs (tools/gpu/*.sh): the tiled kernels for the narrow decoder levels
     _lib = lib
     return lib
 

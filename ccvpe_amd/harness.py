@@ -131,13 +131,19 @@ class GradientAllReducer:
         self.bytes_reduced_last_step = 0      # payload bytes handed to all-reduce by the last arena step
 
     # ---- arena mode: reduce inside the model's backward -------------------------------------------------
-    def attach(self, model, optimizer=None):
+    def attach(self, model, optimizer=None, step_in_backward=False):
         """Build the flat gradient arena for `model` (a ccvpe_amd CVM_* module) and register with it: its backward then
         calls begin() / ready() (after each of the three gradient groups) / finish().  After finish() every `p.grad` holds
         the MEAN over the ranks, whatever the backend: RCCL averages inside the collective (ncclAvg); a backend that can
         only SUM (gloo, a build without ncclAvg) gets one in-place 1/world pass over the reduced slice (~230 MB, once per
         step) — the scale is NOT deferred to the optimizer, so clipping / logging between backward() and step() see the
-        same numbers on every backend.  `optimizer` is accepted for source compatibility and not touched."""
+        same numbers on every backend.
+        step_in_backward=True (needs a ccvpe_amd.optim.Adam as `optimizer`): finish() runs `optimizer.step_subset()` on each
+        gradient group as soon as that group's all-reduce has completed, in issue order — the update of the early (large)
+        groups then runs beside the collective of the last one (the ground encoder's 16 MB), which would otherwise be exposed
+        in front of a whole-model optimizer step; the caller's `optimizer.step()` after backward() skips what was updated.
+        Same arithmetic and bit-identical parameters (tests/test_rccl_single_rank_gpu.py).  Off by default: a training loop that
+        clips or inspects gradients between backward() and step() needs them untouched.  Without it `optimizer` is not touched."""
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad and "._fc." not in n]
         named.sort(key=lambda np_: grad_group(np_[0]))           # stable: keeps parameter order inside a group
         off, slots, bounds = 0, {}, [[None, None] for _ in range(3)]
@@ -154,6 +160,9 @@ class GradientAllReducer:
         for n, (o, cnt, shp, g, p) in slots.items():
             self._arena["views"][n] = self._arena["flat"][o:o + cnt].view(shp)
         self._optimizer = optimizer
+        self._step_in_backward = bool(step_in_backward)
+        if self._step_in_backward and not hasattr(optimizer, "step_subset"):
+            raise ValueError("step_in_backward needs an optimizer with step_subset() (ccvpe_amd.optim.Adam)")
         model._grad_sync = self
         return self
 
@@ -209,9 +218,11 @@ class GradientAllReducer:
         ar = self._arena
         glo, ghi = None, None
         small = []                                           # (src ptr, dst ptr, floats): one multi-copy launch per 96
+        in_arena = []
         for n in names:
             if n not in ar["slots"]:
                 continue                                     # frozen / excluded parameter: stays with autograd
+            in_arena.append(n)
             o, cnt, shp, g, p = ar["slots"][n]
             gr, view = grads[n], ar["views"][n]
             if (cnt <= _MULTI_COPY_MAX_FLOATS and gr.is_cuda and gr.dtype == torch.float32 and gr.is_contiguous()
@@ -230,7 +241,9 @@ class GradientAllReducer:
             work, scale = _allreduce_mean(ar["flat"][lo:hi])
             self.allreduce_calls += 1
             self.bytes_reduced_last_step += (hi - lo) * 4
-            self._pending.append((work, scale, ar["flat"][lo:hi], None, None))
+            self._pending.append((work, scale, ar["flat"][lo:hi], None, in_arena))
+        elif getattr(self, "_step_in_backward", False):
+            self._pending.append((None, 1.0, ar["flat"][lo:hi], None, in_arena))      # no collective: the group is final as it is
 
     def finish(self, grads):
         """Wait for the collectives; arena mode: hand the arena views to the parameters as their .grad and drop those
@@ -240,6 +253,14 @@ class GradientAllReducer:
                 work.wait()
             if scale != 1.0:
                 flat.mul_(scale)                         # SUM backends: p.grad is the mean here too (see attach)
+            if names is None and getattr(self, "_step_in_backward", False) and shapes:
+                # `shapes` carries the arena names of this group: their gradients are final -> update them now
+                ar = self._arena
+                group = []
+                for n in shapes:
+                    ar["slots"][n][4].grad = ar["views"][n]
+                    group.append(ar["slots"][n][4])
+                self._optimizer.step_subset(group)
             if names is not None:
                 off = 0
                 for n, shp in zip(names, shapes):

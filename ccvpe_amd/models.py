@@ -169,8 +169,6 @@ PACK_GATHER = __import__("os").environ.get("CCVPE_PACK_GATHER", "1") != "0"
 # eval forward: CCVPE_EVAL_TWO_STREAMS=0 runs the ground encoder on the main stream too (for per-kernel profiles in which no
 # two kernels share the chip; the default overlaps the two encoders)
 EVAL_TWO_STREAMS = __import__("os").environ.get("CCVPE_EVAL_TWO_STREAMS", "1") != "0"
-# eval forward as a software pipeline over N sub-batches (see _CVMBase._forward_pipelined); 0 / 1 = off.  Per model: net.eval_pipeline = N
-EVAL_PIPELINE = int(__import__("os").environ.get("CCVPE_EVAL_PIPELINE", "0"))
 
 
 def _pack_upconv(wd, bd, col_map, cp, w3, b3, dtype=torch.float32):
@@ -597,43 +595,14 @@ class _CVMBase(nn.Module):
             if self.ori_noise is not None:          # ori_prior returns the recomputed 20-shift volume (models.py:501-511)
                 outs[3] = outs[3][:, len(self._loc_shifts()):]
             return tuple(outs)
-        nsplit = int(getattr(self, "eval_pipeline", 0) or EVAL_PIPELINE)
-        if nsplit > 1 and grd.shape[0] >= 2 * nsplit and grd.shape[0] % nsplit == 0 and ops._record is None:
-            return self._forward_pipelined(grd, sat, nsplit)
         main = torch.cuda.current_stream()
         return self._forward_eval(grd, sat, main, self._side_stream() if EVAL_TWO_STREAMS else main)
 
-    def _forward_pipelined(self, grd, sat, nsplit):
-        """The eval forward on `nsplit` sub-batches in a software pipeline: the encoders of sub-batch h+1 start when those of
-        sub-batch h are done, so they run BESIDE the decoders of sub-batch h (the encoders are bandwidth / vector-ALU work in
-        small launches, the decoders matrix work: complementary use of a CU).  Each sub-batch has its own pair of streams;
-        everything forks from and joins the caller's stream (legal inside hipGraph capture).  Results are concatenated along
-        the batch axis: bit-identical to the one-batch forward wherever no kernel's tile choice depends on the batch size."""
-        cur = torch.cuda.current_stream()
-        per = grd.shape[0] // nsplit
-        outs, prev_enc = [], None
-        for h in range(nsplit):
-            m, sd = self._side_stream(10 + 2 * h), self._side_stream(11 + 2 * h)
-            m.wait_stream(cur)
-            if prev_enc is not None:
-                m.wait_event(prev_enc)
-            ev = torch.cuda.Event()
-            with torch.cuda.stream(m):
-                o = self._forward_eval(grd[h * per:(h + 1) * per], sat[h * per:(h + 1) * per], m, sd, after_encoders=ev.record)
-            prev_enc = ev
-            outs.append(o)
-        for h in range(nsplit):
-            cur.wait_stream(self._side_stream(10 + 2 * h))
-        res = []
-        for parts in zip(*outs):
-            for t in parts:
-                t.record_stream(cur)
-            res.append(torch.cat(parts, 0))
-        return tuple(res)
-
-    def _forward_eval(self, grd, sat, main, side, after_encoders=None):
-        """One eval forward on the stream pair (main, side); main must be the current stream.  `after_encoders()` is called
-        right after both encoders have been joined on main (the pipelined schedule records its hand-off event there)."""
+    def _forward_eval(self, grd, sat, main, side):
+        """One eval forward on the stream pair (main, side); main must be the current stream.
+        (Round 5 measured a software pipeline over sub-batches on top of this — the encoders of half-batch 2 beside the decoders
+        of half-batch 1, four streams — and removed it: bf16 C1 at B = 64 9.45 -> 11.5 ms with two halves, 12.8 with four; the
+        kernels lose more at the smaller batch than the extra concurrency returns.)"""
         spec = MODEL_SPECS[self.kind]
         n_rot = spec["n_rot"]
         strides = MATCH_STRIDES[self.kind]
@@ -661,8 +630,6 @@ class _CVMBase(nn.Module):
             svol, sfeats = _run_encoder(pk.sat, sat, False, True, pk.dtype)
             main.wait_stream(side)
             gdesc.record_stream(main)
-            if after_encoders is not None:
-                after_encoders()
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
                                    in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
 

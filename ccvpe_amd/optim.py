@@ -25,12 +25,16 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False))
         self._layout = None
+        self._subset_layouts = {}    # tuple of parameter ids -> launch geometry of step_subset()
+        self._pre_stepped = set()    # ids updated by step_subset() since the last step(): step() skips them once
         self.grad_scale = 1.0        # caller-set multiplier applied to every gradient inside the update kernel (e.g. loss scaling)
 
     # ---- static launch geometry: rebuilt only when the parameter set changes --------------------------------
-    def _build_layout(self):
+    def _build_layout(self, params=None):
         lib = _lib.load()
-        params = [p for g in self.param_groups for p in g["params"]]
+        whole = params is None
+        if whole:
+            params = [p for g in self.param_groups for p in g["params"]]
         for p in params:
             if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                 raise ValueError("ccvpe_amd.optim.Adam needs contiguous fp32 parameters on the MI355X (no CPU fallback)")
@@ -46,7 +50,8 @@ class Adam(torch.optim.Optimizer):
                    chunk_off=torch.from_numpy(np.concatenate(co)).to(dev),
                    table=np.zeros((len(params), 5), dtype=np.int64),
                    hyper=np.zeros((len(params), lib.ccvpe_adam_hyper_floats()), dtype=np.float32))
-        self._layout = lay
+        if whole:
+            self._layout = lay
         return lay
 
     def _state_of(self, p):
@@ -63,37 +68,60 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
-        lib = _lib.load()
         lay = self._layout
         if lay is None or lay["ids"] != tuple(id(p) for g in self.param_groups for p in g["params"]):
             lay = self._build_layout()
+        skip, self._pre_stepped = self._pre_stepped, set()
+        self._launch(lay, skip)
+        return loss
+
+    @torch.no_grad()
+    def step_subset(self, params):
+        """Update ONLY `params` now (their .grad must be final) and remember them: the next step() skips them once.
+        harness.GradientAllReducer(step_in_backward=True) calls this per gradient group as soon as the group's all-reduce has
+        finished, so the optimizer of the early groups runs beside the collectives of the late ones and the last (small)
+        all-reduce is not exposed in front of a whole-model update.  Same arithmetic, same per-parameter step counts as step()."""
+        params = [p for p in params if p.grad is not None and id(p) not in self._pre_stepped]
+        if not params:
+            return
+        key = tuple(id(p) for p in params)
+        lay = self._subset_layouts.get(key)
+        if lay is None:
+            lay = self._subset_layouts[key] = self._build_layout(params)
+        self._launch(lay, set())
+        self._pre_stepped.update(key)
+
+    def _group_of(self):
+        return {id(p): g for g in self.param_groups for p in g["params"]}
+
+    def _launch(self, lay, skip):
+        lib = _lib.load()
         table, hyper = lay["table"], lay["hyper"]
-        keep, any_grad, t = [], False, 0
-        for g in self.param_groups:
+        group_of = self._group_of()
+        keep, any_grad = [], False
+        for t, p in enumerate(lay["params"]):
+            g = group_of[id(p)]
             lr, (b1, b2), eps = float(g["lr"]), g["betas"], float(g["eps"])
             if g.get("weight_decay", 0) or g.get("amsgrad", False) or g.get("maximize", False):
                 raise ValueError("ccvpe_amd.optim.Adam: weight_decay / amsgrad / maximize are not implemented")
-            for p in g["params"]:
-                gr = p.grad
-                if gr is None:
-                    table[t, 1] = 0
-                    t += 1
-                    continue
-                if gr.is_sparse:
-                    raise RuntimeError("ccvpe_amd.optim.Adam does not support sparse gradients")
-                if not gr.is_contiguous() or gr.dtype != torch.float32:
-                    gr = gr.contiguous().float()
-                    keep.append(gr)
-                st = self._state_of(p)
-                st["step"] += 1
-                k = float(st["step"])
-                # bias corrections and 1 - beta in double on the host, as torch.optim.Adam does with Python floats
-                hyper[t] = (lr / (1.0 - b1 ** k), b1, b2, 1.0 - b1, 1.0 - b2, eps, math.sqrt(1.0 - b2 ** k), 0.0)
-                table[t] = (p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
-                any_grad = True
-                t += 1
+            gr = p.grad
+            if gr is None or id(p) in skip:
+                table[t, 1] = 0
+                continue
+            if gr.is_sparse:
+                raise RuntimeError("ccvpe_amd.optim.Adam does not support sparse gradients")
+            if not gr.is_contiguous() or gr.dtype != torch.float32:
+                gr = gr.contiguous().float()
+                keep.append(gr)
+            st = self._state_of(p)
+            st["step"] += 1
+            k = float(st["step"])
+            # bias corrections and 1 - beta in double on the host, as torch.optim.Adam does with Python floats
+            hyper[t] = (lr / (1.0 - b1 ** k), b1, b2, 1.0 - b1, 1.0 - b2, eps, math.sqrt(1.0 - b2 ** k), 0.0)
+            table[t] = (p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel())
+            any_grad = True
         if not any_grad:
-            return loss
+            return
         dev = lay["params"][0].device
         tab_d = torch.from_numpy(table).to(dev, non_blocking=False)
         hyp_d = torch.from_numpy(hyper).to(dev, non_blocking=False)
@@ -103,4 +131,3 @@ class Adam(torch.optim.Optimizer):
         cur = torch.cuda.current_stream()
         for k in keep + [tab_d, hyp_d]:
             k.record_stream(cur)
-        return loss

@@ -26,7 +26,9 @@ pytestmark = pytest.mark.gpu
 
 def _net(synth_sd, kind, ori_noise, circular, precision):
     from ccvpe_amd import models
-    if ori_noise is None:
+    if kind == "kitti":
+        net = models.CVM_KITTI("cuda")
+    elif ori_noise is None:
         net = models.CVM_VIGOR("cuda", circular)
     else:
         net = models.CVM_VIGOR_ori_prior("cuda", ori_noise, circular)
@@ -56,11 +58,11 @@ def _check_alone(net, grd, sat, out, picks, rtol):
             assert float((a[0] - b[i]).abs().max()) <= max(rtol, 2e-5) * 10
 
 
-def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision):
+def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision, kind="vigor"):
     """Samples `picks` of the benched batch against the CPU oracle run on those samples alone."""
     idx = torch.tensor(list(picks))
     with torch.no_grad():
-        ref = O.forward(synth_sd("vigor", 0), grd[idx].cpu(), sat[idx].cpu(), "vigor", circular, ori_noise)
+        ref = O.forward(synth_sd(kind, 0), grd[idx].cpu(), sat[idx].cpu(), kind, circular, ori_noise)
     got = [t[idx.to(t.device)].cpu() for t in out]
     assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref]
     for j, i in enumerate(picks):
@@ -92,9 +94,11 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
 @pytest.mark.parametrize("name,ori_noise,circular,gshape,batch,precision,rtol", [
     ("C1 fp32 B=64", 0, True, "vigor", 64, "fp32", 1e-4),
     ("C2 bf16 B=32 N_rot=20", None, True, "vigor", 32, "bf16", 2e-2),
+    ("C3 model CVM_KITTI fp32 B=64 (eval)", None, False, "kitti", 64, "fp32", 1e-4),
 ])
 def test_batch_position_invariance_at_bench_size(synth_sd, name, ori_noise, circular, gshape, batch, precision, rtol):
-    net = _net(synth_sd, "vigor", ori_noise, circular, precision)
+    kind = "kitti" if gshape == "kitti" else "vigor"
+    net = _net(synth_sd, kind, ori_noise, circular, precision)
     grd, sat = synth.synthetic_pair(batch, gshape, 1234)
     grd, sat = grd.cuda(), sat.cuda()
     out = [t.clone() for t in net(grd, sat)]
@@ -108,7 +112,7 @@ def test_batch_position_invariance_at_bench_size(synth_sd, name, ori_noise, circ
     for k, (a, b) in enumerate(zip(out, out_p)):
         assert torch.equal(a[perm], b), "output %d of %s depends on the sample's position in the batch" % (k, name)
     _check_alone(net, grd, sat, out, (0, batch // 2 - 1, batch - 1), rtol)
-    _check_oracle(synth_sd, out, grd, sat, (0, batch // 2 - 1, batch - 1), circular, ori_noise, precision)
+    _check_oracle(synth_sd, out, grd, sat, (0, batch // 2 - 1, batch - 1), circular, ori_noise, precision, kind)
 
 
 def test_c4_graph_replay_at_b256_matches_eager_and_subbatch(synth_sd):

@@ -53,11 +53,11 @@ def test_conv_wgrad_at_benched_shapes(name, b, c0, c1, n, k, hw, tile, min_split
     assert torch.equal(got, again), "%s: two runs differ (a non-deterministic merge)" % name
 
 
-def _step(net, grd, sat, masks, center, angle):
+def _step(net, grd, sat, masks, center, angle, n_rot=20):
     from ccvpe_amd import losses, targets
     for p in net.parameters():
         p.grad = None
-    gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, 20)
+    gt, gt_flat, gt_ori, labels = targets.train_targets(center, angle, n_rot)
     out = net(grd, sat, drop_masks=masks)
     nce = 0.0
     for lvl in range(6):                                   # the loss mix of train_VIGOR.py:131-150, as bench.py times it
@@ -68,25 +68,29 @@ def _step(net, grd, sat, masks, center, angle):
     return float(loss.detach()), {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
 
 
-def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_sd):
+@pytest.mark.parametrize("kind", ["vigor", "kitti"])
+def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_sd, kind):
+    """kitti = BASELINE configs[3]'s own model and batch (CVM_KITTI, B = 64 per GPU): its shapes (2048-d aerial descriptor, the
+    88 -> 128 conv of level 3, a 256 x 1024 ground image, 16 orientation bins) take other tiles and split choices than VIGOR's."""
     from ccvpe_amd import models
     batch = 64
-    net = models.CVM_VIGOR("cuda", True)
-    net.load_state_dict(synth_sd("vigor", 0), strict=True)
+    n_rot = synth.MODEL_SPECS[kind]["n_rot"]
+    net = models.CVM_VIGOR("cuda", True) if kind == "vigor" else models.CVM_KITTI("cuda")
+    net.load_state_dict(synth_sd(kind, 0), strict=True)
     net = net.to("cuda:0").train()
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}          # running statistics are updated in place
-    grd, sat = synth.synthetic_pair(batch, "vigor", 1234)
+    grd, sat = synth.synthetic_pair(batch, kind, 1234)
     grd, sat = grd.cuda(), sat.cuda()
     u = synth.uniform((batch, 3), 99)
     center, angle = ((u[:, :2] - 0.5) * 384.0).cuda(), (u[:, 2] * 359.99).cuda()
     keys = [("%s_efficientnet" % e, i) for e in ("grd", "sat") for i in range(16)]
     masks = {k: (synth.uniform((batch,), 7000 + j) > 0.1).float().cuda() for j, k in enumerate(keys)}
 
-    loss_a, g_a = _step(net, grd, sat, masks, center, angle)
+    loss_a, g_a = _step(net, grd, sat, masks, center, angle, n_rot)
     assert loss_a == loss_a and abs(loss_a) < 1e9, "non-finite loss %r" % loss_a
     assert len(g_a) >= 500 and all(torch.isfinite(g).all() for g in g_a.values())
     net.load_state_dict(sd0, strict=True)
-    loss_b, g_b = _step(net, grd, sat, masks, center, angle)
+    loss_b, g_b = _step(net, grd, sat, masks, center, angle, n_rot)
     assert loss_a == loss_b
     for n in g_a:
         assert torch.equal(g_a[n], g_b[n]), "gradient of %s differs between two identical steps" % n
@@ -94,7 +98,7 @@ def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_s
     perm = torch.randperm(batch, generator=torch.Generator().manual_seed(5)).cuda()
     net.load_state_dict(sd0, strict=True)
     loss_p, g_p = _step(net, grd[perm].contiguous(), sat[perm].contiguous(), {k: v[perm].contiguous() for k, v in masks.items()},
-                        center[perm].contiguous(), angle[perm].contiguous())
+                        center[perm].contiguous(), angle[perm].contiguous(), n_rot)
     assert abs(loss_p - loss_a) <= 1e-5 * abs(loss_a), (loss_a, loss_p)
     top = max(float(g.norm()) for g in g_a.values())
     rels = []
@@ -107,7 +111,7 @@ def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_s
         rels.append((d / na, n))
     rels.sort(reverse=True)
     med = rels[len(rels) // 2][0]
-    print("B=64 training step: loss %.6f; relative gradient change under a batch permutation: median %.2e, worst five %s"
+    print(kind + " B=64 training step: loss %.6f; relative gradient change under a batch permutation: median %.2e, worst five %s"
           % (loss_a, med, [(n, "%.2e" % r) for r, n in rels[:5]]))
     assert med <= PERM_MEDIAN_RTOL and rels[0][0] <= PERM_WORST_RTOL, rels[:5]
 

@@ -54,6 +54,38 @@ assert calls1 == 3 and ok1, (calls1, ok1)
 assert set(got) == set(base) and len(got) >= 500
 for n in base:
     assert torch.equal(base[n], got[n]), n
+
+# Adam per gradient group inside the backward (attach(step_in_backward=True)): same parameters, bit for bit, as backward ->
+# reducer() -> optimizer.step(); the caller's step() afterwards must not update anything twice; two steps in a row
+from ccvpe_amd import optim
+def train2(in_backward):
+    c = G.TRAIN_CASE
+    torch.manual_seed(7)
+    net = models.CVM_VIGOR("cuda", c["circular"])
+    net.load_state_dict(synth.synthetic_state_dict(c["kind"], c["wseed"]), strict=True)
+    net = net.to(dev).train()
+    opt = optim.Adam(net.parameters(), lr=1e-4)
+    red = harness.GradientAllReducer(net.parameters()).attach(net, optimizer=opt, step_in_backward=in_backward)
+    grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+    masks, _, _ = G.train_drop_masks(c["batch"])
+    for it in range(2):
+        opt.zero_grad(set_to_none=True)
+        out = net(grd.cuda(), sat.cuda(), drop_masks=masks)
+        G.train_loss(out).backward()
+        red()
+        opt.step()
+    torch.cuda.synchronize()
+    steps = {float(opt.state[p]["step"]) for p in net.parameters() if p in opt.state and len(opt.state[p])}
+    return {n: p.detach().clone() for n, p in net.named_parameters()}, steps
+pa, sa = train2(False)
+pb, sb = train2(True)
+assert sa == {2.0} and sb == {2.0}, (sa, sb)
+moved = 0
+sd0 = synth.synthetic_state_dict(G.TRAIN_CASE["kind"], G.TRAIN_CASE["wseed"])
+for n in pa:
+    assert torch.equal(pa[n], pb[n]), n
+    moved += int(not torch.equal(pa[n], sd0[n].to(dev)))
+assert moved >= 500, moved
 dist.destroy_process_group()
 print("RCCL_SINGLE_RANK_OK", len(got))
 '''
