@@ -1,5 +1,6 @@
 // Narrow decoder levels, bf16 storage (narrow_impl.h): instantiations + dispatch.
 #include "narrow_impl.h"
+#include "tail2_impl.h"
 
 namespace ccvpe {
 
@@ -78,6 +79,27 @@ int up2_dispatch(const void* src0, const void* src1, const void* w, const float*
   if (id == 1) return launch_up2<11, 2, 3, 8>(q, batch, stream);
   if (id == 2) return launch_up2<8, 2, 2, 8>(q, batch, stream);
   return launch_up2<17, 2, 2, 8>(q, batch, stream);
+}
+
+// The 512 x 512 level (tail2_kernel): the bf16 orientation tail (32 channels -> 2 + F.normalize).  The kernel also exists for the
+// localisation tails — bf16 (48 -> 1) and fp32 operands as hi + lo planes — and is correct there (measured at B = 64: 445 vs 376 us
+// and 984 vs 639 us against tail512_kernel: at one wave per SIMD the ~1 400 non-matrix instructions per tile of the two epilogues,
+// the in-LDS hi / lo conversion and the softmax partials are not hidden by anything), so only the form that wins is dispatched:
+// 353 vs 393 us with two workgroups per CU.
+int tail2_supported(int is_bf16, int split, int cout, int c0, int ld0, int h1, int w1, int batch) {
+  if (!(is_bf16 && !split && c0 == 32 && cout == 2)) return 0;
+  if (h1 % 8 || w1 % 16 || w1 < 16 || ld0 % 8) return 0;
+  if ((long)batch * (h1 / 8) * (w1 / 16) < 2L * num_cus()) return 0;
+  return 1;
+}
+
+int tail2_dispatch(int id, const void* x, const void* w, const float* shift9, const float* w2, const float* b2, float* out, float* smx,
+                   int batch, int h1, int w1, int c0, int ld0, int kpad, int normalize, hipStream_t stream) {
+  Tail2Params q{};
+  q.x = x; q.w = w; q.shift9 = shift9; q.w2 = w2; q.b2 = b2; q.out = out; q.smx = smx;
+  q.H1 = h1; q.W1 = w1; q.c0 = c0; q.ld0 = ld0; q.Kpad = kpad; q.normalize = normalize;
+  if (id == 1) return launch_tail2<4, 2, false, 8>(q, batch, stream);
+  return fail(CCVPE_EINVAL, "tail2: unsupported layer");
 }
 
 }  // namespace ccvpe
