@@ -78,6 +78,8 @@ PROTOTYPES = {
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_set_narrow_kernels": (c_int, [c_int]),
+    "ccvpe_conv3x3_match1_ok": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
+    "ccvpe_conv3x3_match1_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_void_p]),
     "ccvpe_upconv3x3_f32": (c_int, [ctypes.POINTER(UpconvDesc), c_void_p]),

@@ -272,6 +272,8 @@ template <typename T> int conv3x3_dispatch(const IgemmParams& p, int batch, int 
 extern bool g_use_narrow;                                 // ccvpe_set_narrow_kernels (conv_igemm.hip)
 int c3n_supported(const IgemmParams& p, int batch);      // 0 = not served, else an instantiation id
 int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream);
+int c3n_match_supported(const IgemmParams& p, int batch, int L);
+int c3n_match_dispatch(const IgemmParams& p, int batch, const float* g, int ldg, int L, int off, float* scores, hipStream_t stream);
 int tail2_supported(int is_bf16, int split, int cout, int c0, int ld0, int h1, int w1, int batch);   // 0, or an instantiation id
 int tail2_dispatch(int id, const void* x, const void* w, const float* shift9, const float* w2, const float* b2, float* out, float* smx,
                    int batch, int h1, int w1, int c0, int ld0, int kpad, int normalize, hipStream_t stream);

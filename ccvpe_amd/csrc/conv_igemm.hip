@@ -340,9 +340,12 @@ extern "C" int ccvpe_set_narrow_kernels(int on) {
 // route (optional): filled with the kernel family + tile the dispatcher picks for `d` (CCVPE_ROUTE_* | MT << 8 | NT << 12 |
 // WN << 16) and NOTHING is launched — ccvpe_conv_igemm_route(); tests and bench.py's launch recorder read it instead of
 // mirroring the dispatch rules in Python
+// the next level's one-hypothesis matching fused into a 3x3 layer's epilogue (ccvpe_conv3x3_match1_bf16)
+struct MatchFuse { const float* g; int ldg, L, off; float* scores; bool query; };
+
 template <typename T>
 static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, float* scratch = nullptr,
-                          long* want_floats = nullptr, int* route = nullptr) {
+                          long* want_floats = nullptr, int* route = nullptr, const MatchFuse* mf = nullptr) {
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;
   if (!d) return fail(CCVPE_EINVAL, "conv_igemm: null desc");
@@ -387,6 +390,16 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   const TileCfg c = kCfgs[pick_cfg(p.Npad)];
   const bool is3x3 = d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 &&
                      d->out_mode == CCVPE_OUT_NHWC && !d->gate;
+  if (mf) {
+    if constexpr (sizeof(T) == 2) {
+      const bool ok = is3x3 && g_use_narrow && c3n_match_supported(p, d->batch, mf->L);
+      if (mf->query) return ok ? 1 : 0;
+      if (!ok) return fail(CCVPE_EINVAL, "conv3x3_match1: this layer / shape is not served (ask ccvpe_conv3x3_match1_ok first)");
+      return c3n_match_dispatch(p, d->batch, mf->g, mf->ldg, mf->L, mf->off, mf->scores, st);
+    } else {
+      return mf->query ? 0 : fail(CCVPE_EINVAL, "conv3x3_match1: bf16 storage only");
+    }
+  }
   // bf16 3x3 on images >= 16 columns wide with at least 128 halo tiles: the LDS-DMA 3x3 kernel UN-split beats the split-K gather
   // kernel + its second pass (tools/conv3_probe.py bf16, 16 x 16 images: B = 32 257 -> 166 us at 1344 -> 640 and 140 -> 82 us at
   // 640 -> 640, B = 16 equal, B = 8 slower), so the planning call reports "no split" there.  fp32 keeps the split (its 3x3 kernel
@@ -456,6 +469,22 @@ extern "C" int ccvpe_conv_igemm_route(const ccvpe_conv_desc* d, int is_bf16, int
   const int rc = is_bf16 ? conv_igemm_any<bf16_t>(d, nullptr, out_f32 ? 1 : 0, nullptr, nullptr, &route)
                          : conv_igemm_any<float>(d, nullptr, 1, nullptr, nullptr, &route);
   return rc ? rc : route;
+}
+static int match1_offset(int n, int shift, int stride, int window_offset) {
+  long o = (-((long)shift * stride + window_offset)) % n;      // match_any()'s offset (csrc/matching.hip)
+  return (int)(o < 0 ? o + n : o);
+}
+extern "C" int ccvpe_conv3x3_match1_ok(const ccvpe_conv_desc* d, int out_f32, int L) {
+  MatchFuse mf{nullptr, 0, L, 0, nullptr, true};
+  const int rc = conv_igemm_any<bf16_t>(d, nullptr, out_f32 ? 1 : 0, nullptr, nullptr, nullptr, &mf);
+  return rc < 0 ? 0 : rc;
+}
+extern "C" int ccvpe_conv3x3_match1_bf16(const ccvpe_conv_desc* d, int out_f32, const float* g, int ldg, int L, int shift, int stride,
+                                         int window_offset, float* scores, void* stream) {
+  if (!d || !g || !scores) return fail(CCVPE_EINVAL, "conv3x3_match1: null pointer");
+  if (L > ldg) return fail(CCVPE_EINVAL, "conv3x3_match1: L > ldg");
+  MatchFuse mf{g, ldg, L, match1_offset(d->n, shift, stride, window_offset), scores, false};
+  return conv_igemm_any<bf16_t>(d, stream, out_f32 ? 1 : 0, nullptr, nullptr, nullptr, &mf);
 }
 extern "C" int ccvpe_conv_igemm_splitk_bf16(const ccvpe_conv_desc* d, int out_f32, float* scratch, void* stream) {
   if (!scratch) return fail(CCVPE_EINVAL, "conv_igemm_splitk: scratch is NULL");

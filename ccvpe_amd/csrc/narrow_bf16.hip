@@ -35,6 +35,12 @@ int c3n_supported(const IgemmParams& p, int batch) {
   return id;
 }
 
+static int c3n_launch_id(int id, const NarrowParams& q, int batch, bool f32out, bool match, hipStream_t stream) {
+  if (id == 1) return launch_c3n<5, 3, 4>(q, batch, f32out, match, stream);
+  if (id == 2) return launch_c3n<4, 2, 4>(q, batch, f32out, match, stream);
+  return launch_c3n<8, 4, 4, false>(q, batch, f32out, match, stream);
+}
+
 int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream) {
   const int id = c3n_supported(p, batch);
   if (!id) return fail(CCVPE_EINVAL, "c3n: unsupported layer");
@@ -42,10 +48,33 @@ int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream) {
   q.src = p.src0; q.w = p.w; q.shift = p.shift; q.dst = p.dst;
   q.H = p.H; q.W = p.W; q.ld = p.ld0; q.N = p.N; q.Kpad = p.Kpad; q.ldd = p.ldd;
   q.act_floor = p.act == CCVPE_ACT_RELU ? 0.f : -__builtin_huge_valf();
-  const bool f32out = p.out_f32 != 0;
-  if (id == 1) return launch_c3n<5, 3, 4>(q, batch, f32out, stream);
-  if (id == 2) return launch_c3n<4, 2, 4>(q, batch, f32out, stream);
-  return launch_c3n<8, 4, 4>(q, batch, f32out, stream);
+  return c3n_launch_id(id, q, batch, p.out_f32 != 0, false, stream);
+}
+
+// 3x3 conv + the next level's one-hypothesis matching in its epilogue (c3n_kernel<MATCH>).  `p` describes the conv with dst = the
+// decoder input rows (pitch p.ldd >= N + 1, a multiple of 8) — c3n_supported() is asked about the conv alone (ldd = N).
+int c3n_match_supported(const IgemmParams& p, int batch, int L) {
+  IgemmParams c = p;
+  c.ldd = p.out_f32 ? (p.N + 3) / 4 * 4 : (p.N + 7) / 8 * 8;
+  const int id = c3n_supported(c, batch);
+  if (!id || id == 3) return 0;                               // (64 channels: 4 column tiles + tables do not fit the register budget: not built)
+  const int nt = id == 1 ? 3 : 2;
+  if (p.N % 4 || p.ldd < p.N + 1 || p.ldd > 16 * nt || p.ldd % (p.out_f32 ? 4 : 8) || L < 1 || L > p.N) return 0;
+  if (p.act != CCVPE_ACT_NONE) return 0;
+  const int lds = (id == 1 ? C3nGeom<5, 3, 4>::LDS_BYTES : C3nGeom<4, 2, 4>::LDS_BYTES) + batch * (2 * 16 * nt + 1) * 4;
+  if (lds > 160 * 1024) return 0;
+  return id;
+}
+
+int c3n_match_dispatch(const IgemmParams& p, int batch, const float* g, int ldg, int L, int off, float* scores, hipStream_t stream) {
+  const int id = c3n_match_supported(p, batch, L);
+  if (!id) return fail(CCVPE_EINVAL, "conv3x3_match1: unsupported layer / shape");
+  NarrowParams q{};
+  q.src = p.src0; q.w = p.w; q.shift = p.shift; q.dst = p.dst;
+  q.H = p.H; q.W = p.W; q.ld = p.ld0; q.N = p.N; q.Kpad = p.Kpad; q.ldd = p.ldd;
+  q.act_floor = -__builtin_huge_valf();
+  q.g = g; q.ldg = ldg; q.L = L; q.off = off; q.scores = scores;
+  return c3n_launch_id(id, q, batch, p.out_f32 != 0, true, stream);
 }
 
 // Folded deconv + 3x3 on the narrow levels (up2_kernel): level 2 of the localisation decoder (81 -> 40 | 16 skip channels),

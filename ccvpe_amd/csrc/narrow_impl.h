@@ -134,6 +134,12 @@ struct NarrowParams {
   void* dst;           // [B,H,W,ldd] bf16 or fp32
   int H, W, ld, N, Kpad, ldd;
   float act_floor;     // 0 for ReLU, -inf for none: v = max(v, act_floor)
+  // MATCH (c3n_kernel<..., MATCH = true>): the NEXT level's rotational matching for ONE rotation hypothesis in this layer's epilogue
+  // (models.py:186-205 pattern with a single shift: CVM_VIGOR_ori_prior(0)).  dst then receives the decoder input rows
+  // [x / max(|x|, 1e-12) (N channels) | score | 0-pad] of pitch ldd, `scores` the [B,1,H,W] score volume.
+  const float* g;      // [B][ldg] ground descriptor of the level (first L entries)
+  float* scores;
+  int ldg, L, off, batch;   // off = (-shift * stride - window_offset) mod N: window channel c of x meets g[(c + off) mod N]
   TileIndex ti;
   int ablate;          // diagnostics builds only (-DCCVPE_ABLATE, tools/gpu/ablate_narrow.sh): 1 = no halo requests after the first two tiles,
                        // 2 = no epilogue stores, 4 = no matrix instructions, 8 = no fragment reads, 16 = no barrier / DMA wait
@@ -150,7 +156,11 @@ struct C3nGeom {
   static constexpr int NCH = (9 * CPT + 3) / 4;                // 32-wide k-steps
 };
 
-template <int CPT, int NT, int MT, bool F32OUT>
+// LDS behind the two halo buffers of c3n_kernel<MATCH>: per sample, in this kernel's QUAD order, [16 NT] descriptor values
+// g[(c + off) mod N] (0 outside the window), [16 NT] window indicators, then |g| per sample
+template <int NT> constexpr int match_tab_floats(int batch) { return batch * (2 * 16 * NT + 1); }
+
+template <int CPT, int NT, int MT, bool F32OUT, bool MATCH = false>
 __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   using G = C3nGeom<CPT, NT, MT>;
   constexpr int HC = G::HC, NCH = G::NCH, NDMA = G::NDMA, PP = G::PP;
@@ -208,6 +218,24 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)nsm;
   const int Hs = sgpr(p.H), Ws = sgpr(p.W), lds_ = sgpr(p.ld);
+  float* mtab = reinterpret_cast<float*>(nsm + G::LDS_BYTES);  // MATCH: [batch][2][16 NT] tables, then [batch] |g|
+  if constexpr (MATCH) {
+    const int C = p.N;
+    for (int e = tid; e < p.batch * 16 * NT; e += 256) {
+      const int b = e / (16 * NT), rem = e - b * (16 * NT);      // rem = (n * 4 + q) * 4 + r
+      const int ch = chan_of_quad(rem >> 4, (rem >> 2) & 3) + (rem & 3);
+      int k = ch + p.off;
+      k = k >= C ? k - C : k;
+      const bool in = ch < C && k < p.L;
+      mtab[(b * 2 + 0) * 16 * NT + rem] = in ? p.g[(size_t)b * p.ldg + k] : 0.f;
+      mtab[(b * 2 + 1) * 16 * NT + rem] = in ? 1.f : 0.f;
+    }
+    for (int b = tid; b < p.batch; b += 256) {
+      float s = 0.f;
+      for (int k = 0; k < p.L; ++k) { const float v = p.g[(size_t)b * p.ldg + k]; s = fmaf(v, v, s); }
+      mtab[p.batch * 2 * 16 * NT + b] = sqrtf(s);
+    }
+  }
 
   auto stage = [&](int t, int buf) {                         // request tile t's halo into buffer `buf`
     int b, ty, tx;
@@ -273,6 +301,16 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
     int b, ty, tx;
     tile_decode(p.ti, t, b, ty, tx);
     const size_t pix0 = ((size_t)(b * Hs + ty * G::TH + wave * MT) * Ws + tx * 16 + f);
+    f32x4 gq[NT], wq[NT];
+    float gnorm = 1.f;
+    if constexpr (MATCH) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        gq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 0) * 16 * NT + (n * 4 + q) * 4);
+        wq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 1) * 16 * NT + (n * 4 + q) * 4);
+      }
+      gnorm = mtab[p.batch * 2 * 16 * NT + b];
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
       f32x4 v[NT];
@@ -282,12 +320,38 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
       }
+      if constexpr (MATCH) {
+        // this lane holds 4 NT of the pixel's channels (the lanes f, f + 16, f + 32, f + 48 share a pixel; channels >= N are exact
+        // zeros: zero weight rows, zero bias).  |x|^2, the window's |.|^2 and the dot product with the rolled descriptor: partial
+        // sums here, combined over the four lanes (fixed order); then exactly match_kernel's formulas (no eps in the cosine).
+        float s2 = 0.f, wn = 0.f, dt = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float x2 = v[n][r] * v[n][r];
+            s2 += x2;
+            wn = fmaf(x2, wq[n][r], wn);
+            dt = fmaf(v[n][r], gq[n][r], dt);
+          }
+        s2 += __shfl_xor(s2, 16, 64); wn += __shfl_xor(wn, 16, 64); dt += __shfl_xor(dt, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64); wn += __shfl_xor(wn, 32, 64); dt += __shfl_xor(dt, 32, 64);
+        const float inv = 1.0f / fmaxf(sqrtf(s2), 1e-12f);
+        const float score = dt / (sqrtf(wn) * gnorm);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          const int ch = chan_of_quad(n, q);
+          if (ch < p.N) v[n] *= inv;
+          else v[n] = (f32x4){ch == p.N ? score : 0.f, 0.f, 0.f, 0.f};          // [max score | 0-pad] (N % 4 == 0)
+        }
+        if (q == 0 && !(abl & 2)) p.scores[pix0 + (size_t)i * Ws] = score;         // [B,1,H,W]
+      }
       if (abl & 2) {
 #pragma unroll
         for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
         continue;
       }
-      store_row<NT, F32OUT>(p.dst, (pix0 + (size_t)i * Ws) * p.ldd, v, q, p.N);
+      store_row<NT, F32OUT>(p.dst, (pix0 + (size_t)i * Ws) * p.ldd, v, q, MATCH ? p.ldd : p.N);
     }
   };
   auto tile_end = [&]() {                                     // this wave's halo requests have landed + everyone is done reading
@@ -323,23 +387,31 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 
 int num_cus();   // narrow_bf16.hip
 
-template <int CPT, int NT, int MT>
-static int launch_c3n(NarrowParams p, int batch, bool f32out, hipStream_t stream) {
+template <int CPT, int NT, int MT, bool WITH_MATCH = true>
+static int launch_c3n(NarrowParams p, int batch, bool f32out, bool match, hipStream_t stream) {
   using G = C3nGeom<CPT, NT, MT>;
   const int tiles_x = p.W / 16, tiles_y = p.H / G::TH;
   const long total = (long)tiles_x * tiles_y * batch;
   if (total > 0x7fffffffL || total * (tiles_x > tiles_y ? tiles_x : tiles_y) >= (1L << 32)) return fail(CCVPE_EINVAL, "c3n: grid too large");
   p.ti = make_tile_index(tiles_x, tiles_y, (int)total);
   p.ablate = narrow_ablate_env();
-  static bool attr_set[2] = {false, false};
-  auto kern = f32out ? c3n_kernel<CPT, NT, MT, true> : c3n_kernel<CPT, NT, MT, false>;
-  if (!attr_set[f32out]) {
-    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS_BYTES);
+  p.batch = batch;
+  const int lds = G::LDS_BYTES + (match ? match_tab_floats<NT>(batch) * 4 : 0);
+  if (lds > 160 * 1024) return fail(CCVPE_EINVAL, "c3n: batch %d needs %d B of LDS for the matching tables", batch, lds);
+  void (*kern)(const NarrowParams) = f32out ? c3n_kernel<CPT, NT, MT, true, false> : c3n_kernel<CPT, NT, MT, false, false>;
+  if (match) {
+    if constexpr (WITH_MATCH) kern = f32out ? c3n_kernel<CPT, NT, MT, true, true> : c3n_kernel<CPT, NT, MT, false, true>;
+    else return fail(CCVPE_EINVAL, "c3n: the matching epilogue is not built for this tile");
+  }
+  static int attr_lds[4] = {0, 0, 0, 0};
+  const int slot = (match ? 2 : 0) + (f32out ? 1 : 0);
+  if (attr_lds[slot] < lds) {
+    hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "c3n_kernel: set smem attr: %s", hipGetErrorString(e));
-    attr_set[f32out] = true;
+    attr_lds[slot] = lds;
   }
   const int grid = (int)(total < num_cus() ? total : num_cus());
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), G::LDS_BYTES, stream, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, p);
   return check_launch("c3n_kernel");
 }
 

@@ -166,6 +166,8 @@ SPLIT_TAIL = __import__("os").environ.get("CCVPE_SPLIT_TAIL", "1") != "0"
 PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
 # train mode, fp32: the per-step re-pack as ONE gather launch (ccvpe_amd/repack.py); CCVPE_PACK_GATHER=0 keeps the graph replay
 PACK_GATHER = __import__("os").environ.get("CCVPE_PACK_GATHER", "1") != "0"
+# one-hypothesis matching of level j + 1 inside level j's last conv (bf16 narrow levels); CCVPE_FUSE_MATCH=0 = separate launches (A/B runs)
+FUSE_MATCH = __import__("os").environ.get("CCVPE_FUSE_MATCH", "1") != "0"
 # eval forward: CCVPE_EVAL_TWO_STREAMS=0 runs the ground encoder on the main stream too (for per-kernel profiles in which no
 # two kernels share the chip; the default overlaps the two encoders)
 EVAL_TWO_STREAMS = __import__("os").environ.get("CCVPE_EVAL_TWO_STREAMS", "1") != "0"
@@ -635,6 +637,7 @@ class _CVMBase(nn.Module):
 
             overlap = _overlap_decoders(self.precision)
             loc_shifts = self._loc_shifts()
+            fused = None
             scores_out = []
             smx = None
             x = sdesc
@@ -662,8 +665,12 @@ class _CVMBase(nn.Module):
                     n_tail = n_rot
                 else:
                     shifts, n_max, n_tail = loc_shifts, len(loc_shifts), 0
-                sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c,
-                                          window_offset=window_offset(self.kind, lv.c, L))
+                if fused is not None:                # the previous level's last conv already produced this level's (scores, cat)
+                    sc, cat = fused
+                    fused = None
+                else:
+                    sc, cat = ops.match_level(x, g, L, shifts, n_max, n_tail, strides[j], lv.ldo, channels=lv.c,
+                                              window_offset=window_offset(self.kind, lv.c, L))
                 if j == 0:
                     cat6 = cat
                     scores_out.append(sc if self.ori_noise is None else sc[:, n_max:])
@@ -695,9 +702,21 @@ class _CVMBase(nn.Module):
                     y = _double_conv(lv, up, skip, batch, 2 * hw)
                 if j < 5:
                     # the level feeding the fp32 tail writes its output in fp32 directly (no separate widening pass)
-                    x = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
-                                       kh=3, kw=3, pad=1, shift=lv.b_b,
-                                       out_f32=(j + 1 == pk.f32_from and y.dtype != torch.float32))
+                    to_f32 = j + 1 == pk.f32_from and y.dtype != torch.float32
+                    nxt = pk.loc[j + 1]
+                    L_n = gw * spec["cd"][j + 1]
+                    if (FUSE_MATCH and len(loc_shifts) == 1 and
+                            ops.conv3x3_match1(y, lv.n_a, lv.w_b, lv.n_b, None, L_n, loc_shifts[0], strides[j + 1], nxt.ldo, batch=batch,
+                                               in_h=2 * hw, in_w=2 * hw, bias=lv.b_b, out_f32=to_f32, query_only=True)):
+                        # one rotation hypothesis (ori_prior(0)): the next level's matching rides in this conv's epilogue
+                        # (bf16 narrow levels: csrc/narrow_impl.h c3n_kernel<MATCH>); x itself is never written
+                        fused = ops.conv3x3_match1(y, lv.n_a, lv.w_b, lv.n_b, gdesc[:, goff:goff + L_n], L_n, loc_shifts[0],
+                                                   strides[j + 1], nxt.ldo, batch=batch, in_h=2 * hw, in_w=2 * hw, bias=lv.b_b,
+                                                   window_offset=window_offset(self.kind, nxt.c, L_n), out_f32=to_f32)
+                        x = fused[1]                 # (only its shape is read at the top of the next level)
+                    else:
+                        x = ops.conv_igemm(y, lv.n_a, lv.w_b, lv.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
+                                           kh=3, kw=3, pad=1, shift=lv.b_b, out_f32=to_f32)
                 else:
                     logits_map = ops.head_conv3x3(y, lv.w_b, lv.b_b, 1, False)      # [B,1,512,512]
             logits = logits_map.reshape(batch, -1)                                   # models.py:319

@@ -405,6 +405,47 @@ def ground_descriptor(y1, wh, bh, cd):
     return out
 
 
+def conv3x3_match1(src0, c0, w_packed, n, g, L, shift, stride, ldo, *, batch, in_h, in_w, bias, window_offset=0, out_f32=False,
+                   query_only=False):
+    """convK.2 (3x3, bias, no activation) of a decoder level WITH the next level's one-hypothesis matching in its epilogue
+    (ccvpe_conv3x3_match1_bf16, csrc/narrow_impl.h c3n_kernel<MATCH>): returns (scores [B,1,H,W] fp32, cat [B,H,W,ldo] bf16 / fp32)
+    = what conv_igemm(...) followed by match_level(x, g, L, [shift], 1, 0, stride, ldo) returns; x is never written.
+    query_only: True / False — does the library serve this layer and shape (else the caller runs the two ops)."""
+    lib = _lib.load()
+    dt = _act_dtype(src0)
+    if dt != torch.bfloat16:
+        if query_only:
+            return False
+        raise ValueError("conv3x3_match1: bf16 storage only")
+    _chk(src0, "src0", dt)
+    _chk(w_packed, "w", dt)
+    _chk(bias, "bias")
+    d = ConvDesc()
+    d.src0, d.src1, d.gate, d.w = _ptr(src0), None, None, _ptr(w_packed)
+    d.scale, d.shift, d.residual = None, _ptr(bias), None
+    d.c0, d.ld0, d.c1, d.ld1 = c0, src0.shape[-1], 0, 0
+    d.batch, d.in_h, d.in_w = batch, in_h, in_w
+    d.kh, d.kw, d.stride, d.pad = 3, 3, 1, 1
+    d.n, d.kpad, d.ldd, d.ldres = n, w_packed.shape[1], ldo, 0
+    d.act, d.out_mode = ACT_NONE, OUT_NHWC
+    if query_only:
+        return lib.ccvpe_conv3x3_match1_ok(ctypes.byref(d), int(bool(out_f32)), L) == 1
+    if not g.is_cuda or g.dtype != torch.float32 or g.stride(-1) != 1:
+        raise ValueError("g must be an fp32 device tensor with unit inner stride")
+    scores = _empty((batch, 1, in_h, in_w), device=src0.device, dtype=torch.float32)
+    cat = _empty((batch, in_h, in_w, ldo), device=src0.device, dtype=torch.float32 if out_f32 else dt)
+    d.dst = _ptr(cat)
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
+    check(lib.ccvpe_conv3x3_match1_bf16(ctypes.byref(d), int(bool(out_f32)), _ptr(g), g.stride(0), L, int(shift), int(stride),
+                                        int(window_offset), _ptr(scores), _stream()), "ccvpe_conv3x3_match1_bf16")
+    if rec is not None:
+        m = batch * in_h * in_w
+        rec.end("c3n_kernel<bf16,%d,match>" % n, "3x3+match M%d N%d K%d" % (m, n, 9 * c0), 2.0 * m * n * 9 * c0,
+                2.0 * m * c0 + (4.0 if out_f32 else 2.0) * m * ldo + 4.0 * m + 2.0 * n * 9 * c0, ev0)
+    return scores, cat
+
+
 def match_level(x, g, L, shifts, n_max, n_tail, stride, ldo, channels=None, window_offset=0):
     """Fused rotational matching.  x [B,H,W,ldx]; g [B,ldg] view with row stride ldg.
     Returns (scores [B,n_shifts,H,W], dstx [B,H,W,ldo])."""

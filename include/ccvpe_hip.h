@@ -105,6 +105,16 @@ int ccvpe_conv_igemm_route(const ccvpe_conv_desc* desc, int is_bf16, int out_f32
 /* A/B switch for measurements (process-wide, default on): 0 sends the narrow bf16 decoder layers (CCVPE_ROUTE_C3N, and the
  * narrow form of ccvpe_upconv3x3_bf16) back to the tiled kernels.  Returns the previous setting. */
 int ccvpe_set_narrow_kernels(int on);
+/* A 3x3 layer (desc: bf16 storage, one source, bias, no activation — convK.2 of double_conv, models.py:42-47) WITH the next
+ * level's rotational matching in its epilogue, for ONE rotation hypothesis (the localisation branch of CVM_VIGOR_ori_prior(0):
+ * models.py:489-500 with k = 0): replaces  x = convK.2(y);  scores, cat = match(x)  (models.py:211-228 pattern) — x never reaches
+ * HBM.  desc->n = channels of x, desc->dst / ldd = the decoder input rows [x / max(|x|, 1e-12) | score | 0-pad] (ldd >= n + 1;
+ * bf16, or fp32 with out_f32), scores [B,1,H,W] fp32; g [B][ldg] fp32 ground descriptor (first L entries), shift / stride /
+ * window_offset as ccvpe_match_level.  Same formulas as ccvpe_match_level (no eps in the cosine).  _ok: 1 if the library serves
+ * this layer / shape (narrow-level kernel, csrc/narrow_impl.h), else 0 — then run the two calls separately. */
+int ccvpe_conv3x3_match1_ok(const ccvpe_conv_desc* desc, int out_f32, int L);
+int ccvpe_conv3x3_match1_bf16(const ccvpe_conv_desc* desc, int out_f32, const float* g, int ldg, int L, int shift, int stride,
+                              int window_offset, float* scores, void* stream);
 int ccvpe_conv_igemm_splitk_f32(const ccvpe_conv_desc* desc, float* scratch, void* stream);
 
 /* -------------------------------------------------------------------------------------------

@@ -134,6 +134,37 @@ def test_narrow_conv3x3_weights_in_registers(ops, c, cout, hw, b, act, f32out):
     close(nchw(got), nchw(ref).float().cpu(), 1e-2 if not f32out else 1e-5, "narrow vs tiled 3x3")
 
 
+@pytest.mark.parametrize("c,hw,b,L,shift,stride,f32out", [(40, 256, 2, 40, 0, 2, True), (40, 256, 3, 40, 0, 2, False),
+                                                          (40, 256, 2, 20, -3, 2, True), (40, 256, 2, 33, 7, 4, False)])
+def test_narrow_conv3x3_with_the_next_levels_matching_in_its_epilogue(ops, c, hw, b, L, shift, stride, f32out):
+    """ccvpe_conv3x3_match1_bf16 == ccvpe_conv_igemm_bf16 (convK.2) followed by ccvpe_match_level with one rotation hypothesis
+    (models.py:211-228 with a single shift): scores and decoder-input rows, full and partial windows, a rolled window, fp32 and
+    bf16 rows; and against the oracle's rotational_matching on the CPU convolution."""
+    a = r(synth.normal((b, c, hw, hw), 20 + c))
+    wt = r(synth.normal((c, c, 3, 3), 22, (1.0 / (9 * c)) ** 0.5))
+    bias = synth.normal((c,), 23, 0.1)
+    g = synth.normal((b, L + 8), 24)
+    ldo = (c + 1 + 7) // 8 * 8
+    x_ref = F.conv2d(a, wt, bias, padding=1)
+    sc_ref = O.rotational_matching(x_ref, g[:, :L], [shift], stride)                       # [B,1,H,W]
+    xd, wp, bd, gd = dev(nhwc(a)), dev(pack(wt)), dev(bias, torch.float32), dev(g, torch.float32)
+    kw = dict(batch=b, in_h=hw, in_w=hw, bias=bd, out_f32=f32out)
+    assert ops.conv3x3_match1(xd, c, wp, c, None, L, shift, stride, ldo, query_only=True, **kw)
+    sc, cat = ops.conv3x3_match1(xd, c, wp, c, gd[:, :L], L, shift, stride, ldo, **kw)
+    assert tuple(sc.shape) == (b, 1, hw, hw) and tuple(cat.shape) == (b, hw, hw, ldo) and cat.dtype == (torch.float32 if f32out else BF)
+    assert float((sc.cpu() - sc_ref).abs().max()) <= 2e-5 + 2e-6 * c
+    xn = x_ref / x_ref.norm(dim=1, keepdim=True).clamp_min(1e-12)
+    tol = 1e-5 if f32out else 1e-2
+    close(nchw(cat[..., :c]), xn, tol, "fused: normalised x")
+    assert float((cat[..., c].float().cpu() - sc_ref[:, 0]).abs().max()) <= (2e-5 + 2e-6 * c if f32out else 1e-2)
+    assert float(cat[..., c + 1:].float().abs().max()) == 0.0
+    # the two separate launches on the same operands
+    x2 = ops.conv_igemm(xd, c, wp, c, batch=b, in_h=hw, in_w=hw, kh=3, kw=3, pad=1, shift=bd, out_f32=f32out)
+    sc2, cat2 = ops.match_level(x2, gd[:, :L], L, [shift], 1, 0, stride, ldo, channels=c)
+    assert float((sc - sc2).abs().max()) <= (1e-5 if f32out else 1e-2)                   # (bf16 rows: x is rounded before the matching there)
+    close(cat.float().cpu(), cat2.float().cpu(), 1e-5 if f32out else 1.2e-2, "fused vs conv + match_level")
+
+
 def test_igemm_bf16_2x2s2_and_deconv(ops):
     from ccvpe_amd.models import _pack_deconv
     b, c, n = 2, 64, 48
