@@ -778,7 +778,8 @@ def main():
                 net4.load_state_dict(sdk, strict=True)
                 net4 = net4.to(dev)
                 g4, s4 = synth.synthetic_pair(args.batch, "kitti", 1234 + rank)
-                ent, m4 = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, 5, 3, rank, world, 16, record,
+                dp_steps, dp_warm = (int(v) for v in os.environ.get("CCVPE_BENCH_DP_STEPS", "5,3").split(","))    # (tests shorten it)
+                ent, m4 = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, dp_steps, dp_warm, rank, world, 16, record,
                                       tag="train_dp_kitti_b64")
                 coll = collective_info(dev, m4, world)
                 if coll["ranks_counted_by_allreduce"] != world:

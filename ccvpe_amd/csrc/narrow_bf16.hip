@@ -38,7 +38,7 @@ int c3n_supported(const IgemmParams& p, int batch) {
 static int c3n_launch_id(int id, const NarrowParams& q, int batch, bool f32out, bool match, hipStream_t stream) {
   if (id == 1) return launch_c3n<5, 3, 4>(q, batch, f32out, match, stream);
   if (id == 2) return launch_c3n<4, 2, 4>(q, batch, f32out, match, stream);
-  return launch_c3n<8, 4, 4, false>(q, batch, f32out, match, stream);
+  return launch_c3n<8, 4, 4, false, false>(q, batch, f32out, match, stream);
 }
 
 int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream) {

@@ -160,7 +160,9 @@ struct C3nGeom {
 // g[(c + off) mod N] (0 outside the window), [16 NT] window indicators, then |g| per sample
 template <int NT> constexpr int match_tab_floats(int batch) { return batch * (2 * 16 * NT + 1); }
 
-template <int CPT, int NT, int MT, bool F32OUT, bool MATCH = false>
+// ILV: the previous tile's epilogue interleaved with this tile's matrix work (needs a second accumulator set; the 64-channel tile
+// has no registers left for it)
+template <int CPT, int NT, int MT, bool F32OUT, bool MATCH = false, bool ILV = true>
 __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   using G = C3nGeom<CPT, NT, MT>;
   constexpr int HC = G::HC, NCH = G::NCH, NDMA = G::NDMA, PP = G::PP;
@@ -263,14 +265,81 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
     }
   };
 
-  f32x4 acc[MT][NT];
-  auto compute = [&](auto buf_tag) {
+  // ---- epilogue of ONE pixel row (lane = pixel column f of row i of tile (b, ty, tx)); see run_tile for where it is issued ----------
+  struct EpiCtx { size_t pix0; f32x4 gq[NT], wq[NT]; float gnorm; };
+  auto epi_ctx = [&](int t, EpiCtx& c) {
+    int b, ty, tx;
+    tile_decode(p.ti, t, b, ty, tx);
+    c.pix0 = ((size_t)(b * Hs + ty * G::TH + wave * MT) * Ws + tx * 16 + f);
+    c.gnorm = 1.f;
+    if constexpr (MATCH) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        c.gq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 0) * 16 * NT + (n * 4 + q) * 4);
+        c.wq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 1) * 16 * NT + (n * 4 + q) * 4);
+      }
+      c.gnorm = mtab[p.batch * 2 * 16 * NT + b];
+    }
+  };
+  auto epi_row = [&](const EpiCtx& c, int i, const f32x4* accrow) {
+    f32x4 v[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      v[n] = accrow[n] + bias[n];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
+    }
+    if constexpr (MATCH) {
+      // this lane holds 4 NT of the pixel's channels (the lanes f, f + 16, f + 32, f + 48 share a pixel; channels >= N are exact
+      // zeros: zero weight rows, zero bias).  |x|^2, the window's |.|^2 and the dot product with the rolled descriptor: partial
+      // sums here, combined over the four lanes (fixed order); then exactly match_kernel's formulas (no eps in the cosine).
+      float s2 = 0.f, wn = 0.f, dt = 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float x2 = v[n][r] * v[n][r];
+          s2 += x2;
+          wn = fmaf(x2, c.wq[n][r], wn);
+          dt = fmaf(v[n][r], c.gq[n][r], dt);
+        }
+      s2 += __shfl_xor(s2, 16, 64); wn += __shfl_xor(wn, 16, 64); dt += __shfl_xor(dt, 16, 64);
+      s2 += __shfl_xor(s2, 32, 64); wn += __shfl_xor(wn, 32, 64); dt += __shfl_xor(dt, 32, 64);
+      const float inv = 1.0f / fmaxf(sqrtf(s2), 1e-12f);
+      const float score = dt / (sqrtf(wn) * c.gnorm);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const int ch = chan_of_quad(n, q);
+        if (ch < p.N) v[n] *= inv;
+        else v[n] = (f32x4){ch == p.N ? score : 0.f, 0.f, 0.f, 0.f};          // [max score | 0-pad] (N % 4 == 0)
+      }
+      if (q == 0 && !(abl & 2)) p.scores[c.pix0 + (size_t)i * Ws] = score;       // [B,1,H,W]
+    }
+    if (abl & 2) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
+      return;
+    }
+    store_row<NT, F32OUT>(p.dst, (c.pix0 + (size_t)i * Ws) * p.ldd, v, q, MATCH ? p.ldd : p.N);
+  };
+
+  // ---- one tile: the matrix work of tile s (halo buffer s & 1, accumulator set s & 1) with the EPILOGUE OF TILE s - 1 interleaved:
+  // row i of the previous tile's results (other accumulator set) is converted and stored in the same scheduling region as the matrix
+  // instructions of k-step i, one matrix instruction : a few vector instructions (sched_group_barrier).  At one wave per SIMD nothing
+  // else can fill the issue slots beside a matrix instruction; run back to back, the ~300 instructions of an epilogue cost as much
+  // as a third of the tile's matrix work (ablation: 83 of 216 us with every memory operation and matrix instruction removed). ---------
+  f32x4 acc[ILV ? 2 : 1][MT][NT];
+  auto run_tile = [&](auto buf_tag, auto prev_tag, int tprev) {
     constexpr int BUF = decltype(buf_tag)::value;
+    constexpr bool PREV = decltype(prev_tag)::value;
+    constexpr int SET = ILV ? BUF : 0, OTHER = ILV ? (BUF ^ 1) : 0;
     const char* hb = nsm + BUF * G::BUF_BYTES;
+    EpiCtx ctx;
+    if constexpr (PREV) epi_ctx(tprev, ctx);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int n = 0; n < NT; ++n) acc[SET][i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 a[2][MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) a[0][i] = *reinterpret_cast<const f32x4*>(hb + aoff[0] + i * (HC * XP));
@@ -290,69 +359,26 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[i][n]);
+          for (int n = 0; n < NT; ++n) acc[SET][i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[SET][i][n]);
+      }
+      if constexpr (PREV) {
+        if (j < MT) {
+          epi_row(ctx, j, acc[OTHER][j]);
+#pragma unroll
+          for (int m = 0; m < MT * NT; ++m) {                 // 1 matrix instruction : 6 vector instructions, stores / LDS ops wherever they fall
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
   };
-  // ---- epilogue: lane = pixel column f of row i.  Runs AFTER the tile's closing barrier and the next halo request: its stores are
-  // in flight under the next tile's matrix work instead of being waited for at the barrier -----------------------------------------
-  auto epilogue = [&](int t) {
-    int b, ty, tx;
-    tile_decode(p.ti, t, b, ty, tx);
-    const size_t pix0 = ((size_t)(b * Hs + ty * G::TH + wave * MT) * Ws + tx * 16 + f);
-    f32x4 gq[NT], wq[NT];
-    float gnorm = 1.f;
-    if constexpr (MATCH) {
+  auto epilogue = [&](int t, int set) {                       // the last tile of this workgroup: nothing left to hide it under
+    EpiCtx ctx;
+    epi_ctx(t, ctx);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        gq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 0) * 16 * NT + (n * 4 + q) * 4);
-        wq[n] = *reinterpret_cast<const f32x4*>(mtab + (b * 2 + 1) * 16 * NT + (n * 4 + q) * 4);
-      }
-      gnorm = mtab[p.batch * 2 * 16 * NT + b];
-    }
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      f32x4 v[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        v[n] = acc[i][n] + bias[n];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
-      }
-      if constexpr (MATCH) {
-        // this lane holds 4 NT of the pixel's channels (the lanes f, f + 16, f + 32, f + 48 share a pixel; channels >= N are exact
-        // zeros: zero weight rows, zero bias).  |x|^2, the window's |.|^2 and the dot product with the rolled descriptor: partial
-        // sums here, combined over the four lanes (fixed order); then exactly match_kernel's formulas (no eps in the cosine).
-        float s2 = 0.f, wn = 0.f, dt = 0.f;
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const float x2 = v[n][r] * v[n][r];
-            s2 += x2;
-            wn = fmaf(x2, wq[n][r], wn);
-            dt = fmaf(v[n][r], gq[n][r], dt);
-          }
-        s2 += __shfl_xor(s2, 16, 64); wn += __shfl_xor(wn, 16, 64); dt += __shfl_xor(dt, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64); wn += __shfl_xor(wn, 32, 64); dt += __shfl_xor(dt, 32, 64);
-        const float inv = 1.0f / fmaxf(sqrtf(s2), 1e-12f);
-        const float score = dt / (sqrtf(wn) * gnorm);
-#pragma unroll
-        for (int n = 0; n < NT; ++n) {
-          const int ch = chan_of_quad(n, q);
-          if (ch < p.N) v[n] *= inv;
-          else v[n] = (f32x4){ch == p.N ? score : 0.f, 0.f, 0.f, 0.f};          // [max score | 0-pad] (N % 4 == 0)
-        }
-        if (q == 0 && !(abl & 2)) p.scores[pix0 + (size_t)i * Ws] = score;         // [B,1,H,W]
-      }
-      if (abl & 2) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
-        continue;
-      }
-      store_row<NT, F32OUT>(p.dst, (pix0 + (size_t)i * Ws) * p.ldd, v, q, MATCH ? p.ldd : p.N);
-    }
+    for (int i = 0; i < MT; ++i) epi_row(ctx, i, (ILV && set) ? acc[ILV ? 1 : 0][i] : acc[0][i]);
   };
   auto tile_end = [&]() {                                     // this wave's halo requests have landed + everyone is done reading
     if (abl & 16) return;
@@ -360,8 +386,8 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
     __syncthreads();
   };
 
-  // tile t computes from buffer (t's position in this workgroup's sequence) & 1; the halo of tile s+1 is requested right after the
-  // barrier that ends tile s-1's reads of that buffer, i.e. a whole tile of matrix work before it is needed
+  // tile s of this workgroup's sequence computes from buffer s & 1; the halo of tile s + 2 is requested right after the barrier
+  // that ends tile s's reads of that buffer, i.e. a whole tile of matrix work before it is needed
   int t = blockIdx.x;
   const int step = gridDim.x;
   const int total = p.ti.total;
@@ -369,25 +395,46 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   stage(t, 0);
   if (t + step < total) stage(t + step, 1);
   tile_end();
-  while (true) {
-    compute(std::integral_constant<int, 0>{});
-    tile_end();                                               // buffer 0 free, buffer 1 complete
-    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
-    epilogue(t);
-    t += step;
-    if (t >= total) break;
-    compute(std::integral_constant<int, 1>{});
+  if constexpr (!ILV) {                                       // one accumulator set: the epilogue follows its tile's barrier
+    while (true) {
+      run_tile(std::integral_constant<int, 0>{}, std::false_type{}, 0);
+      tile_end();
+      if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+      epilogue(t, 0);
+      t += step;
+      if (t >= total) return;
+      run_tile(std::integral_constant<int, 1>{}, std::false_type{}, 0);
+      tile_end();
+      if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 1);
+      epilogue(t, 0);
+      t += step;
+      if (t >= total) return;
+    }
+  }
+  run_tile(std::integral_constant<int, 0>{}, std::false_type{}, 0);
+  tile_end();
+  if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+  int tprev = t, last = 0;
+  t += step;
+  while (t < total) {
+    run_tile(std::integral_constant<int, 1>{}, std::true_type{}, tprev);
     tile_end();
     if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 1);
-    epilogue(t);
+    tprev = t; last = 1;
     t += step;
     if (t >= total) break;
+    run_tile(std::integral_constant<int, 0>{}, std::true_type{}, tprev);
+    tile_end();
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+    tprev = t; last = 0;
+    t += step;
   }
+  epilogue(tprev, last);
 }
 
 int num_cus();   // narrow_bf16.hip
 
-template <int CPT, int NT, int MT, bool WITH_MATCH = true>
+template <int CPT, int NT, int MT, bool WITH_MATCH = true, bool ILV = true>
 static int launch_c3n(NarrowParams p, int batch, bool f32out, bool match, hipStream_t stream) {
   using G = C3nGeom<CPT, NT, MT>;
   const int tiles_x = p.W / 16, tiles_y = p.H / G::TH;
@@ -398,9 +445,9 @@ static int launch_c3n(NarrowParams p, int batch, bool f32out, bool match, hipStr
   p.batch = batch;
   const int lds = G::LDS_BYTES + (match ? match_tab_floats<NT>(batch) * 4 : 0);
   if (lds > 160 * 1024) return fail(CCVPE_EINVAL, "c3n: batch %d needs %d B of LDS for the matching tables", batch, lds);
-  void (*kern)(const NarrowParams) = f32out ? c3n_kernel<CPT, NT, MT, true, false> : c3n_kernel<CPT, NT, MT, false, false>;
+  void (*kern)(const NarrowParams) = f32out ? c3n_kernel<CPT, NT, MT, true, false, ILV> : c3n_kernel<CPT, NT, MT, false, false, ILV>;
   if (match) {
-    if constexpr (WITH_MATCH) kern = f32out ? c3n_kernel<CPT, NT, MT, true, true> : c3n_kernel<CPT, NT, MT, false, true>;
+    if constexpr (WITH_MATCH) kern = f32out ? c3n_kernel<CPT, NT, MT, true, true, ILV> : c3n_kernel<CPT, NT, MT, false, true, ILV>;
     else return fail(CCVPE_EINVAL, "c3n: the matching epilogue is not built for this tile");
   }
   static int attr_lds[4] = {0, 0, 0, 0};
@@ -579,19 +626,56 @@ __global__ __launch_bounds__(256, 1) void up2_kernel(const Up2Params p) {
     }
   };
 
-  f32x4 acc[MT][NT];
-  auto compute = [&](auto buf_tag) {
+  // ---- epilogue of one low-res row: pixel (2 (y0 + i) + py, 2 (x0 + f) + px); shift by the pixel's border class ----------------------
+  struct EpiCtx { int b, y0, X, cc; };
+  auto epi_ctx = [&](int t, EpiCtx& c) {
+    int ty, tx;
+    tile_decode(p.ti, t, c.b, ty, tx);
+    c.y0 = ty * MT;
+    c.X = 2 * (tx * 16 + f) + px;
+    c.cc = c.X == 0 ? 0 : (c.X == W2 - 1 ? 2 : 1);
+  };
+  auto epi_row = [&](const EpiCtx& c, int i, const f32x4* accrow) {
+    const int Y = 2 * (c.y0 + i) + py;
+    const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
+    const char* shp = nsm + G::SHIFT_BASE + ((rc * 3 + c.cc) * 16 * NT + q * 4) * 4;
+    f32x4 v[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      v[n] = accrow[n] + *reinterpret_cast<const f32x4*>(shp + 64 * n);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
+    }
+    if (abl & 2) {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
+      return;
+    }
+    store_row<NT, false>(p.dst, ((size_t)(c.b * H2 + Y) * W2 + c.X) * p.ldd, v, q, p.N);
+  };
+
+  // ---- the matrix work of HALF a tile (low-res rows HM h .. HM h + HM - 1, accumulator set h) with the epilogue of the PREVIOUS half
+  // (the other accumulator set; of this tile for h = 1, of the previous tile for h = 0) interleaved: row i of it is converted and
+  // stored in the scheduling region of k-step i's matrix instructions (see c3n_kernel's run_tile).  Two half-tile passes instead of
+  // one whole-tile pass cost nothing here — the weights are registers, a k-step's W fragment is free to re-use — and the two
+  // accumulator sets together are the registers one whole-tile set took. -------------------------------------------------------------
+  constexpr int HM = MT / 2;
+  static_assert(MT % 2 == 0, "up2_kernel: two half-tile passes");
+  f32x4 acc[2][HM][NT];
+  auto run_half = [&](auto buf_tag, auto half_tag, auto prev_tag, const EpiCtx& pc, int prow0) {
     constexpr int BUF = decltype(buf_tag)::value;
+    constexpr int H = decltype(half_tag)::value;
+    constexpr bool PREV = decltype(prev_tag)::value;
     const char* hb = nsm + BUF * G::BUF_BYTES;
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+    for (int i = 0; i < HM; ++i)
 #pragma unroll
-      for (int n = 0; n < NT; ++n) acc[i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 a[2][MT];
+      for (int n = 0; n < NT; ++n) acc[H][i][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 a[2][HM];
     auto rd = [&](int j, f32x4* dst) {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
-        dst[i] = *reinterpret_cast<const f32x4*>(hb + aoff[j] + i * (j < NCHX ? XROW : SROW2));
+      for (int i = 0; i < HM; ++i)
+        dst[i] = *reinterpret_cast<const f32x4*>(hb + aoff[j] + (H * HM + i) * (j < NCHX ? XROW : SROW2));
     };
     rd(0, a[0]);
 #pragma unroll
@@ -601,44 +685,26 @@ __global__ __launch_bounds__(256, 1) void up2_kernel(const Up2Params p) {
       __builtin_amdgcn_sched_barrier(0);
       if (j == NCH - 1 && (9 * CPT1) % 4 != 0) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) a[cur][i] = keep_if(a[cur][i], tail_ok);
+        for (int i = 0; i < HM; ++i) a[cur][i] = keep_if(a[cur][i], tail_ok);
       }
       if (!(abl & 4)) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int i = 0; i < HM; ++i)
 #pragma unroll
-          for (int n = 0; n < NT; ++n) acc[i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[i][n]);
+          for (int n = 0; n < NT; ++n) acc[H][i][n] = mfma_stage<bf16_t>(wreg[j][n], a[(abl & 8) ? 0 : cur][i], acc[H][i][n]);
+      }
+      if constexpr (PREV) {
+        if (j < HM) {
+          epi_row(pc, prow0 + j, acc[H ^ 1][j]);
+#pragma unroll
+          for (int m = 0; m < HM * NT; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
+          }
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
-  };
-  // ---- epilogue (after the tile's closing barrier, see c3n_kernel): pixel (2 (y0 + i) + py, 2 (x0 + f) + px); shift by the
-  // pixel's border class ---------------------------------------------------------------------------------------------------
-  auto epilogue = [&](int t) {
-    int b, ty, tx;
-    tile_decode(p.ti, t, b, ty, tx);
-    const int y0 = ty * MT, x0 = tx * 16;
-    const int X = 2 * (x0 + f) + px;
-    const int cc = X == 0 ? 0 : (X == W2 - 1 ? 2 : 1);
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      const int Y = 2 * (y0 + i) + py;
-      const int rc = Y == 0 ? 0 : (Y == H2 - 1 ? 2 : 1);
-      const char* shp = nsm + G::SHIFT_BASE + ((rc * 3 + cc) * 16 * NT + q * 4) * 4;
-      f32x4 v[NT];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        v[n] = acc[i][n] + *reinterpret_cast<const f32x4*>(shp + 64 * n);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[n][r] = fmaxf(v[n][r], p.act_floor);
-      }
-      if (abl & 2) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
-        continue;
-      }
-      store_row<NT, false>(p.dst, ((size_t)(b * H2 + Y) * W2 + X) * p.ldd, v, q, p.N);
-    }
   };
   auto tile_end = [&]() {
     if (abl & 16) return;
@@ -653,20 +719,35 @@ __global__ __launch_bounds__(256, 1) void up2_kernel(const Up2Params p) {
   stage(t, 0);
   if (t + step < total) stage(t + step, 1);
   tile_end();
-  while (true) {
-    compute(std::integral_constant<int, 0>{});
+  EpiCtx cur_ctx, prev_ctx;
+  epi_ctx(t, cur_ctx);
+  prev_ctx = cur_ctx;
+  // first tile: its first half has no predecessor
+  run_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{}, prev_ctx, 0);
+  run_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{}, cur_ctx, 0);
+  tile_end();
+  if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
+  prev_ctx = cur_ctx;
+  t += step;
+  int sbuf = 1;
+  while (t < total) {
+    epi_ctx(t, cur_ctx);
+    if (sbuf) {
+      run_half(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}, std::true_type{}, prev_ctx, HM);
+      run_half(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::true_type{}, cur_ctx, 0);
+    } else {
+      run_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::true_type{}, prev_ctx, HM);
+      run_half(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}, std::true_type{}, cur_ctx, 0);
+    }
     tile_end();
-    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 0);
-    epilogue(t);
+    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, sbuf);
+    prev_ctx = cur_ctx;
+    sbuf ^= 1;
     t += step;
-    if (t >= total) break;
-    compute(std::integral_constant<int, 1>{});
-    tile_end();
-    if (t + 2 * step < total && !(abl & 1)) stage(t + 2 * step, 1);
-    epilogue(t);
-    t += step;
-    if (t >= total) break;
   }
+  // the second half of the last tile
+#pragma unroll
+  for (int i = 0; i < HM; ++i) epi_row(prev_ctx, HM + i, acc[1][i]);
 }
 
 template <int CPT0, int CPT1, int NT, int MT>

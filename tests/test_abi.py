@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libccvpe_hip.so does not export %s" % n
     assert sorted(_lib.PROTOTYPES) == names, "ctypes table and header disagree"
-    assert lib.ccvpe_abi_version() == 5
+    assert lib.ccvpe_abi_version() == 6
 
 
 def test_ctypes_prototypes_match_header_signatures():

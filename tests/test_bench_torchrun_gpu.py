@@ -23,7 +23,7 @@ def _run(extra_env, batch, gpus=1):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCVPE_ALLREDUCE_SINGLE_RANK="1", **extra_env)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", CCVPE_ALLREDUCE_SINGLE_RANK="1", CCVPE_BENCH_DP_STEPS="2,2", **extra_env)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
            "--batch", str(batch), "--legs", "dp", "--no-cpu-baseline"]

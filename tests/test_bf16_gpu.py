@@ -311,23 +311,43 @@ def ori_bin_check(o_got, o_ref):
     return int(a_g // 18) == int(a_r // 18), min(d, 18.0 - d) < ORI_EDGE_DEG
 
 
+def _centre_tap_head(sd):
+    """A weight set with PEAKED heat-maps: conv1.0 / conv1.2 as centre-tap filters (x3), so the 512 x 512 logits are a pointwise
+    function of the deconv output instead of a 5 x 5-smoothed one — the top-1 / top-2 margin then clears twice the bf16 error
+    bound on ~3 of 4 samples (tools/argmax_margins.py: median margin 2.2e-2 of the range against 1.4e-2 for the default set)."""
+    sd = {k: v.clone() for k, v in sd.items()}
+    for k in ("conv1.0.weight", "conv1.2.weight"):
+        w = sd[k]
+        c = w[:, :, 1, 1].clone() * 3.0
+        w.zero_()
+        w[:, :, 1, 1] = c
+    return sd
+
+
 def test_bf16_argmax_margin_rule(synth_sd):
     """Arg-max pixel + orientation bin of the bf16 storage path (default fp32 tail) against the fp32 HIP path — itself arg-max
-    and bin exact against the reference's goldens (tests/test_forward_gpu.py) — over 64 seeded pairs of CVM_VIGOR (N_rot = 20).
+    and bin exact against the reference's goldens (tests/test_forward_gpu.py) — over 256 seeded pairs of CVM_VIGOR (N_rot = 20)
+    with the default synthetic weights plus 64 pairs with a PEAKED-heat-map weight set (_centre_tap_head).
 
     The rule (plus an absolute floor on the match count): (1) the logit error is bounded: |bf16 - fp32| <= LOGIT_ERR_BOUND x range for every
-    pixel of every sample; (2) wherever the fp32 top-1 / top-2 margin exceeds TWICE that bound the arg-max pixel is EQUAL;
+    pixel of every sample; (2) wherever the fp32 top-1 / top-2 margin exceeds TWICE that bound the arg-max pixel is EQUAL — and
+    that case must actually occur: >= 25 % of the default-weight samples and >= 60 % of the peaked ones (measured 53 % / 73 %);
     (3) the samples inside the bound ("near ties") are counted and reported, and if the bf16 arg-max moves there it moves to a
     pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) the orientation bin at the fp32
     arg-max pixel is equal wherever the fp32 angle is further than ORI_EDGE_DEG from a bin edge.  Pure bf16 storage
-    (fp32_tail_levels = 0) is held to the same rule with its own measured bound (first 32 pairs)."""
+    (fp32_tail_levels = 0) is held to the same rule with its own measured bound (first 32 pairs).
+    Three model instances (fp32, bf16, pure bf16) share the weights: no re-pack per chunk."""
     from ccvpe_amd import models
-    net = models.CVM_VIGOR("cuda", True)
-    net.load_state_dict(synth_sd("vigor", 0), strict=True)
-    net = net.to("cuda:0").eval()
-    stats = {"tail": dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0),
-             "pure": dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0)}
-    bound = {"tail": LOGIT_ERR_BOUND, "pure": 8e-3}
+
+    def build(sd, precision, tail=1):
+        net = models.CVM_VIGOR("cuda", True)
+        net.load_state_dict(sd, strict=True)
+        return net.to("cuda:0").eval().set_precision(precision, fp32_tail_levels=tail) if precision == "bf16" else net.to("cuda:0").eval()
+
+    def fresh():
+        return dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0)
+    stats = {"tail": fresh(), "pure": fresh(), "peaked": fresh()}
+    bound = {"tail": LOGIT_ERR_BOUND, "pure": 8e-3, "peaked": 7e-3}
 
     def account(st, E, ref, got, ref_ori, got_ori):
         rng = ref.max(1)[0] - ref.min(1)[0]
@@ -352,24 +372,39 @@ def test_bf16_argmax_margin_rule(synth_sd):
             st["bins_edge"] += int(edge)
             st["bins_bad"] += int(not same and not edge)
 
-    for c0 in range(0, 64, 16):
+    sd = synth_sd("vigor", 0)
+    n32, nbf, npure = build(sd, "fp32"), build(sd, "bf16"), build(sd, "bf16", 0)
+    for c0 in range(0, 256, 16):
         grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0)
         grd, sat = grd.cuda(), sat.cuda()
-        r = net.set_precision("fp32")(grd, sat)
+        r = n32(grd, sat)
         ref, ref_ori = r[0].clone(), r[2].clone()
-        g = net.set_precision("bf16")(grd, sat)
+        g = nbf(grd, sat)
         account(stats["tail"], bound["tail"], ref, g[0], ref_ori, g[2])
         if c0 < 32:
-            g = net.set_precision("bf16", fp32_tail_levels=0)(grd, sat)
+            g = npure(grd, sat)
             account(stats["pure"], bound["pure"], ref, g[0], ref_ori, g[2])
+    del n32, nbf, npure
+    sdp = _centre_tap_head(sd)
+    n32, nbf = build(sdp, "fp32"), build(sdp, "bf16")
+    for c0 in range(0, 64, 16):
+        grd, sat = synth.synthetic_pair(16, "vigor", 9000 + c0)
+        grd, sat = grd.cuda(), sat.cuda()
+        r = n32(grd, sat)
+        ref, ref_ori = r[0].clone(), r[2].clone()
+        g = nbf(grd, sat)
+        account(stats["peaked"], bound["peaked"], ref, g[0], ref_ori, g[2])
     for k, st in stats.items():
         print("bf16 (%s): arg-max equal %d/%d, near ties (margin <= 2 x %.0e of range) %d, worst logit error %.2e of range, "
               "orientation bins: %d at a bin edge, %d wrong" % (k, st["same"], st["n"], bound[k], st["near"], st["worst"],
                                                                 st["bins_edge"], st["bins_bad"]))
         assert st["worst"] <= bound[k], "logit error bound exceeded"
         assert st["moved_far"] == 0, "the arg-max moved to a pixel outside the error bound"
-        # an absolute floor next to the margin rule (measured: 64/64 with the fp32 tail, 63/64 pure bf16 over 64 pairs): however
-        # many near ties the synthetic weights produce, the arg-max must not move on more than one (tail) / two (pure) samples
-        floor = {"tail": st["n"] - 1, "pure": st["n"] - 2}[k]
+        # an absolute floor next to the margin rule: however many near ties the synthetic weights produce, the arg-max must not
+        # move on more than 6 % of the samples with the fp32 tail / 6 % in pure bf16 (round 4, 64 pairs: 64/64 and 63/64)
+        floor = {"tail": st["n"] - 16, "pure": st["n"] - 2, "peaked": st["n"] - 3}[k]
         assert st["same"] >= floor, "bf16 arg-max equal on %d of %d samples (floor %d)" % (st["same"], st["n"], floor)
         assert st["bins_bad"] == 0, "orientation bin differs away from a bin edge"
+    # "exact" is actually exercised: clear-margin samples exist in number (on them the arg-max was asserted EQUAL above)
+    assert stats["tail"]["n"] - stats["tail"]["near"] >= 64, stats["tail"]
+    assert stats["peaked"]["n"] - stats["peaked"]["near"] >= 38, stats["peaked"]
