@@ -597,8 +597,7 @@ def main():
         net, gshape = models.CVM_KITTI(dev), "kitti"
     net.load_state_dict(sd, strict=True)
     net = net.to(dev).eval().set_precision(args.precision)
-    grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank)
-    grd, sat = grd.to(dev), sat.to(dev)                     # inputs resident in HBM before timing
+    grd, sat = synth.synthetic_pair(args.batch, gshape, 1234 + rank, device=dev)      # generated in HBM (same bits as on the CPU): resident before timing
     record = not args.no_kernel_events
     failed = []                                             # legs whose failure must fail the run (after the line is printed)
 
@@ -738,8 +737,7 @@ def main():
                 net2 = ctor()
                 net2.load_state_dict(sd, strict=True)
                 net2 = net2.to(dev).eval().set_precision("bf16")
-                g2, s2 = synth.synthetic_pair(b2, gsh, seed + rank)
-                g2, s2 = g2.to(dev), s2.to(dev)
+                g2, s2 = synth.synthetic_pair(b2, gsh, seed + rank, device=dev)
                 f2 = net2
                 if graph:
                     from ccvpe_amd.graph import GraphedForward
@@ -777,9 +775,9 @@ def main():
                 net4 = models.CVM_KITTI(dev)
                 net4.load_state_dict(sdk, strict=True)
                 net4 = net4.to(dev)
-                g4, s4 = synth.synthetic_pair(args.batch, "kitti", 1234 + rank)
+                g4, s4 = synth.synthetic_pair(args.batch, "kitti", 1234 + rank, device=dev)
                 dp_steps, dp_warm = (int(v) for v in os.environ.get("CCVPE_BENCH_DP_STEPS", "5,3").split(","))    # (tests shorten it)
-                ent, m4 = train_entry(net4, "kitti", g4.to(dev), s4.to(dev), dev, args.batch, dp_steps, dp_warm, rank, world, 16, record,
+                ent, m4 = train_entry(net4, "kitti", g4, s4, dev, args.batch, dp_steps, dp_warm, rank, world, 16, record,
                                       tag="train_dp_kitti_b64")
                 coll = collective_info(dev, m4, world)
                 if coll["ranks_counted_by_allreduce"] != world:

@@ -38,9 +38,12 @@ def _fmix32(h):
     return h
 
 
-def hash_u32(n, seed):
-    """n hashed 32-bit words (int64 tensor) for stream `seed`."""
-    idx = torch.arange(n, dtype=torch.int64)
+def hash_u32(n, seed, device=None):
+    """n hashed 32-bit words (int64 tensor) for stream `seed`.  `device`: where the integer ops run — the hash is exact integer
+    arithmetic and the float conversions below are single IEEE operations, so a tensor generated on the MI355X is BIT-identical
+    to the CPU one (tests/test_synth_device_gpu.py); large test batches are generated there (B = 64 pairs: 15 s on 8 host
+    cores, milliseconds on the device)."""
+    idx = torch.arange(n, dtype=torch.int64, device=device)
     s = (int(seed) * 0x9E3779B1 + 0x7F4A7C15) & _M32
     h = (idx & _M32) ^ s
     h = _fmix32(h)
@@ -48,17 +51,17 @@ def hash_u32(n, seed):
     return h
 
 
-def uniform(shape, seed, lo=0.0, hi=1.0):
+def uniform(shape, seed, lo=0.0, hi=1.0, device=None):
     n = int(math.prod(shape)) if len(shape) else 1
-    u = (hash_u32(n, seed) >> 8).to(torch.float32) * (1.0 / 16777216.0)   # 24 bits, exact
+    u = (hash_u32(n, seed, device) >> 8).to(torch.float32) * (1.0 / 16777216.0)   # 24 bits, exact
     return (u * (hi - lo) + lo).reshape(shape)
 
 
-def normal(shape, seed, std=1.0, mean=0.0):
+def normal(shape, seed, std=1.0, mean=0.0, device=None):
     """Irwin-Hall(4) approximation of a unit normal: exact fp32 sums of 16-bit uniforms."""
     n = int(math.prod(shape)) if len(shape) else 1
-    a = hash_u32(n, seed)
-    b = hash_u32(n, seed ^ 0x5BD1E995)
+    a = hash_u32(n, seed, device)
+    b = hash_u32(n, seed ^ 0x5BD1E995, device)
     s = ((a & 0xFFFF) + (a >> 16) + (b & 0xFFFF) + (b >> 16)).to(torch.float32)
     z = (s * (1.0 / 65536.0) - 2.0) * math.sqrt(3.0)
     return (z * std + mean).reshape(shape)
@@ -71,12 +74,12 @@ GRD_SHAPES = {"vigor": (320, 640), "vigor_fov180": (320, 320), "kitti": (256, 10
               "oxford": (154, 231)}          # train_OxfordRobotCar.py:50 (transforms.Resize([154, 231]))
 
 
-def synthetic_pair(batch, kind="vigor", seed=1234, grd_hw=None, sat_hw=(512, 512)):
+def synthetic_pair(batch, kind="vigor", seed=1234, grd_hw=None, sat_hw=(512, 512), device=None):
     """(grd [B,3,h,w], sat [B,3,512,512]) fp32 NCHW, ~unit normal like ImageNet-normalised
-    images (/root/reference/train_VIGOR.py:57-70)."""
+    images (/root/reference/train_VIGOR.py:57-70).  device: generate there (same bits, see hash_u32)."""
     gh, gw = grd_hw if grd_hw is not None else GRD_SHAPES[kind]
-    grd = normal((batch, 3, gh, gw), seed * 2 + 1)
-    sat = normal((batch, 3, sat_hw[0], sat_hw[1]), seed * 2 + 2)
+    grd = normal((batch, 3, gh, gw), seed * 2 + 1, device=device)
+    sat = normal((batch, 3, sat_hw[0], sat_hw[1]), seed * 2 + 2, device=device)
     return grd, sat
 
 

@@ -300,15 +300,17 @@ def test_forward_bf16_vs_oracle(case, synth_sd):
 
 
 LOGIT_ERR_BOUND = 6e-3        # bf16 storage path (default fp32 tail): max |logit error| / logit range, asserted below (measured 4.5e-3)
-ORI_EDGE_DEG = 2.0            # asin(3e-2): the angle the asserted orientation-vector bound can move
+ORI_EDGE_DEG = 2.0            # asin(3e-2): the angle the asserted orientation-vector bound can move (the B = 2 cases above)
+ORI_VEC_BOUND_AT_SCALE = 5e-2  # the (cos, sin) error bound over hundreds of samples (tests/test_fullsize_gpu.py: 3.3e-2 observed over the
+ORI_EDGE_DEG_AT_SCALE = 3.0    # benched batches): asin(5e-2) = 2.9 deg is the angle IT can move
 
 
-def ori_bin_check(o_got, o_ref):
-    """(bins equal, oracle angle within ORI_EDGE_DEG of an 18-degree bin edge) for two (cos, sin) vectors."""
+def ori_bin_check(o_got, o_ref, edge_deg=ORI_EDGE_DEG):
+    """(bins equal, oracle angle within edge_deg of an 18-degree bin edge) for two (cos, sin) vectors."""
     ang = lambda v: float(torch.atan2(v[1], v[0]) * 180 / 3.14159265) % 360
     a_g, a_r = ang(o_got), ang(o_ref)
     d = a_r % 18.0
-    return int(a_g // 18) == int(a_r // 18), min(d, 18.0 - d) < ORI_EDGE_DEG
+    return int(a_g // 18) == int(a_r // 18), min(d, 18.0 - d) < edge_deg
 
 
 def _centre_tap_head(sd):
@@ -333,8 +335,9 @@ def test_bf16_argmax_margin_rule(synth_sd):
     pixel of every sample; (2) wherever the fp32 top-1 / top-2 margin exceeds TWICE that bound the arg-max pixel is EQUAL — and
     that case must actually occur: >= 25 % of the default-weight samples and >= 60 % of the peaked ones (measured 53 % / 73 %);
     (3) the samples inside the bound ("near ties") are counted and reported, and if the bf16 arg-max moves there it moves to a
-    pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) the orientation bin at the fp32
-    arg-max pixel is equal wherever the fp32 angle is further than ORI_EDGE_DEG from a bin edge.  Pure bf16 storage
+    pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) the (cos, sin) vector at the fp32
+    arg-max pixel is within ORI_VEC_BOUND_AT_SCALE of the fp32 one on every sample, and the orientation bin is equal wherever
+    the fp32 angle is further from a bin edge than the angle that bound can move (ORI_EDGE_DEG_AT_SCALE).  Pure bf16 storage
     (fp32_tail_levels = 0) is held to the same rule with its own measured bound (first 32 pairs).
     Three model instances (fp32, bf16, pure bf16) share the weights: no re-pack per chunk."""
     from ccvpe_amd import models
@@ -345,7 +348,7 @@ def test_bf16_argmax_margin_rule(synth_sd):
         return net.to("cuda:0").eval().set_precision(precision, fp32_tail_levels=tail) if precision == "bf16" else net.to("cuda:0").eval()
 
     def fresh():
-        return dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0)
+        return dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0, ori_worst=0.0)
     stats = {"tail": fresh(), "pure": fresh(), "peaked": fresh()}
     bound = {"tail": LOGIT_ERR_BOUND, "pure": 8e-3, "peaked": 7e-3}
 
@@ -368,15 +371,15 @@ def test_bf16_argmax_margin_rule(synth_sd):
                 st["moved_far"] += int(drop > 2 * E)
             o_g = got_ori[b].reshape(2, -1)[:, ia[b]].cpu()
             o_r = ref_ori[b].reshape(2, -1)[:, ia[b]].cpu()
-            same, edge = ori_bin_check(o_g, o_r)
+            same, edge = ori_bin_check(o_g, o_r, ORI_EDGE_DEG_AT_SCALE)
+            st["ori_worst"] = max(st["ori_worst"], float((o_g - o_r).abs().max()))
             st["bins_edge"] += int(edge)
             st["bins_bad"] += int(not same and not edge)
 
     sd = synth_sd("vigor", 0)
     n32, nbf, npure = build(sd, "fp32"), build(sd, "bf16"), build(sd, "bf16", 0)
     for c0 in range(0, 256, 16):
-        grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0)
-        grd, sat = grd.cuda(), sat.cuda()
+        grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0, device="cuda")
         r = n32(grd, sat)
         ref, ref_ori = r[0].clone(), r[2].clone()
         g = nbf(grd, sat)
@@ -388,17 +391,17 @@ def test_bf16_argmax_margin_rule(synth_sd):
     sdp = _centre_tap_head(sd)
     n32, nbf = build(sdp, "fp32"), build(sdp, "bf16")
     for c0 in range(0, 64, 16):
-        grd, sat = synth.synthetic_pair(16, "vigor", 9000 + c0)
-        grd, sat = grd.cuda(), sat.cuda()
+        grd, sat = synth.synthetic_pair(16, "vigor", 9000 + c0, device="cuda")
         r = n32(grd, sat)
         ref, ref_ori = r[0].clone(), r[2].clone()
         g = nbf(grd, sat)
         account(stats["peaked"], bound["peaked"], ref, g[0], ref_ori, g[2])
     for k, st in stats.items():
         print("bf16 (%s): arg-max equal %d/%d, near ties (margin <= 2 x %.0e of range) %d, worst logit error %.2e of range, "
-              "orientation bins: %d at a bin edge, %d wrong" % (k, st["same"], st["n"], bound[k], st["near"], st["worst"],
-                                                                st["bins_edge"], st["bins_bad"]))
+              "orientation: worst vector error %.2e, bins: %d at a bin edge, %d wrong" % (k, st["same"], st["n"], bound[k], st["near"],
+                                                                                          st["worst"], st["ori_worst"], st["bins_edge"], st["bins_bad"]))
         assert st["worst"] <= bound[k], "logit error bound exceeded"
+        assert st["ori_worst"] <= ORI_VEC_BOUND_AT_SCALE, "orientation vector error bound exceeded"
         assert st["moved_far"] == 0, "the arg-max moved to a pixel outside the error bound"
         # an absolute floor next to the margin rule: however many near ties the synthetic weights produce, the arg-max must not
         # move on more than 6 % of the samples with the fp32 tail / 6 % in pure bf16 (round 4, 64 pairs: 64/64 and 63/64)

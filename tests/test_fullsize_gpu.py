@@ -62,7 +62,7 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
     """Samples `picks` of the benched batch against the CPU oracle run on those samples alone."""
     idx = torch.tensor(list(picks))
     with torch.no_grad():
-        ref = O.forward(synth_sd(kind, 0), grd[idx].cpu(), sat[idx].cpu(), kind, circular, ori_noise)
+        ref = O.forward(synth_sd(kind, 0), grd[idx.to(grd.device)].cpu(), sat[idx.to(sat.device)].cpu(), kind, circular, ori_noise)
     got = [t[idx.to(t.device)].cpu() for t in out]
     assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref]
     for j, i in enumerate(picks):
@@ -99,8 +99,7 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
 def test_batch_position_invariance_at_bench_size(synth_sd, name, ori_noise, circular, gshape, batch, precision, rtol):
     kind = "kitti" if gshape == "kitti" else "vigor"
     net = _net(synth_sd, kind, ori_noise, circular, precision)
-    grd, sat = synth.synthetic_pair(batch, gshape, 1234)
-    grd, sat = grd.cuda(), sat.cuda()
+    grd, sat = synth.synthetic_pair(batch, gshape, 1234, device="cuda")      # same bits as on the CPU (tests/test_synth_device_gpu.py)
     out = [t.clone() for t in net(grd, sat)]
     _props(out, batch)
     order = []
@@ -120,8 +119,7 @@ def test_c4_graph_replay_at_b256_matches_eager_and_subbatch(synth_sd):
     from ccvpe_amd.graph import GraphedForward
     batch = 256
     net = _net(synth_sd, "vigor", 180, False, "bf16")
-    grd, sat = synth.synthetic_pair(batch, "vigor_fov180", 4321)
-    grd, sat = grd.cuda(), sat.cuda()
+    grd, sat = synth.synthetic_pair(batch, "vigor_fov180", 4321, device="cuda")
     eager = [t.clone() for t in net(grd, sat)]
     _props(eager, batch)
     graphed = GraphedForward(net, grd, sat)

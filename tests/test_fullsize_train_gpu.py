@@ -79,8 +79,7 @@ def test_training_step_at_b64_is_deterministic_and_permutation_invariant(synth_s
     net.load_state_dict(synth_sd(kind, 0), strict=True)
     net = net.to("cuda:0").train()
     sd0 = {k: v.clone() for k, v in net.state_dict().items()}          # running statistics are updated in place
-    grd, sat = synth.synthetic_pair(batch, kind, 1234)
-    grd, sat = grd.cuda(), sat.cuda()
+    grd, sat = synth.synthetic_pair(batch, kind, 1234, device="cuda")          # same bits as on the CPU (tests/test_synth_device_gpu.py)
     u = synth.uniform((batch, 3), 99)
     center, angle = ((u[:, :2] - 0.5) * 384.0).cuda(), (u[:, 2] * 359.99).cuda()
     keys = [("%s_efficientnet" % e, i) for e in ("grd", "sat") for i in range(16)]
@@ -132,8 +131,7 @@ def test_stream_overlap_does_not_change_a_single_bit(synth_sd):
     while another stream still reads it, a missing join) shows up here as a differing bit."""
     from ccvpe_amd import models, train
     batch = 16
-    grd, sat = synth.synthetic_pair(batch, "vigor", 4321)
-    grd, sat = grd.cuda(), sat.cuda()
+    grd, sat = synth.synthetic_pair(batch, "vigor", 4321, device="cuda")
     u = synth.uniform((batch, 3), 77)
     center, angle = ((u[:, :2] - 0.5) * 384.0).cuda(), (u[:, 2] * 359.99).cuda()
     keys = [("%s_efficientnet" % e, i) for e in ("grd", "sat") for i in range(16)]
