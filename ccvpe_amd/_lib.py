@@ -70,7 +70,6 @@ PROTOTYPES = {
                                   ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong), ctypes.POINTER(ctypes.c_longlong)]),
     "ccvpe_forward": (c_int, [c_void_p, c_void_p, c_void_p, ctypes.POINTER(c_void_p), c_void_p]),
     "ccvpe_tail512_partials": (c_int, [ctypes.POINTER(TailDesc), c_int]),
-    "ccvpe_tail512_route": (c_int, [ctypes.POINTER(TailDesc), c_int]),
     "ccvpe_softmax_apply_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "ccvpe_tail512_f32": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),
     "ccvpe_tail512_bf16": (c_int, [ctypes.POINTER(TailDesc), c_void_p]),

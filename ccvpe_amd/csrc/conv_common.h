@@ -274,9 +274,6 @@ int c3n_supported(const IgemmParams& p, int batch);      // 0 = not served, else
 int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream);
 int c3n_match_supported(const IgemmParams& p, int batch, int L);
 int c3n_match_dispatch(const IgemmParams& p, int batch, const float* g, int ldg, int L, int off, float* scores, hipStream_t stream);
-int tail2_supported(int is_bf16, int split, int cout, int c0, int ld0, int h1, int w1, int batch);   // 0, or an instantiation id
-int tail2_dispatch(int id, const void* x, const void* w, const float* shift9, const float* w2, const float* b2, float* out, float* smx,
-                   int batch, int h1, int w1, int c0, int ld0, int kpad, int normalize, hipStream_t stream);
 int up2_supported(int c0, int c1, int n, int kpad, int h1, int w1, int batch);
 int up2_dispatch(const void* src0, const void* src1, const void* w, const float* shift9, void* dst, int c0, int ld0, int c1, int ld1,
                  int h1, int w1, int n, int kpad, int ldd, int act, int batch, hipStream_t stream);

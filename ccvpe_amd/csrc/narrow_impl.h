@@ -75,13 +75,14 @@ static int narrow_ablate_env() { return 0; }
 // Epilogue stores of one pixel row: acc[n] (this lane's quad of column tile n, bias / shift and activation already applied).
 // bf16: column tiles are paired through v_permlane32_swap — lanes q < 2 store 8 channels of the even tile, lanes q >= 2 8 channels
 // of the odd tile; an unpaired last tile is stored by the lanes q < 2.  fp32: one 16-byte store per quad.  N % 8 == 0.
+// t0: first column tile of v[] (a wave that owns the column tiles t0 .. t0 + NT - 1 of a wider layer)
 template <int NT, bool F32OUT>
-__device__ __forceinline__ void store_row(void* dst, size_t o, const f32x4* v, int q, int N) {
+__device__ __forceinline__ void store_row(void* dst, size_t o, const f32x4* v, int q, int N, int t0 = 0) {
   if constexpr (F32OUT) {
     float* dp = reinterpret_cast<float*>(dst) + o;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
-      const int ch = chan_of_quad(n, q);
+      const int ch = chan_of_quad(t0 + n, q);
       if (ch < N) *reinterpret_cast<f32x4*>(dp + ch) = v[n];
     }
   } else {
@@ -102,7 +103,7 @@ __device__ __forceinline__ void store_row(void* dst, size_t o, const f32x4* v, i
       bf16x8 ob;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ob[r] = (bf16_t)lo[r]; ob[r + 4] = (bf16_t)hi[r]; }
-      const int ch = 16 * (n + (q >> 1)) + 8 * (q & 1);
+      const int ch = 16 * (t0 + n + (q >> 1)) + 8 * (q & 1);
       if (ch < N) *reinterpret_cast<bf16x8*>(dp + ch) = ob;
     }
     if constexpr (NT & 1) {
@@ -117,7 +118,7 @@ __device__ __forceinline__ void store_row(void* dst, size_t o, const f32x4* v, i
       bf16x8 ob;
 #pragma unroll
       for (int r = 0; r < 4; ++r) { ob[r] = (bf16_t)own[r]; ob[r + 4] = (bf16_t)hi[r]; }
-      const int ch = 16 * n + 8 * (q & 1);
+      const int ch = 16 * (t0 + n) + 8 * (q & 1);
       if (q < 2 && ch < N) *reinterpret_cast<bf16x8*>(dp + ch) = ob;
     }
   }
@@ -132,7 +133,7 @@ struct NarrowParams {
   const void* w;       // packed [Npad][Kpad] bf16, k = tap * (8 CPT) + channel (models._pack_conv)
   const float* shift;  // bias [N] or nullptr
   void* dst;           // [B,H,W,ldd] bf16 or fp32
-  int H, W, ld, N, Kpad, ldd;
+  int H, W, ld, N, Npad, Kpad, ldd;
   float act_floor;     // 0 for ReLU, -inf for none: v = max(v, act_floor)
   // MATCH (c3n_kernel<..., MATCH = true>): the NEXT level's rotational matching for ONE rotation hypothesis in this layer's epilogue
   // (models.py:186-205 pattern with a single shift: CVM_VIGOR_ori_prior(0)).  dst then receives the decoder input rows
@@ -145,9 +146,10 @@ struct NarrowParams {
                        // 2 = no epilogue stores, 4 = no matrix instructions, 8 = no fragment reads, 16 = no barrier / DMA wait
 };
 
-template <int CPT, int NT, int MT>
+// NS: the output channels are split over NS groups of waves (each NT column tiles wide); 4 / NS waves share the tile's rows
+template <int CPT, int NT, int MT, int NS = 1>
 struct C3nGeom {
-  static constexpr int TH = 4 * MT, HR = TH + 2, HC = 18;
+  static constexpr int TH = (4 / NS) * MT, HR = TH + 2, HC = 18;
   static constexpr int PP = odd_pitch(CPT);                    // slots per pixel
   static constexpr int PIECES = HR * HC * PP;                  // 16-byte slots of a halo tile (DMA piece order)
   static constexpr int NDMA = (PIECES + 255) / 256;            // requests per thread per tile
@@ -162,9 +164,10 @@ template <int NT> constexpr int match_tab_floats(int batch) { return batch * (2 
 
 // ILV: the previous tile's epilogue interleaved with this tile's matrix work (needs a second accumulator set; the 64-channel tile
 // has no registers left for it)
-template <int CPT, int NT, int MT, bool F32OUT, bool MATCH = false, bool ILV = true>
+template <int CPT, int NT, int MT, bool F32OUT, bool MATCH = false, bool ILV = true, int NS = 1>
 __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
-  using G = C3nGeom<CPT, NT, MT>;
+  using G = C3nGeom<CPT, NT, MT, NS>;
+  static_assert(!(MATCH && NS > 1), "the matching epilogue needs all of a pixel's channels in one wave");
   constexpr int HC = G::HC, NCH = G::NCH, NDMA = G::NDMA, PP = G::PP;
   constexpr int XP = PP * 16;                                   // pixel pitch in the halo image (bytes)
   extern __shared__ __attribute__((aligned(16))) char nsm[];
@@ -173,6 +176,8 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = sgpr(tid >> 6);
+  const int wr = NS > 1 ? wave / NS : wave;                     // row group of this wave
+  const int t0 = NS > 1 ? (wave % NS) * NT : 0;                 // its first column tile
   const int f = lane & 15, q = lane >> 4;
 
   // ---- the layer's weights: MFMA "A" operands (rows = output channels, permuted: chan_of_row), resident for the whole kernel ---
@@ -182,15 +187,17 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        wreg[j][t] = *reinterpret_cast<const f32x4*>(wp + (size_t)chan_of_row(t, f) * p.Kpad + 32 * j + 8 * q);
+      for (int t = 0; t < NT; ++t) {
+        const int row = chan_of_row(t0 + t, f);                 // (a split layer's last column tile may lie beyond the packed rows)
+        wreg[j][t] = keep_if(*reinterpret_cast<const f32x4*>(wp + (size_t)(row < p.Npad ? row : 0) * p.Kpad + 32 * j + 8 * q), row < p.Npad);
+      }
   }
   f32x4 bias[NT];                                               // this lane's quads (no loads inside the tile loop)
 #pragma unroll
   for (int n = 0; n < NT; ++n)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int ch = chan_of_quad(n, q) + r;
+      const int ch = chan_of_quad(t0 + n, q) + r;
       bias[n][r] = (p.shift && ch < p.N) ? p.shift[ch] : 0.f;
     }
 
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
     const int oo = o < 9 * CPT ? o : 0;
     const int tap = oo / CPT, c = oo - tap * CPT;
     const int ky = tap / 3, kx = tap - 3 * ky;
-    aoff[j] = ((wave * MT + ky) * HC + f + kx) * XP + c * 16;
+    aoff[j] = ((wr * MT + ky) * HC + f + kx) * XP + c * 16;
   }
   const bool tail_ok = 4 * (NCH - 1) + q < 9 * CPT;            // the last k-step may end in octets that do not exist (W is zero there)
 
@@ -270,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
   auto epi_ctx = [&](int t, EpiCtx& c) {
     int b, ty, tx;
     tile_decode(p.ti, t, b, ty, tx);
-    c.pix0 = ((size_t)(b * Hs + ty * G::TH + wave * MT) * Ws + tx * 16 + f);
+    c.pix0 = ((size_t)(b * Hs + ty * G::TH + wr * MT) * Ws + tx * 16 + f);
     c.gnorm = 1.f;
     if constexpr (MATCH) {
 #pragma unroll
@@ -320,7 +327,7 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
       for (int n = 0; n < NT; ++n) asm volatile("" ::"v"(v[n]));
       return;
     }
-    store_row<NT, F32OUT>(p.dst, (c.pix0 + (size_t)i * Ws) * p.ldd, v, q, MATCH ? p.ldd : p.N);
+    store_row<NT, F32OUT>(p.dst, (c.pix0 + (size_t)i * Ws) * p.ldd, v, q, MATCH ? p.ldd : p.N, t0);
   };
 
   // ---- one tile: the matrix work of tile s (halo buffer s & 1, accumulator set s & 1) with the EPILOGUE OF TILE s - 1 interleaved:
@@ -434,9 +441,9 @@ __global__ __launch_bounds__(256, 1) void c3n_kernel(const NarrowParams p) {
 
 int num_cus();   // narrow_bf16.hip
 
-template <int CPT, int NT, int MT, bool WITH_MATCH = true, bool ILV = true>
+template <int CPT, int NT, int MT, bool WITH_MATCH = true, bool ILV = true, int NS = 1>
 static int launch_c3n(NarrowParams p, int batch, bool f32out, bool match, hipStream_t stream) {
-  using G = C3nGeom<CPT, NT, MT>;
+  using G = C3nGeom<CPT, NT, MT, NS>;
   const int tiles_x = p.W / 16, tiles_y = p.H / G::TH;
   const long total = (long)tiles_x * tiles_y * batch;
   if (total > 0x7fffffffL || total * (tiles_x > tiles_y ? tiles_x : tiles_y) >= (1L << 32)) return fail(CCVPE_EINVAL, "c3n: grid too large");
@@ -445,9 +452,9 @@ static int launch_c3n(NarrowParams p, int batch, bool f32out, bool match, hipStr
   p.batch = batch;
   const int lds = G::LDS_BYTES + (match ? match_tab_floats<NT>(batch) * 4 : 0);
   if (lds > 160 * 1024) return fail(CCVPE_EINVAL, "c3n: batch %d needs %d B of LDS for the matching tables", batch, lds);
-  void (*kern)(const NarrowParams) = f32out ? c3n_kernel<CPT, NT, MT, true, false, ILV> : c3n_kernel<CPT, NT, MT, false, false, ILV>;
+  void (*kern)(const NarrowParams) = f32out ? c3n_kernel<CPT, NT, MT, true, false, ILV, NS> : c3n_kernel<CPT, NT, MT, false, false, ILV, NS>;
   if (match) {
-    if constexpr (WITH_MATCH) kern = f32out ? c3n_kernel<CPT, NT, MT, true, true, ILV> : c3n_kernel<CPT, NT, MT, false, true, ILV>;
+    if constexpr (WITH_MATCH) kern = f32out ? c3n_kernel<CPT, NT, MT, true, true, ILV, NS> : c3n_kernel<CPT, NT, MT, false, true, ILV, NS>;
     else return fail(CCVPE_EINVAL, "c3n: the matching epilogue is not built for this tile");
   }
   static int attr_lds[4] = {0, 0, 0, 0};

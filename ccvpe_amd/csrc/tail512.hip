@@ -419,12 +419,6 @@ static int tail_any(const ccvpe_tail_desc* d, void* stream) {
   p.tiles_x = p.tiles_y = p.tiles_total = p.tiles_per_wg = 0;
   const int nch = (d->c0 + SK - 1) / SK;
   hipStream_t st = (hipStream_t)stream;
-  // the narrow-level form (tail2_kernel, narrow_bf16.hip): whole halo by LDS-DMA, conv1.2 as a second MFMA pass over an LDS mid image
-  if (g_use_narrow) {
-    const int id = tail2_supported(sizeof(T) == 2, d->split, d->cout, d->c0, d->ld0, d->h1, d->w1, d->batch);
-    if (id) return tail2_dispatch(id, d->x, d->w, d->shift9, d->w2, d->b2, d->out, p.smx, d->batch, d->h1, d->w1, d->c0, d->ld0, d->kpad,
-                                  d->normalize, st);
-  }
   // Workgroup tile, fp32: 16 x 16 low-res pixels, one wave per parity, one tile per workgroup, two workgroups per CU (a workgroup's
   // stage 2/3 runs under the other's matrix loop).  Measured against 32 x 16 with two waves per parity and one workgroup per CU
   // (B = 64, tools/tail_probe.py): fp32 loc 1.11 vs 1.23 ms, fp32 ori 0.95 vs 1.01 — the smaller apron does not pay for the lost
@@ -467,10 +461,6 @@ using namespace ccvpe;
 
 extern "C" int ccvpe_tail512_partials(const ccvpe_tail_desc* desc, int is_bf16) {
   return is_bf16 ? tail_partials<bf16_t>(desc) : tail_partials<float>(desc);
-}
-extern "C" int ccvpe_tail512_route(const ccvpe_tail_desc* d, int is_bf16) {
-  if (!d) return fail(CCVPE_EINVAL, "tail512_route: null desc");
-  return g_use_narrow && tail2_supported(is_bf16, d->split, d->cout, d->c0, d->ld0, d->h1, d->w1, d->batch) ? 1 : 0;
 }
 extern "C" int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream) { return tail_any<float>(desc, stream); }
 extern "C" int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream) { return tail_any<bf16_t>(desc, stream); }

@@ -253,7 +253,7 @@ def upconv3x3(src0, c0, w_packed, shift9, n, *, batch, h1, w1, src1=None, c1=0, 
     return dst
 
 
-def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1, split=False, want_softmax=False, route_only=False):
+def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1, split=False, want_softmax=False):
     """The whole 512 x 512 decoder level in one launch (ccvpe_tail512_f32 / _bf16): folded deconv + conv.0 + ReLU + conv.2
     (+ F.normalize for cout = 2).  x [B,h1,w1,ld0]; w_packed / shift9 from models._pack_upconv (n = 16, no skip);
     w2 [cout,3,3,16], b2 [cout] fp32; returns [B,cout,2h1,2w1] fp32."""
@@ -271,9 +271,6 @@ def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1, 
     d.batch, d.h1, d.w1 = batch, h1, w1
     d.c0, d.ld0, d.kpad = c0, x.shape[-1], w_packed.shape[-1]
     d.cout, d.normalize, d.split = cout, int(bool(normalize)), int(bool(split))
-    kern = "tail2_kernel" if lib.ccvpe_tail512_route(ctypes.byref(d), int(dt != torch.float32)) == 1 else "tail512_kernel"
-    if route_only:
-        return kern
     smx = None
     if want_softmax:                         # cout = 1: per-(tile, wave) softmax partials for softmax_apply()
         npart = lib.ccvpe_tail512_partials(ctypes.byref(d), int(dt != torch.float32))
@@ -288,7 +285,7 @@ def tail512(x, c0, w_packed, shift9, w2, b2, cout, normalize, *, batch, h1, w1, 
     if rec is not None:
         m = batch * h1 * w1 * 4
         esz = 4.0 if dt == torch.float32 else 2.0
-        rec.end(kern + "<%s,%d>" % (("f32" if not split else "f32 as bf16 hi+lo") if dt == torch.float32 else "bf16", cout), "tail M%d Keff%d" % (m, 4 * c0),
+        rec.end("tail512_kernel<%s,%d>" % (("f32" if not split else "f32 as bf16 hi+lo") if dt == torch.float32 else "bf16", cout), "tail M%d Keff%d" % (m, 4 * c0),
                 2.0 * m * 16 * (4 * c0 + 9 * cout), esz * batch * h1 * w1 * c0 + 4.0 * m * cout, ev0)
     return (out, smx) if want_softmax else out
 

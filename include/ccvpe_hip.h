@@ -180,8 +180,6 @@ typedef struct ccvpe_tail_desc {
 
 int ccvpe_tail512_f32(const ccvpe_tail_desc* desc, void* stream);
 int ccvpe_tail512_bf16(const ccvpe_tail_desc* desc, void* stream);
-int ccvpe_tail512_route(const ccvpe_tail_desc* desc, int is_bf16);      /* 0 = tail512_kernel, 1 = tail2_kernel (csrc/tail2_impl.h: bf16 / hi + lo
-                                                                           operands at >= 2 tiles per CU); launches nothing */
 int ccvpe_tail512_partials(const ccvpe_tail_desc* desc, int is_bf16);   /* partial pairs per sample for this descriptor (launches nothing) */
 /* Softmax(dim=-1) over rows of n logits from n_partials (max, sum exp) pairs per row (models.py:320): out = exp(l - M) / S. */
 int ccvpe_softmax_apply_f32(const float* logits, const float* partials, int n_partials, float* out, int rows, int n,

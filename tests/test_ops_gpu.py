@@ -290,8 +290,6 @@ def test_upconv_level6_packs_two_images_per_tile(ops, b, bf16):
     (32, 32, 2, 32, 32, True),       # ori level 1 in bf16 storage (one 32-channel chunk)
     (48, 41, 1, 16, 16, True),       # bf16 loc (two chunks, the second half empty)
     (32, 25, 1, 16, 32, True),       # bf16, one chunk, cout 1
-    # tail2_kernel (csrc/tail2_impl.h; >= 2 tiles per CU): whole halo by LDS-DMA, conv1.2 as a second MFMA pass over an LDS mid image
-    (32, 32, 2, 128, 256, True),     # bf16 orientation tail
 ])
 def test_tail512_fuses_the_512_level(ops, cp, cref, cout, h1, w1, bf16):
     """deconv (k2 s2) -> conv3x3 + ReLU -> conv3x3 (16 -> cout) [-> F.normalize]  ==  ccvpe_tail512 (models.py:124-127,
@@ -317,15 +315,12 @@ def test_tail512_fuses_the_512_level(ops, cp, cref, cout, h1, w1, bf16):
     w2p = w2.permute(0, 2, 3, 1).contiguous().cuda()
     got = ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), cout, cout == 2, batch=b, h1=h1, w1=w1)
     assert tuple(got.shape) == (b, cout, 2 * h1, 2 * w1) and got.dtype == torch.float32
-    assert ops.tail512(xd, cp, fw, fshift, w2p, b2.cuda(), cout, cout == 2, batch=b, h1=h1, w1=w1, route_only=True) == \
-        ("tail2_kernel" if h1 * w1 >= 128 * 256 else "tail512_kernel")
     # cout = 2: the normalised field is ill-conditioned where the un-normalised vector is tiny -> compare where it is not
     if cout == 2:
         raw = F.conv2d(mid, w2, b2, padding=1)
         ok = (raw.pow(2).sum(1, keepdim=True).sqrt() > (0.2 if bf16 else 1e-2)).expand_as(want)
         err = ((got.cpu() - want).abs() * ok).max().item()
-        # (tail2_kernel keeps the 16-channel mid tensor as bf16 in LDS — what the unfused bf16 pair stores; tail512_kernel kept it fp32)
-        assert err <= ((4e-2 if h1 * w1 >= 128 * 256 else 3e-2) if bf16 else 1e-4), "tail512 ori: %.3e" % err
+        assert err <= (3e-2 if bf16 else 1e-4), "tail512 ori: %.3e" % err
         assert float((got.pow(2).sum(1).sqrt() - 1).abs().max()) < 1e-5
     else:
         close(got.cpu(), want, 2e-2 if bf16 else 1e-5, "tail512 cp=%d" % cp)

@@ -13,6 +13,7 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 lib = _lib.load()
 BF = torch.bfloat16
 shapes = [(64, 256, 256, 40, 40, False), (64, 256, 256, 40, 40, True), (64, 256, 256, 32, 32, False), (64, 128, 128, 64, 64, False),
+          (64, 128, 128, 80, 80, False),
           (32, 256, 256, 40, 40, False), (256, 256, 256, 32, 32, False)]
 
 
@@ -79,32 +80,3 @@ for (b, h1, cp, cref, cd, c1, co) in [(64, 128, 88, 81, 40, 16, 40), (64, 128, 6
     print("up3x3 B%d %dx%d %d|%d->%d  narrow %7.1f us (%6.1f TF, %5.2f TB/s)   tiled %7.1f us   x%.2f"
           % (b, h1, h1, cref, c1, co, t1, fl / t1 / 1e6, by / t1 / 1e6, t0, t0 / t1), flush=True)
 
-
-for (b, h1, cp, cref, cout, dt, split) in [(64, 256, 32, 32, 2, BF, False), (64, 256, 48, 41, 1, torch.float32, True),
-                                           (64, 256, 48, 41, 1, BF, False), (32, 256, 48, 41, 1, torch.float32, True)][:2 if FEW else 4]:
-    x = (torch.randn((b, h1, h1, cp), device="cuda")).to(dt)
-    x[..., cref:] = 0
-    wd = torch.randn((cref, 16, 2, 2), device="cuda") * cref ** -0.5
-    bd = torch.randn((16,), device="cuda") * 0.3
-    w3 = torch.randn((16, 16, 3, 3), device="cuda") / 12.0
-    b3 = torch.randn((16,), device="cuda") * 0.1
-    w2 = torch.randn((cout, 3, 3, 16), device="cuda") / 12.0
-    b2 = torch.randn((cout,), device="cuda") * 0.1
-    fw, fshift = _pack_upconv(wd, bd, [(0, 0, cref)], cp, w3, b3, dt)
-
-    def run():
-        return ops.tail512(x, cp, fw, fshift, w2, b2, cout, cout == 2, batch=b, h1=h1, w1=h1, split=split, want_softmax=(cout == 1))
-    res = {0: [], 1: []}
-    outs = {}
-    for rnd in range(3):
-        for on in (1, 0):
-            lib.ccvpe_set_narrow_kernels(on)
-            res[on].append(timed(run))
-            o = run()
-            outs[on] = (o[0] if cout == 1 else o).clone()
-    lib.ccvpe_set_narrow_kernels(1)
-    t1, t0 = min(res[1]), min(res[0])
-    diff = float((outs[1] - outs[0]).abs().max()) / float(outs[0].abs().max())
-    by = b * h1 * h1 * (cp * (4 if dt == torch.float32 else 2) + 4 * cout * 4)
-    print("tail B%d %dx%d c0 %d -> %d %s  tail2 %7.1f us (%5.2f TB/s)   tail512 %7.1f us   x%.2f   (max diff %.1e of scale)"
-          % (b, h1, h1, cref, cout, "hi+lo" if split else ("bf16 " if dt == BF else "f32  "), t1, by / t1 / 1e6, t0, t0 / t1, diff), flush=True)
