@@ -101,7 +101,7 @@ def upconv_route_name(desc, is_bf16):
     k, mt, nt, wn, pair = upconv_route(desc, is_bf16)
     ty = "bf16" if is_bf16 else "f32"
     if k == "up2_kernel":
-        return "up2_kernel<bf16,%d>" % desc.n
+        return "up2_kernel<bf16,%d,%d>" % (desc.c0, desc.n)
     return "%s<%s,%d,%d,%d%s>" % (k, ty, mt, nt, wn, ",pair" if pair else "")
 
 

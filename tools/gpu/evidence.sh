@@ -32,6 +32,10 @@ for w in f32 train bf16; do
   python3 $R/tools/pmc_traffic.py $OUT/pmc_fetch_$w/p_counter_collection.csv $OUT/pmc_write_$w/p_counter_collection.csv $OUT/pmc_traffic_$w.json $COMMIT "$w" || true
   python3 $R/tools/mfma_busy.py $OUT/pmc_mfma_$w/p_counter_collection.csv $OUT/pmc_mfma_$w/p_kernel_trace.csv $OUT/mfma_busy_$w.json $COMMIT || true
 done
+# per-dispatch trace of ONE forward on one stream (no two kernels share the chip): the per-family picture DESIGN reads
+for prec in bf16 fp32; do
+  bash $R/tools/gpu/fwd_trace.sh $prec > /dev/null 2>&1 && cp $R/gpurun_out/fwd_trace_$prec.csv $OUT/fwd_trace_$prec.csv
+done
 # keep the merge small: drop the per-dispatch counter / trace CSVs of the PMC passes
 rm -rf $OUT/pmc_fetch_* $OUT/pmc_write_* $OUT/pmc_mfma_*
 find $OUT -name '*kernel_trace.csv' -size +8M -delete

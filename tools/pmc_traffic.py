@@ -16,6 +16,20 @@ from collections import defaultdict
 def family(name):
     """rocprof kernel name -> the name bench.py's launch recorder uses.  bf16 instantiations arrive MANGLED (the profiler's
     demangler does not know the __bf16 type code DF16b): _ZN5ccvpe14conv3x3_kernelIDF16bLi4ELi5ELi2ELi4ELb1EEEv..."""
+    # round 5: the narrow-level kernels (bf16 only; template arguments are integers / bools) and upconv_dma_kernel's PAIR flag
+    m = re.search(r"c3n_kernelILi(\d+)ELi\d+ELi\d+ELb[01]ELb([01])E", name) or re.search(r"c3n_kernel<(\d+), *\d+, *\d+, *(?:true|false), *(true|false)", name)
+    if m:
+        return "c3n_kernel<bf16,%d%s>" % (8 * int(m.group(1)), ",match" if m.group(2) in ("1", "true") else "")
+    m = re.search(r"up2_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name) or re.search(r"up2_kernel<(\d+), *(\d+), *(\d+)", name)
+    if m:
+        c0, nt = 8 * int(m.group(1)), int(m.group(3))
+        return "up2_kernel<bf16,%d,%d>" % (c0, {3: 40, 2: 32}.get(nt, 16 * nt))
+    m = re.search(r"upconv_dma_kernelIDF16bLi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
+    if m:
+        return "upconv_dma_kernel<bf16,%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), ",pair" if m.group(4) == "1" else "")
+    m = re.search(r"upconv_dma_kernel<float, *(\d+), *(\d+), *(\d+), *(true|false)", name)
+    if m:
+        return "upconv_dma_kernel<f32,%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), ",pair" if m.group(4) == "true" else "")
     m = re.search(r"(igemm_kernel|pw_gemm_kernel|conv3x3_kernel|upconv_kernel|upconv_halo_kernel)IDF16bLi(\d+)ELi(\d+)ELi(\d+)E", name)
     if m:
         k, a, b, c = m.groups()
