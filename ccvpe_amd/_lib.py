@@ -88,6 +88,9 @@ PROTOTYPES = {
     "ccvpe_dwconv_nblk": (c_int, [c_int] * 4),
     "ccvpe_dwconv_f32": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p]),
     "ccvpe_mbconv_front_nblk": (c_int, [c_int] * 6),
+    "ccvpe_stem_dw_nblk": (c_int, [c_int] * 3),
+    "ccvpe_stem_dw_f32": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p]),
+    "ccvpe_stem_dw_bf16": (c_int, [c_void_p] * 9 + [c_int] * 4 + [c_void_p]),
     "ccvpe_mbconv_front_f32": (c_int, [c_void_p, c_void_p, c_int] + [c_void_p] * 7 + [c_int] * 8 + [c_void_p]),
     "ccvpe_se_gate_f32": (c_int, [c_void_p, c_int, c_float] + [c_void_p] * 5 + [c_int] * 3 + [c_void_p]),
     "ccvpe_ground_descriptor_f32": (c_int, [c_void_p, c_int, c_void_p, c_void_p, ctypes.POINTER(c_int),

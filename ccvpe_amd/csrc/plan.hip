@@ -49,6 +49,7 @@ static const std::unordered_map<std::string, Invoker>& registry() {
       CCVPE_REG(ccvpe_conv_igemm_f32), CCVPE_REG(ccvpe_conv_igemm_bf16), CCVPE_REG(ccvpe_conv_igemm_splitk_f32),
       CCVPE_REG(ccvpe_conv_igemm_splitk_bf16), CCVPE_REG(ccvpe_conv3x3_match1_bf16), CCVPE_REG(ccvpe_upconv3x3_f32), CCVPE_REG(ccvpe_upconv3x3_bf16),
       CCVPE_REG(ccvpe_tail512_f32), CCVPE_REG(ccvpe_tail512_bf16), CCVPE_REG(ccvpe_stem_conv_f32), CCVPE_REG(ccvpe_stem_conv_bf16),
+      CCVPE_REG(ccvpe_stem_dw_f32), CCVPE_REG(ccvpe_stem_dw_bf16),
       CCVPE_REG(ccvpe_dwconv_f32), CCVPE_REG(ccvpe_dwconv_bf16), CCVPE_REG(ccvpe_mbconv_front_f32), CCVPE_REG(ccvpe_mbconv_front_bf16),
       CCVPE_REG(ccvpe_se_gate_f32), CCVPE_REG(ccvpe_ground_descriptor_f32), CCVPE_REG(ccvpe_match_level_f32),
       CCVPE_REG(ccvpe_match_level_bf16), CCVPE_REG(ccvpe_head_conv3x3_f32), CCVPE_REG(ccvpe_head_conv3x3_bf16),

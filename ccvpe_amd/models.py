@@ -168,6 +168,8 @@ PACK_GRAPH = __import__("os").environ.get("CCVPE_PACK_GRAPH", "1") != "0"
 PACK_GATHER = __import__("os").environ.get("CCVPE_PACK_GATHER", "1") != "0"
 # one-hypothesis matching of level j + 1 inside level j's last conv (bf16 narrow levels); CCVPE_FUSE_MATCH=0 = separate launches (A/B runs)
 FUSE_MATCH = __import__("os").environ.get("CCVPE_FUSE_MATCH", "1") != "0"
+# stem conv + block-0 depthwise conv as one launch (csrc/stem_dw.hip); CCVPE_FUSE_STEM=0 = the two unfused launches (A/B runs)
+FUSE_STEM = __import__("os").environ.get("CCVPE_FUSE_STEM", "1") != "0"
 # eval forward: CCVPE_EVAL_TWO_STREAMS=0 runs the ground encoder on the main stream too (for per-kernel profiles in which no
 # two kernels share the chip; the default overlaps the two encoders)
 EVAL_TWO_STREAMS = __import__("os").environ.get("CCVPE_EVAL_TWO_STREAMS", "1") != "0"
@@ -364,11 +366,20 @@ def _pack_model(sd, kind, n_tail, dtype=torch.float32, fold=True, f32_tail=0):
 # ----------------------------------------------------------------------------------------
 def _run_encoder(e, img, circular, multiscale, dtype=torch.float32):
     """EfficientNet.extract_features[_multiscale] (efficientnet_pytorch/model.py:278-326)."""
-    x = ops.stem_conv(img, e.stem_w, e.stem_scale, e.stem_shift, circular, out_dtype=dtype)
+    blk0 = e.blocks[0]
+    stem_fused = (FUSE_STEM and not blk0.expand and blk0.k == 3 and blk0.s == 1 and blk0.mid == 32
+                  and ops.stem_dw_supported(img.shape[2], img.shape[3], circular) > 0)
+    x = None if stem_fused else ops.stem_conv(img, e.stem_w, e.stem_scale, e.stem_shift, circular, out_dtype=dtype)
     feats = []
     for blk in e.blocks:
-        b, h, w, _ = x.shape
-        if blk.expand and ops.mbconv_front_supported(h, w, blk.cin, blk.mid, blk.k, blk.s):
+        if x is not None:
+            b, h, w, _ = x.shape
+        if x is None:
+            # block 0 has no expand conv: the stem tensor only feeds its depthwise conv and stays in LDS (csrc/stem_dw.hip)
+            u, part = ops.stem_dw(img, e.stem_w, e.stem_scale, e.stem_shift, blk.w_dw, blk.s1, blk.b1, circular,
+                                  out_dtype=dtype)
+            b = u.shape[0]
+        elif blk.expand and ops.mbconv_front_supported(h, w, blk.cin, blk.mid, blk.k, blk.s):
             # early blocks: the 6x-expanded tensor stays in LDS (csrc/mbconv_front.hip)
             u, part = ops.mbconv_front(x, blk.w_exp, blk.s0, blk.b0, blk.w_dw, blk.s1, blk.b1, blk.mid,
                                        blk.k, blk.s, circular)

@@ -322,6 +322,38 @@ def stem_conv(x_nchw, w, scale, shift, circular, out_dtype=torch.float32):
     return y
 
 
+def stem_dw_supported(in_h, in_w, circular):
+    """SE partial rows per sample of the fused stem + block-0 depthwise launch, 0 when the shape runs unfused."""
+    return _lib.load().ccvpe_stem_dw_nblk(in_h, in_w, int(bool(circular)))
+
+
+def stem_dw(x_nchw, w, s0, b0, w_dw, s1, b1, circular, out_dtype=torch.float32):
+    """Stem conv + BN + swish -> block-0 depthwise 3x3 + BN + swish + SE squeeze partials, the stem tensor kept in LDS
+    (csrc/stem_dw.hip); returns (y [B,Ho,Wo,32], se_partial [B,nblk,32])."""
+    lib = _lib.load()
+    for t, nm in ((x_nchw, "x"), (w, "w"), (s0, "s0"), (b0, "b0"), (w_dw, "w_dw"), (s1, "s1"), (b1, "b1")):
+        _chk(t, nm)
+    b, c, h, wd = x_nchw.shape
+    if c != 3 or w_dw.numel() != 9 * 32:
+        raise ValueError("stem_dw expects 3 input channels and a 3x3x32 depthwise weight")
+    nblk = stem_dw_supported(h, wd, circular)
+    if nblk <= 0:
+        raise _lib.CcvpeError("stem_dw: unsupported shape %s" % (tuple(x_nchw.shape),))
+    ho, wo = (h + 1 - 3) // 2 + 1, (wd + 1 - 3) // 2 + 1
+    y = _empty((b, ho, wo, 32), device=x_nchw.device, dtype=out_dtype)
+    part = _empty((b, nblk, 32), device=x_nchw.device, dtype=torch.float32)
+    rec = _recorder
+    ev0 = rec.begin() if rec is not None else None
+    fn = lib.ccvpe_stem_dw_f32 if out_dtype == torch.float32 else lib.ccvpe_stem_dw_bf16
+    check(fn(_ptr(x_nchw), _ptr(w), _ptr(s0), _ptr(b0), _ptr(w_dw), _ptr(s1), _ptr(b1), _ptr(y), _ptr(part), b, h, wd,
+             int(bool(circular)), _stream()), "ccvpe_stem_dw")
+    if rec is not None:
+        flops = 2.0 * b * ho * wo * 32 * (27 + 9)
+        nbytes = 4.0 * b * 3 * h * wd + (4.0 if out_dtype == torch.float32 else 2.0) * b * ho * wo * 32
+        rec.end("stem_dw_kernel", "in %dx%dx3" % (h, wd), flops, nbytes, ev0)
+    return y, part
+
+
 def dwconv(x, w, scale, shift, k, stride, circular):
     """Depthwise conv + BN + swish; returns (y, se_partial [B,nblk,C])."""
     lib = _lib.load()

@@ -233,6 +233,23 @@ int ccvpe_dwconv_f32(const float* x, const float* w, const float* scale, const f
                      int circular, void* stream);
 
 /* -------------------------------------------------------------------------------------------
+ * Stem + MBConv block 0 front half in one launch (eval): ccvpe_stem_conv + ccvpe_dwconv(k = 3, stride 1, 32
+ * channels) + the SE squeeze partials, with the [B, H/2, W/2, 32] stem tensor kept in LDS
+ * (efficientnet_pytorch/model.py:289 then :108-110,114 of block 0, which has no expand conv).  fp32: the
+ * same bits as the two unfused calls.
+ * ccvpe_stem_dw_nblk() returns the number of SE partial rows per sample (8 x 32 output tiles), 0 if the shape
+ * is not supported (circular padding with an odd width): then use the two unfused calls.
+ *   x_nchw [B,3,H,W] fp32, w [27][32], w_dw [3][3][32], y [B,Ho,Wo,32], se_partial [B][nblk][32]
+ * ----------------------------------------------------------------------------------------- */
+int ccvpe_stem_dw_nblk(int in_h, int in_w, int circular);
+int ccvpe_stem_dw_f32(const float* x_nchw, const float* w, const float* s0, const float* b0, const float* w_dw,
+                      const float* s1, const float* b1, float* y, float* se_partial, int batch, int in_h,
+                      int in_w, int circular, void* stream);
+int ccvpe_stem_dw_bf16(const float* x_nchw, const float* w, const float* s0, const float* b0, const float* w_dw,
+                       const float* s1, const float* b1, void* y, float* se_partial, int batch, int in_h,
+                       int in_w, int circular, void* stream);
+
+/* -------------------------------------------------------------------------------------------
  * Fused MBConv front half for the early (large) blocks: expand 1x1 + BN0 + swish -> depthwise kxk +
  * BN1 + swish + SE squeeze partials, with the 6x-expanded tensor kept in LDS
  * (efficientnet_pytorch/model.py:102-110,114).  Same results as ccvpe_conv_igemm_f32 followed by

@@ -405,6 +405,42 @@ def test_stem_tiles_borders_and_wrap(ops, b, h, w, circ, bf16):
     close(nchw(raw), F.conv2d(xp, wt, stride=2), 1e-5, "stem raw")
 
 
+@pytest.mark.parametrize("b,h,w,circ,bf16", [(2, 70, 300, True, False), (3, 37, 131, False, False), (1, 320, 640, True, True),
+                                             (2, 154, 231, False, True), (2, 16, 64, True, False), (1, 512, 512, False, False)])
+def test_stem_and_block0_depthwise_in_one_launch(ops, b, h, w, circ, bf16):
+    """csrc/stem_dw.hip: stem conv + BN + swish -> depthwise 3x3 + BN + swish + squeeze partials with the stem tensor in LDS.
+    Against the oracle's two convolutions (zero / circular padding of BOTH: the depthwise conv pads the stem OUTPUT), on shapes
+    that are not multiples of the 8 x 32 output tile; fp32 must also equal the two unfused launches bit for bit."""
+    x = synth.normal((b, 3, h, w), 4400 + h)
+    wt = synth.normal((32, 3, 3, 3), 4401, (1.0 / 27) ** 0.5)
+    s0, b0 = synth.uniform((32,), 4402, 0.5, 1.5), synth.normal((32,), 4403, 0.1)
+    wd = synth.normal((32, 1, 3, 3), 4404, 1.0 / 3)
+    s1, b1 = synth.uniform((32,), 4405, 0.5, 1.5), synth.normal((32,), 4406, 0.1)
+    xp = F.pad(x, (0, 1, 0, 0), mode="circular") if circ else F.pad(x, (0, 1, 0, 0))
+    xp = F.pad(xp, (0, 0, 0, 1))
+    t = O.swish(F.conv2d(xp, wt, stride=2) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    want = O.swish(O.same_conv(t, wd, 3, 1, 224, circ, groups=32) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    dt = torch.bfloat16 if bf16 else torch.float32
+    assert ops.stem_dw_supported(h, w, circ) == -(-t.shape[2] // 8) * -(-t.shape[3] // 32)
+    args = (dev(x), dev(wt.permute(2, 3, 1, 0)), dev(s0), dev(b0))
+    dwa = (dev(wd.reshape(32, 3, 3).permute(1, 2, 0)), dev(s1), dev(b1))
+    got, part = ops.stem_dw(*args, *dwa, circ, out_dtype=dt)
+    assert tuple(got.shape) == (b, t.shape[2], t.shape[3], 32)
+    close(nchw(got).float(), want, 1e-2 if bf16 else 1e-5, "stem + dw %dx%d" % (h, w))
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-2 if bf16 else 1e-4, "squeeze partials")
+    if not bf16:
+        u, part2 = ops.dwconv(ops.stem_conv(*args, circ), *dwa, 3, 1, circ)
+        assert torch.equal(got, u), "the fused launch differs from stem_conv + dwconv"
+        close(part.sum(1), part2.sum(1), 1e-5, "squeeze partials vs the unfused launches")
+
+
+def test_stem_dw_rejects_odd_width_with_circular_padding(ops):
+    assert ops.stem_dw_supported(64, 131, True) == 0 and ops.stem_dw_supported(64, 131, False) > 0
+    with pytest.raises(Exception):
+        ops.stem_dw(dev(synth.normal((1, 3, 64, 131), 1)), dev(torch.zeros(3, 3, 3, 32)), dev(torch.ones(32)), dev(torch.zeros(32)),
+                    dev(torch.zeros(3, 3, 32)), dev(torch.ones(32)), dev(torch.zeros(32)), True)
+
+
 @pytest.mark.parametrize("k,s,c,h,w,circ", [(3, 1, 32, 9, 12, False), (3, 2, 96, 10, 14, True), (5, 2, 144, 8, 12, True),
                                             (5, 1, 480, 6, 7, False), (5, 1, 1152, 5, 9, True), (3, 2, 240, 7, 9, False),
                                             (5, 2, 672, 9, 11, False), (3, 1, 1152, 4, 6, True)])
