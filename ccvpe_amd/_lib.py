@@ -77,6 +77,7 @@ PROTOTYPES = {
     "ccvpe_conv_igemm_splitk_floats": (c_int, [ctypes.POINTER(ConvDesc), c_int]),
     "ccvpe_conv_igemm_route": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_set_narrow_kernels": (c_int, [c_int]),
+    "ccvpe_set_pw_ring_kernels": (c_int, [c_int]),
     "ccvpe_conv3x3_match1_ok": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_conv3x3_match1_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
@@ -204,6 +205,8 @@ def load():
         fn.argtypes = args
     if os.environ.get("CCVPE_NARROW") == "0" and hasattr(lib, "ccvpe_set_narrow_kernels"):
         lib.ccvpe_set_narrow_kernels(0)           # A/B runs (tools/gpu/*.sh): the tiled kernels for the narrow decoder levels
+    if os.environ.get("CCVPE_PW_RING") == "0" and hasattr(lib, "ccvpe_set_pw_ring_kernels"):
+        lib.ccvpe_set_pw_ring_kernels(0)          # A/B runs: pw_gemm_kernel for every fp32 pointwise layer
     _lib = lib
     return lib
 

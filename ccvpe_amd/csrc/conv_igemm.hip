@@ -337,6 +337,14 @@ extern "C" int ccvpe_set_narrow_kernels(int on) {
   return prev;
 }
 
+// the same kind of switch for the fp32 pointwise ring kernel (csrc/conv_pw2_f32.hip)
+namespace ccvpe { bool g_use_pw2 = true; }
+extern "C" int ccvpe_set_pw_ring_kernels(int on) {
+  const int prev = ccvpe::g_use_pw2 ? 1 : 0;
+  ccvpe::g_use_pw2 = on != 0;
+  return prev;
+}
+
 // route (optional): filled with the kernel family + tile the dispatcher picks for `d` (CCVPE_ROUTE_* | MT << 8 | NT << 12 |
 // WN << 16) and NOTHING is launched — ccvpe_conv_igemm_route(); tests and bench.py's launch recorder read it instead of
 // mirroring the dispatch rules in Python
@@ -434,6 +442,7 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     else if (is_pw && pw_tile) {
       fam = CCVPE_ROUTE_PW_GEMM;
       if (mt == 4 && nt == 5 && wn == 1) { nt = 3; wn = 2; }
+      if (!sk && sizeof(T) == 4 && pw2_supported(p, mt, nt, wn)) fam = CCVPE_ROUTE_PW_RING;
     }
     *route = fam | (mt << 8) | (nt << 12) | (wn << 16);
     return CCVPE_OK;
@@ -444,8 +453,12 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     }
     if (is3x3) return conv3x3_dispatch<T>(p, d->batch, c.mt, c.nt, c.wn, st);
     if (is_pw && 16 * c.nt * c.wn > 48) {
-      if (c.mt == 4 && c.nt == 5 && c.wn == 1) return pw_dispatch<T>(p, 4, 3, 2, st);
-      return pw_dispatch<T>(p, c.mt, c.nt, c.wn, st);
+      const bool reroute = c.mt == 4 && c.nt == 5 && c.wn == 1;
+      const int mt = c.mt, nt = reroute ? 3 : c.nt, wn = reroute ? 2 : c.wn;
+      if constexpr (sizeof(T) == 4) {
+        if (pw2_supported(p, mt, nt, wn)) return pw2_dispatch(p, mt, nt, wn, st);
+      }
+      return pw_dispatch<T>(p, mt, nt, wn, st);
     }
   }
 #define CCVPE_CASE(MT_, NT_, WN_) \

@@ -165,6 +165,11 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
   int m0 = (tile / p.tiles_n) * BM, n0 = (tile % p.tiles_n) * BN;
   load_stage(m0, n0, 0);
   load_ss(n0);
+#ifdef CCVPE_ABLATE
+  if ((p.ablate >> 8) > 0 && blockIdx.x >= (gridDim.x >> 1)) {          // experiment: de-phase the two workgroups of a CU
+    for (int i = 0; i < (p.ablate >> 8); ++i) __builtin_amdgcn_s_sleep(16);   // ~1024 cycles each
+  }
+#endif
   while (true) {
     f32x4 acc[MT][NT];
 #pragma unroll
@@ -187,6 +192,10 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
     }
     for (int s = 0; s < nstages; ++s) {
       const bool more = s + 1 < nstages;
+#ifdef CCVPE_ABLATE
+      if (p.ablate & 2) {
+      } else
+#endif
       if (more) load_stage(m0, n0, s + 1);
       else if (PREFETCH && has_next) {                   // next tile's first stage: lands during the epilogue below
         load_stage(m0n, n0n, 0);
@@ -240,6 +249,9 @@ __global__ __launch_bounds__(256, 2) void pw_gemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int ii = 0; ii < IC; ++ii) {
           f32x4 vv = acc[ic * IC + ii][j] * sc + sh;
+#ifdef CCVPE_ABLATE
+          if (!(p.ablate & 8))
+#endif
           if (ACT == CCVPE_ACT_SWISH) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) vv[q] = swishf(vv[q]);
@@ -334,9 +346,10 @@ static int launch_pw_act(const IgemmParams& p0, hipStream_t stream) {
   p.ksplit = 1;
   p.sps = p.stages;
   p.partial = nullptr;
-#ifdef CCVPE_ABLATE   // diagnostics build only: 1 = no global stores, 4 = no MFMAs
+#ifdef CCVPE_ABLATE   // diagnostics build only: 1 = no global stores, 2 = no stage loads after the first, 4 = no MFMAs, 8 = no swish
   static const int ablate = getenv("CCVPE_PW_ABLATE") ? atoi(getenv("CCVPE_PW_ABLATE")) : 0;
-  p.ablate = ablate;
+  static const int stagger = getenv("CCVPE_PW_STAGGER") ? atoi(getenv("CCVPE_PW_STAGGER")) : 0;   // x 1024 cycles
+  p.ablate = ablate | (stagger << 8);
 #endif
   static bool attr_set = false;               // one flag per instantiation
   if (!attr_set) {

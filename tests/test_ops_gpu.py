@@ -124,6 +124,52 @@ def test_pw_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd, with_res, act, 
         assert float((got[..., cout:].float() + 7.0).abs().max()) == 0.0, "columns beyond N were written"
 
 
+@pytest.mark.parametrize("cin,cout,hw,gated,with_res,act,b", [
+    (112, 672, 32, False, False, "swish", 2),      # expand of blocks 9-11 (128 x 112 tile, 4 ring stages), K = 3.5 stages
+    (672, 112, 32, True, True, "none", 2),         # their project conv: SE gate on the A fragments + skip
+    (80, 480, 32, False, False, "swish", 2),       # 128 x 160 tile: 3 ring stages, K = 2.5 stages
+    (192, 1152, 16, False, False, "swish", 3),     # 128 x 128 tile, hw = 256: two tiles per sample
+    (1152, 192, 16, True, True, "none", 2),        # 128 x 96 tile, 36 stages, the longest gate vector
+    (320, 1280, 16, False, False, "swish", 1),     # the head conv
+    (672, 112, 32, True, False, "none", 64),       # full size: 512 tiles over 256 workgroups (two tiles each, ring across the tile edge)
+    (112, 672, 32, False, False, "swish", 64),     # full size: 3 072 tiles, 12 per workgroup
+])
+def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_res, act, b):
+    """csrc/conv_pw2_f32.hip (route ASSERTED): the fp32 pointwise GEMM with the LDS-DMA ring against the oracle convolution (small
+    batches) and BIT-IDENTICAL to pw_gemm_kernel, which ccvpe_set_pw_ring_kernels(0) brings back behind the same entry point."""
+    from ccvpe_amd.models import _pack_conv
+    from ccvpe_amd import _lib
+    big = b > 8
+    gen = dict(device="cuda") if big else {}
+    x = synth.normal((b, cin, hw, hw), 610 + cin, **gen)
+    wt = synth.normal((cout, cin, 1, 1), 620 + cout, (1.0 / cin) ** 0.5)
+    sc, sh = synth.uniform((cout,), 629, 0.5, 1.5), synth.normal((cout,), 630, 0.1)
+    gate = synth.uniform((b, cin), 631, 0.1, 1.0) if gated else None
+    res = synth.normal((b, cout, hw, hw), 632, **gen) if with_res else None
+    kw = dict(batch=b, in_h=hw, in_w=hw, scale=dev(sc), shift=dev(sh), act=ops.ACT_SWISH if act == "swish" else ops.ACT_NONE,
+              gate=dev(gate) if gated else None, residual=dev(nhwc(res)) if with_res else None)
+    xs, wp = dev(nhwc(x)), dev(_pack_conv(wt))
+    route = ops.conv_igemm(xs, cin, wp, cout, route_only=True, **kw)
+    assert route[0] == "pw_ring", route
+    got = ops.conv_igemm(xs, cin, wp, cout, **kw)
+    lib = _lib.load()
+    prev = lib.ccvpe_set_pw_ring_kernels(0)
+    try:
+        assert ops.conv_igemm(xs, cin, wp, cout, route_only=True, **kw)[0] == "pw_gemm"
+        old = ops.conv_igemm(xs, cin, wp, cout, **kw)
+    finally:
+        lib.ccvpe_set_pw_ring_kernels(prev)
+    assert torch.equal(got, old), "pw_ring differs from pw_gemm: max %.3e" % float((got - old).abs().max())
+    if not big:
+        xin = x * gate.view(b, cin, 1, 1) if gated else x
+        want = F.conv2d(xin, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        if act == "swish":
+            want = O.swish(want)
+        if with_res:
+            want = want + res
+        close(nchw(got), want, 1e-4, "pw ring %d->%d" % (cin, cout))
+
+
 def test_conv_route_matches_dispatch_rules(ops):
     """ccvpe_conv_igemm_route: 3x3 s1 p1 -> conv3x3; 1x1 N > 48 act NONE/SWISH -> pw_gemm; ReLU / narrow N / gather forms ->
     the generic kernel (csrc/conv_igemm.hip: conv_igemm_any)."""
