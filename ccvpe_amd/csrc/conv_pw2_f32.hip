@@ -29,8 +29,15 @@ __device__ __forceinline__ void pw2_dma(unsigned lds, unsigned voff, const char*
   asm volatile("s_mov_b32 m0, %0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(lds), "v"(voff), "s"(sbase) : "memory", "m0");
 }
 template <int N> __device__ __forceinline__ void pw2_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// lanes of ONE wave exchange data through LDS: the hardware keeps a wave's LDS operations in order, the compiler must too (without
+// the fence it may move a lane's reads above the same lane's writes — other addresses, as far as a single thread can tell)
+__device__ __forceinline__ void pw2_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-constexpr int PW2_LDS = 160 * 1024;
+constexpr int PW2_LDS = 80 * 1024;                                    // two workgroups per CU
 constexpr int PW2_NSTG = 3;                                          // ring stages (two in flight while one is consumed)
 constexpr int PW2_SS = 256;                                          // floats reserved per scale / shift vector (BN <= 160)
 // floats of one tile's vectors in LDS: the sample's gate vector (whole 256-float requests) + scale + shift
@@ -41,15 +48,15 @@ struct Pw2Geom {
   static constexpr int WM = 4 / WN;
   static constexpr int BM = 16 * MT * WM;
   static constexpr int BN = 16 * NT * WN;
-  static constexpr int KS = 32;                                     // floats of K per stage (8 pieces of 16 bytes per row)
+  static constexpr int KS = 16;                                     // floats of K per stage: one 64-byte piece per row
   static constexpr int STAGE_FLOATS = (BM + BN) * KS;
-  static constexpr int NA = BM / 8, NB = BN / 8, ND = NA + NB;      // DMA requests (8 rows x 128 bytes each) per stage
+  static constexpr int NA = BM / 16, NB = BN / 16, ND = NA + NB;    // DMA requests (16 rows x 64 bytes each) per stage
   static constexpr int DPW = (ND + 3) / 4;                          // ... per wave (request j belongs to wave j % 4)
   static constexpr int DMIN = ND / 4;                               // the fewest any wave issues per stage: the unit of the waits
   static constexpr int NSTG = NSTG_;
   static constexpr int RING_BYTES = NSTG * STAGE_FLOATS * 4;
-  // epilogue: per wave a private LDS patch of 16 pixel rows x (16 NT + 4) floats, read back as EPR 16-byte pieces per row
-  static constexpr int EPP = 16 * NT + 4, EPR = 4 * NT, EPK = (16 * EPR + 63) / 64, EP_FLOATS = 16 * EPP;
+  // epilogue: per wave a private LDS patch of 16 pixel rows x (half of the wave's column tiles, 16 NH + 4 floats)
+  static constexpr int NH = (NT + 1) / 2, EPP = 16 * NH + 4, EP_FLOATS = 16 * EPP;
   static int lds_bytes(bool gated, int c0) { return RING_BYTES + 4 * EP_FLOATS * 4 + 2 * pw2_aux_stride(gated, c0) * 4; }
   static_assert((NSTG - 2) * DMIN <= 63, "vmcnt immediate");
 };
@@ -60,7 +67,7 @@ struct Pw2Geom {
 template <int MT, int NT, int WN, int ACT, bool GATED, bool RES, int NSTG_>
 __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
   using G = Pw2Geom<MT, NT, WN, NSTG_>;
-#ifdef CCVPE_ABLATE   // diagnostics build (tools/gpu/ablate_pw.sh): 1 no global stores, 2 no epilogue, 4 no MFMAs, 8 no DMA after the prologue, 16 no waits / ring barriers
+#ifdef CCVPE_ABLATE   // diagnostics build (tools/gpu/ablate_pw.sh): 1 no global stores, 2 no epilogue, 4 no MFMAs, 8 no DMA after the prologue, 16 no waits / ring barriers, 32 no fragment reads
   const int abl = p.ablate;
 #else
   constexpr int abl = 0;
@@ -79,34 +86,26 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
   const int frow = lane & 15;
-  int fcol[2];
-#pragma unroll
-  for (int kp = 0; kp < 2; ++kp) fcol[kp] = ((kp * 4 + (lane >> 4)) ^ ((frow >> 1) & 7)) * 4;
+  // panel layout: row r holds its four 16-byte pieces at slots piece ^ swz(r), swz(r) = (-(r >> 2)) & 3: the 16 lanes of every
+  // ds_read_b128 lane group ({0-3, 12-15, 20-27}, ...: rows 0-3 and 12-15 of one piece, rows 4-11 of the next) then cover the 16
+  // slots of a 256-byte bank row exactly once
+  const int fcol = ((lane >> 4) ^ ((0 - (frow >> 2)) & 3)) * 4;
   const int epix = lane & 15, en = (lane >> 4) * 4;
   const int hw = p.Ho * p.Wo;
   const int nst = (p.c0 + KS - 1) / KS;
-  const bool last_half = (p.c0 % KS) != 0;               // the last stage holds 16 floats of K: its upper pieces duplicate the lower ones
   const float* res = reinterpret_cast<const float*>(p.residual);
 
-  // ---- DMA lane geometry: request j (wave j % 4) covers rows 8 j' .. 8 j' + 7 of the A panel (j < NA) or of the W panel; lane ->
-  // (row 8 j' + lane / 8, LDS slot lane % 8) fetches global piece slot ^ ((row >> 1) & 7) of its row -------------------------------
-  unsigned voff[DPW], voffh[DPW];                        // byte offsets from the stage's scalar base (full stage / half stage)
+  // ---- DMA lane geometry: request j (wave j % 4) covers rows 16 j' .. 16 j' + 15 of the A panel (j < NA) or of the W panel; lane ->
+  // (row 16 j' + lane / 4, LDS slot lane % 4) fetches global piece slot ^ swz(row) of its row ---------------------------------------
+  unsigned voff[DPW];                                    // byte offsets from the stage's scalar base
 #pragma unroll
   for (int i = 0; i < DPW; ++i) {
     const int j = wave + 4 * i;
     const bool isA = j < NA;
-    const int r = 8 * (isA ? j : j - NA) + (lane >> 3);
-    const int c = (lane & 7) ^ ((r >> 1) & 7);
+    const int r = 16 * (isA ? j : j - NA) + (lane >> 2);
+    const int c = (lane & 3) ^ ((0 - (r >> 2)) & 3);
     const unsigned ld = (unsigned)(isA ? p.ld0 : p.Kpad);
     voff[i] = ((unsigned)r * ld + (unsigned)c * 4u) * 4u;
-    voffh[i] = ((unsigned)r * ld + (unsigned)(c & 3) * 4u) * 4u;
-  }
-  int eprow[G::EPK], epcol[G::EPK];                      // epilogue read-back: piece lane + 64 k of the patch -> (pixel row, float column)
-#pragma unroll
-  for (int k = 0; k < G::EPK; ++k) {
-    const int q = lane + 64 * k;
-    eprow[k] = q / G::EPR;
-    epcol[k] = (q - eprow[k] * G::EPR) * 4;
   }
   const char* a0 = reinterpret_cast<const char*>(p.src0);
   const char* w0 = reinterpret_cast<const char*>(p.w);
@@ -129,11 +128,10 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
     const unsigned slot = lds0 + (unsigned)((gi % NSTG) * G::STAGE_FLOATS * 4);
     const char* ab = a0 + ((size_t)mi0 * p.ld0 + (size_t)si * KS) * 4;
     const char* wb = w0 + ((size_t)ni0 * p.Kpad + (size_t)si * KS) * 4;
-    const bool half = last_half && si == nst - 1;
 #pragma unroll
     for (int i = 0; i < DPW; ++i) {
       const int j = wave + 4 * i;
-      if (j < ND) pw2_dma(slot + (unsigned)(j * 1024), half ? voffh[i] : voff[i], j < NA ? ab : wb);
+      if (j < ND) pw2_dma(slot + (unsigned)(j * 1024), voff[i], j < NA ? ab : wb);
     }
     if (si == 0 && wave == 3) {                          // the tile's vectors (wave 3 has the fewest panel requests)
       const unsigned ax = aux0 + (unsigned)((ti & 1) * AUX_STRIDE * 4);
@@ -157,12 +155,39 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
     }
   };
 #pragma unroll 1
-  for (int k = 0; k < NSTG - 1 && gi < total_stages; ++k) issue();
+  for (int k = 0; k < NSTG && gi < total_stages; ++k) issue();
+
+  // read side (one stage ahead of the MFMAs): stage gr -> (tile tr, stage sr).  The fragments of stage g + 1 are requested from LDS
+  // BEFORE the MFMAs of stage g are issued (two register sets, the stage loop unrolled by two): every wave of the CU asks for its 9-12
+  // fragments at the same moment, and with the reads right in front of their MFMAs all 8 waves then sat out the LDS queue together
+  // (the bare read + MFMA loop ran at 77 % of the matrix rate).
+  struct Frag { f32x4 a[MT], b[NT], g; };
+  Frag F0, F1;
+  int gr = 0, tr = 0, sr = 0;
+  auto read_frag = [&](Frag& F) {
+    if (abl & 32) return;                                // (diagnostics: MFMAs on whatever the registers hold)
+    const float* As = ring + (gr % NSTG) * G::STAGE_FLOATS;
+    const float* Bs = As + BM * KS;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) F.a[i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * KS + fcol]);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) F.b[j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * KS + fcol]);
+    if (GATED) F.g = *reinterpret_cast<const f32x4*>(aux + (tr & 1) * AUX_STRIDE + sr * KS + (lane >> 4) * 4);
+    ++gr;
+    if (++sr == nst) { sr = 0; ++tr; }
+  };
 
   int m0 = 0, n0 = 0;
   f32x4 acc[MT][NT];
   int tc = 0, sc_ = 0;                                   // compute side: tile, stage
-  for (int g = 0; g < total_stages; ++g) {
+  // stage 0: at most the two later stages of this wave's requests may still be in flight (requests complete in order)
+  if (total_stages >= 3) pw2_wait<2 * DMIN>();
+  else if (total_stages == 2) pw2_wait<DMIN>();
+  else pw2_wait<0>();
+  __syncthreads();
+  read_frag(F0);
+
+  auto step = [&](Frag& Fc, Frag& Fn, int g) {
     if (sc_ == 0) {
       const int t = xcd_tile((int)blockIdx.x + tc * gsz, p.tiles_total);
       m0 = (t / p.tiles_n) * BM;
@@ -172,47 +197,30 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // stage g has landed once at most `ahead` later stages of this wave's requests are outstanding (requests complete in order;
-    // the epilogue's global stores only make the count conservative)
-    const int ahead = min(NSTG - 2, total_stages - 1 - g);
-    if (!(abl & 16)) {
-      if (ahead >= 2 && NSTG >= 4) pw2_wait<2 * DMIN>();
-      else if (ahead >= 1) pw2_wait<DMIN>();
-      else pw2_wait<0>();
-      __syncthreads();                                   // stage g visible; every wave is past stage g - 1: its slot is free
+    if (g + 1 < total_stages) {
+      if (!(abl & 16)) {
+        // this wave's LDS reads of stage g (requested a whole stage ago) have returned: its slot may be refilled after the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (g + 2 < total_stages) pw2_wait<DMIN>();      // stage g + 1 has landed; stage g + 2 may be in flight
+        else pw2_wait<0>();
+        __syncthreads();                                 // stage g + 1 visible to every wave; every wave has read stage g
+      }
+      read_frag(Fn);
+      if (gi < total_stages && !(abl & 8)) issue();      // stage g + 3 into the slot of stage g
     }
-    if (gi < total_stages && !(abl & 8)) issue();        // stage g + NSTG - 1 into the slot of stage g - 1
-    const float* As = ring + (g % NSTG) * G::STAGE_FLOATS;
-    const float* Bs = As + BM * KS;
-    const float* gl = aux + (tc & 1) * AUX_STRIDE + sc_ * KS + (lane >> 4) * 4;
-    // both 16-float pieces of the stage are requested from LDS up front: the second one's latency hides under the first one's MFMAs
-    const bool two = sc_ * KS + 16 < p.c0;               // K tail: the last stage may hold one piece (uniform)
-    f32x4 af[2][MT], bf[2][NT], g4[2];
-#pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
-      if (kp == 1 && !two) break;
-#pragma unroll
-      for (int i = 0; i < MT; ++i) af[kp][i] = *reinterpret_cast<const f32x4*>(&As[((wm * MT + i) * 16 + frow) * KS + fcol[kp]]);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) bf[kp][j] = *reinterpret_cast<const f32x4*>(&Bs[((wn * NT + j) * 16 + frow) * KS + fcol[kp]]);
-      if (GATED) g4[kp] = *reinterpret_cast<const f32x4*>(gl + kp * 16);
-    }
-#pragma unroll
-    for (int kp = 0; kp < 2; ++kp) {
-      if ((kp == 1 && !two) || (abl & 4)) break;
+    if (!(abl & 4)) {
       if (GATED) {
 #pragma unroll
-        for (int i = 0; i < MT; ++i) af[kp][i] *= g4[kp];
+        for (int i = 0; i < MT; ++i) Fc.a[i] *= Fc.g;
       }
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
-          for (int j = 0; j < NT; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[kp][j][kk], af[kp][i][kk], acc[i][j], 0, 0, 0);
+          for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(Fc.b[j][kk], Fc.a[i][kk], acc[i][j], 0, 0, 0);
     }
-    if (++sc_ < nst) continue;
+    if (++sc_ < nst) return;
     sc_ = 0;
     // ---- epilogue: BN (+ swish) in registers, then each WAVE turns its 16-pixel x (16 NT)-channel row tiles through a private LDS
     // patch — no workgroup barrier, the LDS queue of a wave is in order — and stores whole row pieces: consecutive lanes write
@@ -222,44 +230,52 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
     // the arithmetic costs nothing measurable.
     const float* Ss = aux + (tc & 1) * AUX_STRIDE + SS_OFF;
     ++tc;
-    if (abl & 2) continue;
-    f32x4 scv[NT], shv[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int nl = (wn * NT + j) * 16 + en;
-      scv[j] = *reinterpret_cast<const f32x4*>(&Ss[nl]);
-      shv[j] = *reinterpret_cast<const f32x4*>(&Ss[PW2_SS + nl]);
-    }
-    float* drow0 = reinterpret_cast<float*>(p.dst) + (size_t)(m0 + wm * MT * 16) * p.ldd + n0 + wn * NT * 16;
-    const float* rrow0 = RES ? res + (size_t)(m0 + wm * MT * 16) * p.ldres + n0 + wn * NT * 16 : nullptr;
+    if (abl & 2) return;
+    const float* Sl = Ss + wn * NT * 16 + en;             // this lane's channels of column tile 0 (BN vectors re-read per row tile:
+                                                         // 2 NT registers of them held across the epilogue spill the fragment sets)
+    // (wave-uniform 64-bit bases + 32-bit lane offsets: scalar-base stores / loads instead of a 64-bit address pair per access)
+    char* dbase = reinterpret_cast<char*>(reinterpret_cast<float*>(p.dst) + (size_t)(m0 + wm * MT * 16) * p.ldd + n0 + wn * NT * 16);
+    const char* rbase = RES ? reinterpret_cast<const char*>(res + (size_t)(m0 + wm * MT * 16) * p.ldres + n0 + wn * NT * 16) : nullptr;
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        f32x4 vv = acc[i][j] * scv[j] + shv[j];
-        if (ACT == CCVPE_ACT_SWISH) {
+      for (int c = 0; c < 2; ++c) {                      // the patch holds 16 pixel rows x half of the wave's column tiles
+        constexpr int NH = G::NH;
+        const int j0 = c * NH;
+        const int nj = c == 0 ? NH : NT - NH;            // (compile-time after unrolling)
+        if (nj <= 0) continue;
+        pw2_wave_sync();                                 // the previous patch has been read back
 #pragma unroll
-          for (int q = 0; q < 4; ++q) vv[q] = swishf(vv[q]);
+        for (int j = 0; j < NH; ++j) {
+          if (j >= nj) break;
+          const f32x4 scv = *reinterpret_cast<const f32x4*>(Sl + (j0 + j) * 16);
+          const f32x4 shv = *reinterpret_cast<const f32x4*>(Sl + PW2_SS + (j0 + j) * 16);
+          f32x4 vv = acc[i][j0 + j] * scv + shv;
+          if (ACT == CCVPE_ACT_SWISH) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) vv[q] = swishf(vv[q]);
+          }
+          *reinterpret_cast<f32x4*>(&ep[epix * G::EPP + j * 16 + en]) = vv;
         }
-        *reinterpret_cast<f32x4*>(&ep[epix * G::EPP + j * 16 + en]) = vv;
-      }
-      // (RES is a template parameter: with a runtime `if (res)` the compiler made the adds unconditional behind a select and put an
-      // s_waitcnt vmcnt before each of them — in the layers WITHOUT a skip that drained the DMA ring and the stores at every row tile)
-      f32x4 rv[G::EPK];
-      if (RES) {
+        pw2_wave_sync();
+        // read back: 16 rows x 4 nj pieces of 16 bytes = 64 nj pieces, consecutive lanes along a row
+        // (RES is a template parameter: with a runtime `if (res)` the compiler made the adds unconditional behind a select and put an
+        // s_waitcnt vmcnt before each of them — in the layers WITHOUT a skip that drained the DMA ring and the stores at every row tile)
 #pragma unroll
-        for (int k = 0; k < G::EPK; ++k)
-          if (lane + 64 * k < 16 * G::EPR) rv[k] = *reinterpret_cast<const f32x4*>(rrow0 + (size_t)(i * 16) * p.ldres + eprow[k] * p.ldres + epcol[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < G::EPK; ++k) {
-        if (lane + 64 * k < 16 * G::EPR) {
-          f32x4 vv = *reinterpret_cast<const f32x4*>(&ep[eprow[k] * G::EPP + epcol[k]]);
-          if (RES) vv += rv[k];
-          if (!(abl & 1)) *reinterpret_cast<f32x4*>(drow0 + (size_t)(i * 16) * p.ldd + eprow[k] * p.ldd + epcol[k]) = vv;
+        for (int k = 0; k < NH; ++k) {
+          if (k >= nj) break;
+          const int q = lane + 64 * k;
+          const int row = q / (4 * nj), col = (q - row * 4 * nj) * 4;
+          f32x4 ov = *reinterpret_cast<const f32x4*>(&ep[row * G::EPP + col]);
+          if (RES) ov += *reinterpret_cast<const f32x4*>(rbase + (unsigned)(((i * 16 + row) * p.ldres + j0 * 16 + col) * 4));
+          if (!(abl & 1)) *reinterpret_cast<f32x4*>(dbase + (unsigned)(((i * 16 + row) * p.ldd + j0 * 16 + col) * 4)) = ov;
         }
       }
     }
+  };
+  for (int g = 0; g < total_stages; g += 2) {
+    step(F0, F1, g);
+    if (g + 1 < total_stages) step(F1, F0, g + 1);
   }
 }
 
@@ -273,15 +289,17 @@ bool pw2_supported(const IgemmParams& p, int mt, int nt, int wn) {
   if (!g_use_pw2 || !pw2_tile(mt, nt, wn)) return false;
   const int bm = 16 * mt * (4 / wn), bn = 16 * nt * wn;
   const int hw = p.Ho * p.Wo;
-  if (p.c0 % 16 || p.c0 < 65 || p.c0 > 1152 || p.c1 != 0) return false;          // >= 3 stages of 32
+  if (p.c0 % 16 || p.c0 < 64 || p.c0 > 1152 || p.c1 != 0) return false;          // whole 16-float stages, more than the ring holds
   if (p.M % bm || p.N % bn || p.Npad % bn || p.N % 4) return false;
   if (p.gate && (hw % bm)) return false;                                          // a tile inside one sample: one gate vector
   if (!p.scale || !p.shift) return false;
   const bool expand = !p.gate && !p.residual && p.act == CCVPE_ACT_SWISH, project = p.gate && p.act == CCVPE_ACT_NONE;
   if (!expand && !project) return false;                                          // the instantiated epilogues (pw2_dispatch)
-  if (PW2_NSTG * (bm + bn) * 32 * 4 + 4 * 16 * (16 * nt + 4) * 4 + 2 * pw2_aux_stride(p.gate != nullptr, p.c0) * 4 > PW2_LDS) return false;
+  if (project && p.residual && mt == 4 && nt == 5) return false;
+  if (PW2_NSTG * (bm + bn) * 16 * 4 + 4 * 16 * (16 * ((nt + 1) / 2) + 4) * 4 + 2 * pw2_aux_stride(p.gate != nullptr, p.c0) * 4 > PW2_LDS) return false;
   if (p.ldd % 4 || (p.residual && p.ldres % 4) || p.ld0 % 4 || p.Kpad % 4) return false;
   if ((double)bm * p.ld0 * 4 >= 4294967296.0 || (double)bn * p.Kpad * 4 >= 4294967296.0) return false;
+  if ((double)bm * p.ldd * 4 >= 2147483648.0 || (double)bm * p.ldres * 4 >= 2147483648.0) return false;
   return true;
 }
 
@@ -304,21 +322,23 @@ static int launch_pw2(const IgemmParams& p0, hipStream_t stream) {
     attr_lds = lds;
   }
   const int cus = num_cus();
-  const int grid = p.tiles_total < cus ? (p.tiles_total + 7) / 8 * 8 : cus / 8 * 8;
+  const int grid = p.tiles_total < 2 * cus ? (p.tiles_total + 7) / 8 * 8 : 2 * cus / 8 * 8;
   hipLaunchKernelGGL((pw2_kernel<MT, NT, WN, ACT, GATED, RES, PW2_NSTG>), dim3(grid), dim3(256), lds, stream, p);
   return check_launch("pw2_kernel");
 }
 
 // the three layer forms of the encoder: expand / head (BN + swish), project (SE gate, BN) without and with the skip
 int pw2_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream) {
-#define CCVPE_PW2(MT_, NT_, WN_)                                                                                  \
+#define CCVPE_PW2(MT_, NT_, WN_, SKIP_)                                                                           \
   if (mt == MT_ && nt == NT_ && wn == WN_) {                                                                      \
     if (!p.gate && !p.residual && p.act == CCVPE_ACT_SWISH) return launch_pw2<MT_, NT_, WN_, CCVPE_ACT_SWISH, false, false>(p, stream); \
-    if (p.gate && p.act == CCVPE_ACT_NONE)                                                                        \
-      return p.residual ? launch_pw2<MT_, NT_, WN_, CCVPE_ACT_NONE, true, true>(p, stream)                        \
-                        : launch_pw2<MT_, NT_, WN_, CCVPE_ACT_NONE, true, false>(p, stream);                      \
+    if (p.gate && p.act == CCVPE_ACT_NONE && !p.residual) return launch_pw2<MT_, NT_, WN_, CCVPE_ACT_NONE, true, false>(p, stream);      \
+    if constexpr (SKIP_) {                                                                                        \
+      if (p.gate && p.act == CCVPE_ACT_NONE) return launch_pw2<MT_, NT_, WN_, CCVPE_ACT_NONE, true, true>(p, stream);                   \
+    }                                                                                                             \
   }
-  CCVPE_PW2(2, 7, 1) CCVPE_PW2(4, 5, 2) CCVPE_PW2(4, 4, 2) CCVPE_PW2(4, 3, 2)
+  // (the 128 x 160 tile with gate AND skip needs more than 256 registers — no EfficientNet-B0 layer has that form: pw2_supported)
+  CCVPE_PW2(2, 7, 1, true) CCVPE_PW2(4, 5, 2, false) CCVPE_PW2(4, 4, 2, true) CCVPE_PW2(4, 3, 2, true)
 #undef CCVPE_PW2
   return fail(CCVPE_EINVAL, "pw2: no kernel for tile <%d,%d,%d> with this epilogue", mt, nt, wn);
 }
