@@ -268,10 +268,10 @@ static int pick_cfg(int npad16) {
 // is a row of kCfgs; the functions return CCVPE_EINVAL for a tile they do not instantiate.
 template <typename T> int pw_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream);        // conv_pw_*.hip
 template <typename T> int conv3x3_dispatch(const IgemmParams& p, int batch, int mt, int nt, int wn, hipStream_t stream);   // conv3x3_*.hip
-// conv_pw2_f32.hip: the fp32 pointwise GEMM with an LDS-DMA ring (one workgroup per CU), for the shapes pw2_supported() accepts
+// conv_pw2_impl.h (conv_pw2_f32.hip / conv_pw2_bf16.hip): the pointwise GEMM with an LDS-DMA ring, for the shapes pw2_supported() accepts
 extern bool g_use_pw2;                                    // ccvpe_set_pw_ring_kernels (conv_igemm.hip)
-bool pw2_supported(const IgemmParams& p, int mt, int nt, int wn);
-int pw2_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream);
+template <typename T> bool pw2_supported(const IgemmParams& p, int mt, int nt, int wn);
+template <typename T> int pw2_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream);
 int num_cus();                                            // narrow_bf16.hip
 // narrow_bf16.hip: bf16 3x3 layers with few channels on large images — weights resident in registers, persistent workgroups
 extern bool g_use_narrow;                                 // ccvpe_set_narrow_kernels (conv_igemm.hip)

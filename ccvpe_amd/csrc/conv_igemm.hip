@@ -442,7 +442,7 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     else if (is_pw && pw_tile) {
       fam = CCVPE_ROUTE_PW_GEMM;
       if (mt == 4 && nt == 5 && wn == 1) { nt = 3; wn = 2; }
-      if (!sk && sizeof(T) == 4 && pw2_supported(p, mt, nt, wn)) fam = CCVPE_ROUTE_PW_RING;
+      if (!sk && pw2_supported<T>(p, mt, nt, wn)) fam = CCVPE_ROUTE_PW_RING;
     }
     *route = fam | (mt << 8) | (nt << 12) | (wn << 16);
     return CCVPE_OK;
@@ -455,9 +455,7 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
     if (is_pw && 16 * c.nt * c.wn > 48) {
       const bool reroute = c.mt == 4 && c.nt == 5 && c.wn == 1;
       const int mt = c.mt, nt = reroute ? 3 : c.nt, wn = reroute ? 2 : c.wn;
-      if constexpr (sizeof(T) == 4) {
-        if (pw2_supported(p, mt, nt, wn)) return pw2_dispatch(p, mt, nt, wn, st);
-      }
+      if (pw2_supported<T>(p, mt, nt, wn)) return pw2_dispatch<T>(p, mt, nt, wn, st);
       return pw_dispatch<T>(p, mt, nt, wn, st);
     }
   }
