@@ -206,7 +206,7 @@ def load():
     if os.environ.get("CCVPE_NARROW") == "0" and hasattr(lib, "ccvpe_set_narrow_kernels"):
         lib.ccvpe_set_narrow_kernels(0)           # A/B runs (tools/gpu/*.sh): the tiled kernels for the narrow decoder levels
     if os.environ.get("CCVPE_PW_RING") == "0" and hasattr(lib, "ccvpe_set_pw_ring_kernels"):
-        lib.ccvpe_set_pw_ring_kernels(0)          # A/B runs: pw_gemm_kernel for every fp32 pointwise layer
+        lib.ccvpe_set_pw_ring_kernels(0)          # A/B runs: pw_gemm_kernel for every pointwise layer
     _lib = lib
     return lib
 

@@ -1,6 +1,7 @@
-// pw2_kernel: the fp32 pointwise (1x1) GEMM of the EfficientNet expand / project / head convolutions with an LDS-DMA ring
-// (efficientnet_pytorch/model.py:62,86,209: _expand_conv + _bn0 + swish, _project_conv + _bn2 (+ skip), _conv_head).  Route
-// CCVPE_ROUTE_PW_RING behind the unchanged ccvpe_conv_igemm_f32; ccvpe_set_pw_ring_kernels(0) brings pw_gemm_kernel back.
+// pw2_kernel: the pointwise (1x1) GEMM of the EfficientNet expand / project / head convolutions with an LDS-DMA ring
+// (efficientnet_pytorch/model.py:62,86,209: _expand_conv + _bn0 + swish, _project_conv + _bn2 (+ skip), _conv_head), fp32 and bf16
+// storage (conv_pw2_f32.hip / conv_pw2_bf16.hip instantiate it).  Route CCVPE_ROUTE_PW_RING behind the unchanged
+// ccvpe_conv_igemm_f32 / _bf16; ccvpe_set_pw_ring_kernels(0) brings pw_gemm_kernel back.  Designed on the fp32 layers:
 //
 // Why (round 5): pw_gemm_kernel (conv_pw_impl.h) stages ONE 32-float K stage ahead through registers into a single LDS buffer and
 // turns every output tile through LDS behind two workgroup barriers.  On the encoder's fp32 layers (M = 16 384 / 65 536 pixels,
@@ -36,8 +37,11 @@
 //   * epilogue per 16-pixel row tile: BN (+ swish) in registers, a wave-private LDS patch (no workgroup barrier: a wave's LDS queue is
 //     in order; the compiler is told with a wavefront-scope fence), 16-byte stores with consecutive lanes along a pixel row;
 //   * same MFMA k-order and the same fp32 operations as pw_gemm_kernel / igemm_kernel: results are BIT-IDENTICAL (tests/test_ops_gpu.py).
+//   * bf16 storage: a stage is 32 channels (ONE 16x16x32 MFMA per fragment pair), a last stage of 16 channels re-reads its lower
+//     pieces on the activation side (finite data against the zero padding of the packed weights), the gate multiplies in fp32 and
+//     rounds back as pw_gemm_kernel's staging does, 16-byte stores of 8 channels.
 // Measured (isolated launches, B = 64, tools/pw_probe.py): 112 -> 672 @32^2 116 us against 138 (85 TF), 672 -> 112 100 / 109, 80 -> 480
-// 63 / 79, 192 -> 1152 @16^2 80 / 88, 320 -> 1280 119 / 140.  Inside the C1 forward, where the two encoders share the chip, the step time
+// 63 / 79, 192 -> 1152 @16^2 80 / 88, 320 -> 1280 119 / 140; bf16: 39.5 / 47.1, 22.1 / 22.6, 26.0 / 32.1, 22.6 / 24.4, 28.2 / 31.7.  Inside the C1 forward, where the two encoders share the chip, the step time
 // does not move measurably (32.68 -> 32.65 ms, tools/gpu/ab_pw_ring.sh): DESIGN.md section 4.
 // Shapes: c0 % 16 == 0, M % BM == 0, N % BN == 0, gated tiles inside one sample, the three epilogue forms of the encoder; everything
 // else stays with pw_gemm_kernel (pw2_supported).

@@ -134,21 +134,28 @@ def test_pw_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd, with_res, act, 
     (672, 112, 32, True, False, "none", 64),       # full size: 512 tiles over 256 workgroups (two tiles each, ring across the tile edge)
     (112, 672, 32, False, False, "swish", 64),     # full size: 3 072 tiles, 12 per workgroup
 ])
-def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_res, act, b):
-    """csrc/conv_pw2_f32.hip (route ASSERTED): the fp32 pointwise GEMM with the LDS-DMA ring against the oracle convolution (small
-    batches) and BIT-IDENTICAL to pw_gemm_kernel, which ccvpe_set_pw_ring_kernels(0) brings back behind the same entry point."""
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_res, act, b, dtype):
+    """csrc/conv_pw2_impl.h (route ASSERTED): the pointwise GEMM with the LDS-DMA ring, fp32 and bf16 storage, against the oracle
+    convolution (small batches) and BIT-IDENTICAL to pw_gemm_kernel, which ccvpe_set_pw_ring_kernels(0) brings back behind the same
+    entry point.  bf16: K = 112 and 80 end in a HALF stage (16 of 32 channels)."""
     from ccvpe_amd.models import _pack_conv
     from ccvpe_amd import _lib
     big = b > 8
+    bf = dtype == "bf16"
+    tdt = torch.bfloat16 if bf else torch.float32
     gen = dict(device="cuda") if big else {}
     x = synth.normal((b, cin, hw, hw), 610 + cin, **gen)
     wt = synth.normal((cout, cin, 1, 1), 620 + cout, (1.0 / cin) ** 0.5)
     sc, sh = synth.uniform((cout,), 629, 0.5, 1.5), synth.normal((cout,), 630, 0.1)
     gate = synth.uniform((b, cin), 631, 0.1, 1.0) if gated else None
     res = synth.normal((b, cout, hw, hw), 632, **gen) if with_res else None
+    if bf:      # the oracle sees the values the kernel reads
+        x, wt = x.bfloat16().float(), wt.bfloat16().float()
+        res = res.bfloat16().float() if with_res else None
     kw = dict(batch=b, in_h=hw, in_w=hw, scale=dev(sc), shift=dev(sh), act=ops.ACT_SWISH if act == "swish" else ops.ACT_NONE,
-              gate=dev(gate) if gated else None, residual=dev(nhwc(res)) if with_res else None)
-    xs, wp = dev(nhwc(x)), dev(_pack_conv(wt))
+              gate=dev(gate) if gated else None, residual=dev(nhwc(res)).to(tdt) if with_res else None)
+    xs, wp = dev(nhwc(x)).to(tdt), dev(_pack_conv(wt, tdt))
     route = ops.conv_igemm(xs, cin, wp, cout, route_only=True, **kw)
     assert route[0] == "pw_ring", route
     got = ops.conv_igemm(xs, cin, wp, cout, **kw)
@@ -159,15 +166,17 @@ def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_re
         old = ops.conv_igemm(xs, cin, wp, cout, **kw)
     finally:
         lib.ccvpe_set_pw_ring_kernels(prev)
-    assert torch.equal(got, old), "pw_ring differs from pw_gemm: max %.3e" % float((got - old).abs().max())
+    assert torch.equal(got, old), "pw_ring differs from pw_gemm: max %.3e" % float((got.float() - old.float()).abs().max())
     if not big:
         xin = x * gate.view(b, cin, 1, 1) if gated else x
+        if bf and gated:
+            xin = xin.bfloat16().float()                 # the gated activations are rounded back to bf16 before the matrix product
         want = F.conv2d(xin, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
         if act == "swish":
             want = O.swish(want)
         if with_res:
             want = want + res
-        close(nchw(got), want, 1e-4, "pw ring %d->%d" % (cin, cout))
+        close(nchw(got).float(), want, 1.2e-2 if bf else 1e-4, "pw ring %d->%d %s" % (cin, cout, dtype))
 
 
 def test_conv_route_matches_dispatch_rules(ops):
