@@ -15,3 +15,9 @@ if [ "$1" = train ]; then
 run "train pw_gemm" "--train --model vigor20 --steps 5 --warmup 3" CCVPE_PW_RING=0
 run "train pw_ring" "--train --model vigor20 --steps 5 --warmup 3" CCVPE_PW_RING=1
 fi
+if [ "$1" = bf16 ] || [ "$2" = bf16 ]; then
+for rep in 1 2; do
+run "bf16 forward pw_gemm" "--precision bf16 --steps 20 --warmup 5" CCVPE_PW_RING=0
+run "bf16 forward pw_ring" "--precision bf16 --steps 20 --warmup 5" CCVPE_PW_RING=1
+done
+fi

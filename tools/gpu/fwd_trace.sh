@@ -12,8 +12,8 @@ import csv, glob, sys
 f = glob.glob('/tmp/fw_tr/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-# the last forward: from the last stem_conv pair onwards
-idx = [i for i, r in enumerate(rows) if 'stem_conv' in r['Kernel_Name']]
+# the last forward: from the last pair of stem launches (stem_dw_kernel since round 5, stem_conv_kernel with CCVPE_FUSE_STEM=0) onwards
+idx = [i for i, r in enumerate(rows) if 'stem_conv' in r['Kernel_Name'] or 'stem_dw' in r['Kernel_Name']]
 start = idx[-2] if len(idx) >= 2 else 0
 with open(sys.argv[1], 'w') as out:
     out.write("n,us,gap_us,grid,wg,lds,vgpr,kernel\n")

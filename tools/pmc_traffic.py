@@ -24,9 +24,10 @@ def family(name):
     if m:
         c0, nt = 8 * int(m.group(1)), int(m.group(3))
         return "up2_kernel<bf16,%d,%d>" % (c0, {3: 40, 2: 32}.get(nt, 16 * nt))
-    m = re.search(r"pw2_kernel<(\d+), *(\d+), *(\d+)", name) or re.search(r"pw2_kernelILi(\d+)ELi(\d+)ELi(\d+)E", name)
-    if m:       # fp32 pointwise ring kernel: bench.py's recorder calls it by its route (ops.conv_route_name)
-        return "pw_ring_f32_kernel<%s,%s,%s>" % m.groups()
+    m = re.search(r"pw2_kernel<(float|__bf16), *(\d+), *(\d+), *(\d+)", name) or re.search(r"pw2_kernelI(f|DF16b)Li(\d+)ELi(\d+)ELi(\d+)E", name)
+    if m:       # pointwise ring kernel: bench.py's recorder calls it by its route (ops.conv_route_name)
+        t, a, b, c = m.groups()
+        return ("pw_ring_f32_kernel<%s,%s,%s>" if t in ("float", "f") else "pw_ring_kernel<bf16,%s,%s,%s>") % (a, b, c)
     m = re.search(r"upconv_dma_kernelIDF16bLi(\d+)ELi(\d+)ELi(\d+)ELb([01])E", name)
     if m:
         return "upconv_dma_kernel<bf16,%s,%s,%s%s>" % (m.group(1), m.group(2), m.group(3), ",pair" if m.group(4) == "1" else "")
