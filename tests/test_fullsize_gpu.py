@@ -90,7 +90,8 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
             # orientation field: F.normalize amplifies the error where the raw 2-vector is small, so the error at ONE pixel is
             # heavy-tailed (tests/test_bf16_gpu.py: over 256 samples p99 3.5e-2 with single samples at 5e-2 ... 1.2e-1, and WHICH
             # sample is an accident of the rounding pattern) — the field is held to 5e-2 on 99 % of its 262 144 pixels and the
-            # arg-max pixel to the absolute bound of that test
+            # arg-max pixel to the absolute bound of that test.  (Measured on the benched C2 batches: p50 2.3e-3, p99 2.9-3.2e-2,
+            # p99.9 9-10e-2, field maximum 0.7-1.6 — a near-zero raw vector flips; at the arg-max pixels 1.8e-3 ... 6.2e-2.)
             oerr = (got[2][j] - ref[2][j]).abs().reshape(2, -1).max(0)[0]
             assert float(torch.quantile(oerr[::7].float(), 0.99)) <= 5e-2, "orientation field: p99 error %.3e" % float(torch.quantile(oerr[::7].float(), 0.99))
             assert float(oerr[ia]) <= 0.2, "orientation vector at the arg-max pixel: error %.3e" % float(oerr[ia])
