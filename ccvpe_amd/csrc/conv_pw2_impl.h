@@ -87,9 +87,10 @@ struct Pw2Geom {
   static_assert((NSTG - 2) * DMIN <= 63, "vmcnt immediate");
 };
 
-// (__launch_bounds__(256, 2) although the LDS admits ONE workgroup per CU: with 512 registers per lane on offer the compiler keeps the
-// loop-carried accumulators in VGPRs, the MFMA destinations in AGPRs and copies all of them both ways around every 16 K — 112
-// v_accvgpr moves + a drained matrix pipe per 56 MFMAs, the kernel at 65 % of its matrix rate with nothing else in the loop)
+// (__launch_bounds__(256, 2) is not only the occupancy this kernel runs at: with 512 registers per lane on offer — (256, 1), tried with
+// the one-workgroup-per-CU ring — the compiler keeps the loop-carried accumulators in VGPRs, the MFMA destinations in AGPRs and copies
+// all of them both ways around every 16 K: 112 v_accvgpr moves + a drained matrix pipe per 56 MFMAs, 65 % of the matrix rate with
+// nothing else in the loop)
 template <typename T, int MT, int NT, int WN, int ACT, bool GATED, bool RES, int NSTG_>
 __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
   using G = Pw2Geom<MT, NT, WN, NSTG_>;
@@ -104,7 +105,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
   constexpr int WM = G::WM, BM = G::BM, BN = G::BN, KS = G::KS, NSTG = G::NSTG;
   constexpr int NA = G::NA, ND = G::ND, DPW = G::DPW, DMIN = G::DMIN;
   extern __shared__ __attribute__((aligned(16))) float pw2_sm[];
-  float* ring = pw2_sm;                                  // [NSTG][BM + BN rows][32 floats, pieces swizzled]
+  float* ring = pw2_sm;                                  // [NSTG][BM + BN rows][16 floats = 64 bytes, pieces swizzled]
   float* aux = pw2_sm + NSTG * G::STAGE_FLOATS;          // [2 tile parities][gate (K up to whole requests) | scale 256 | shift 256]
   float* ep = aux + 2 * pw2_aux_stride(GATED, p.c0) + ((int)threadIdx.x >> 6) * G::EP_FLOATS;   // this wave's epilogue patch
   const int AUX_STRIDE = pw2_aux_stride(GATED, p.c0), SS_OFF = AUX_STRIDE - 2 * PW2_SS;
