@@ -65,6 +65,7 @@ __device__ __forceinline__ void pw2_wave_sync() {
 
 constexpr int PW2_LDS = 80 * 1024;                                    // two workgroups per CU
 constexpr int PW2_NSTG = 3;                                          // ring stages (two in flight while one is consumed)
+constexpr int PW2_RAW = -1;                                          // "activation" of the raw form: no BN vectors, plain store (train mode, 1x1 input gradients)
 constexpr int PW2_SS = 256;                                          // floats reserved per scale / shift vector (BN <= 160)
 // floats of one tile's vectors in LDS: the sample's gate vector (whole 256-float requests) + scale + shift
 static inline __host__ __device__ int pw2_aux_stride(bool gated, int c0) { return (gated ? (c0 + 255) / 256 * 256 : 0) + 2 * PW2_SS; }
@@ -94,6 +95,7 @@ struct Pw2Geom {
 template <typename T, int MT, int NT, int WN, int ACT, bool GATED, bool RES, int NSTG_>
 __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
   using G = Pw2Geom<MT, NT, WN, NSTG_>;
+  constexpr bool RAW = ACT == PW2_RAW;
   constexpr int E = ElemTraits<T>::E;                    // elements per 16 bytes
   constexpr int KE = 4 * E;                              // K elements per stage
   constexpr int ES = (int)sizeof(T);
@@ -178,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
           pw2_dma(ax + (unsigned)(c * 4), (unsigned)(k * 4), gb);
         }
       }
-      if (lane < BN / 4) {
+      if (!RAW && lane < BN / 4) {
         pw2_dma(ax + (unsigned)(SS_OFF * 4), (unsigned)(lane * 16), reinterpret_cast<const char*>(p.scale + ni0));
         pw2_dma(ax + (unsigned)((SS_OFF + PW2_SS) * 4), (unsigned)(lane * 16), reinterpret_cast<const char*>(p.shift + ni0));
       }
@@ -295,9 +297,12 @@ __global__ __launch_bounds__(256, 2) void pw2_kernel(const IgemmParams p) {
 #pragma unroll
         for (int j = 0; j < NH; ++j) {
           if (j >= nj) break;
-          const f32x4 scv = *reinterpret_cast<const f32x4*>(Sl + (j0 + j) * 16);
-          const f32x4 shv = *reinterpret_cast<const f32x4*>(Sl + PW2_SS + (j0 + j) * 16);
-          f32x4 vv = acc[i][j0 + j] * scv + shv;
+          f32x4 vv = acc[i][j0 + j];
+          if (!RAW) {
+            const f32x4 scv = *reinterpret_cast<const f32x4*>(Sl + (j0 + j) * 16);
+            const f32x4 shv = *reinterpret_cast<const f32x4*>(Sl + PW2_SS + (j0 + j) * 16);
+            vv = vv * scv + shv;
+          }
           if (ACT == CCVPE_ACT_SWISH) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) vv[q] = swishf(vv[q]);
@@ -358,9 +363,10 @@ bool pw2_supported(const IgemmParams& p, int mt, int nt, int wn) {
   if (p.c0 % 16 || p.c0 < 64 || p.c0 > 1152 || p.c1 != 0) return false;          // whole 16-byte pieces, more stages than the ring holds
   if (p.M % bm || p.N % bn || p.Npad % bn || p.N % 8 || p.Kpad % (64 / ES)) return false;
   if (p.gate && (hw % bm)) return false;                                          // a tile inside one sample: one gate vector
-  if (!p.scale || !p.shift) return false;
+  const bool raw = !p.scale && !p.shift && p.act == CCVPE_ACT_NONE && !p.residual && ES == 4;      // train mode, 1x1 input gradients (fp32)
+  if (!raw && (!p.scale || !p.shift)) return false;
   const bool expand = !p.gate && !p.residual && p.act == CCVPE_ACT_SWISH, project = p.gate && p.act == CCVPE_ACT_NONE;
-  if (!expand && !project) return false;                                          // the instantiated epilogues (pw2_dispatch)
+  if (!expand && !project && !raw) return false;                                  // the instantiated epilogues (pw2_dispatch)
   if (project && p.residual && mt == 4 && nt == 5) return false;
   if (PW2_NSTG * (bm + bn) * 16 * 4 + 4 * 16 * (16 * ((nt + 1) / 2) + 4) * 4 + 2 * pw2_aux_stride(p.gate != nullptr, p.c0) * 4 > PW2_LDS) return false;
   if ((p.ldd * ES) % 16 || (p.residual && (p.ldres * ES) % 16) || (p.ld0 * ES) % 16) return false;
@@ -393,11 +399,16 @@ static int launch_pw2(const IgemmParams& p0, hipStream_t stream) {
   return check_launch("pw2_kernel");
 }
 
-// the three layer forms of the encoder: expand / head (BN + swish), project (SE gate, BN) without and with the skip
+// the layer forms of the encoder: expand / head (BN + swish), project (SE gate, BN) without and with the skip; fp32 also the RAW
+// forms of train mode (no BN vectors: the batch statistics come first) and of the 1x1 input gradients, plain or gated
 template <typename T>
 int pw2_dispatch(const IgemmParams& p, int mt, int nt, int wn, hipStream_t stream) {
 #define CCVPE_PW2(MT_, NT_, WN_, SKIP_)                                                                           \
   if (mt == MT_ && nt == NT_ && wn == WN_) {                                                                      \
+    if constexpr (sizeof(T) == 4) {                                                                               \
+      if (!p.scale && !p.shift)                                                                                   \
+        return p.gate ? launch_pw2<T, MT_, NT_, WN_, PW2_RAW, true, false>(p, stream) : launch_pw2<T, MT_, NT_, WN_, PW2_RAW, false, false>(p, stream); \
+    }                                                                                                             \
     if (!p.gate && !p.residual && p.act == CCVPE_ACT_SWISH) return launch_pw2<T, MT_, NT_, WN_, CCVPE_ACT_SWISH, false, false>(p, stream); \
     if (p.gate && p.act == CCVPE_ACT_NONE && !p.residual) return launch_pw2<T, MT_, NT_, WN_, CCVPE_ACT_NONE, true, false>(p, stream);      \
     if constexpr (SKIP_) {                                                                                        \

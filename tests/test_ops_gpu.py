@@ -133,6 +133,9 @@ def test_pw_gemm_ragged_n_k_tail_many_tiles(ops, cin, cout, ldd, with_res, act, 
     (320, 1280, 16, False, False, "swish", 1),     # the head conv
     (672, 112, 32, True, False, "none", 64),       # full size: 512 tiles over 256 workgroups (two tiles each, ring across the tile edge)
     (112, 672, 32, False, False, "swish", 64),     # full size: 3 072 tiles, 12 per workgroup
+    (112, 672, 32, False, False, "raw", 2),        # train mode / 1x1 input gradients: no BN vectors, plain store (fp32 only)
+    (672, 112, 32, True, False, "raw", 2),         # train-mode project conv: SE gate, raw output
+    (1152, 192, 16, False, False, "raw", 3),       # input gradient of a 192 -> 1152 expand conv
 ])
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_res, act, b, dtype):
@@ -143,6 +146,9 @@ def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_re
     from ccvpe_amd import _lib
     big = b > 8
     bf = dtype == "bf16"
+    raw = act == "raw"
+    if raw and bf:
+        pytest.skip("the raw forms are instantiated for fp32 (train mode runs in fp32)")
     tdt = torch.bfloat16 if bf else torch.float32
     gen = dict(device="cuda") if big else {}
     x = synth.normal((b, cin, hw, hw), 610 + cin, **gen)
@@ -153,7 +159,8 @@ def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_re
     if bf:      # the oracle sees the values the kernel reads
         x, wt = x.bfloat16().float(), wt.bfloat16().float()
         res = res.bfloat16().float() if with_res else None
-    kw = dict(batch=b, in_h=hw, in_w=hw, scale=dev(sc), shift=dev(sh), act=ops.ACT_SWISH if act == "swish" else ops.ACT_NONE,
+    kw = dict(batch=b, in_h=hw, in_w=hw, scale=None if raw else dev(sc), shift=None if raw else dev(sh),
+              act=ops.ACT_SWISH if act == "swish" else ops.ACT_NONE,
               gate=dev(gate) if gated else None, residual=dev(nhwc(res)).to(tdt) if with_res else None)
     xs, wp = dev(nhwc(x)).to(tdt), dev(_pack_conv(wt, tdt))
     route = ops.conv_igemm(xs, cin, wp, cout, route_only=True, **kw)
@@ -171,7 +178,9 @@ def test_pw_ring_kernel_vs_oracle_and_pw_gemm(ops, cin, cout, hw, gated, with_re
         xin = x * gate.view(b, cin, 1, 1) if gated else x
         if bf and gated:
             xin = xin.bfloat16().float()                 # the gated activations are rounded back to bf16 before the matrix product
-        want = F.conv2d(xin, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+        want = F.conv2d(xin, wt)
+        if not raw:
+            want = want * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
         if act == "swish":
             want = O.swish(want)
         if with_res:
