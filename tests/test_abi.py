@@ -184,3 +184,38 @@ def test_planning_entry_points_without_a_gpu():
     assert lib.ccvpe_dwconv_wgrad_nblk(64, 64, 3, 1) == 64 and lib.ccvpe_dwconv_wgrad_nblk(256, 256, 3, 2) == 64
     assert lib.ccvpe_conv_wgrad_scratch_floats(2, 16, 16, 3, 3, 1, 1, 1344, 640) > 0
     assert lib.ccvpe_adam_chunk_elems() == 4096 and lib.ccvpe_train_targets_nblk(512, 512) == 256
+
+
+def test_round5_queries_without_a_gpu():
+    """Host-only: the fused-stem planner and the pointwise-ring route (csrc/stem_dw.hip, csrc/conv_pw2_impl.h: pw2_supported)."""
+    import ctypes
+    lib = _lib.load()
+    assert lib.ccvpe_stem_dw_nblk(512, 512, 0) == 32 * 8                     # aerial: 256 x 256 outputs in 8 x 32 tiles
+    assert lib.ccvpe_stem_dw_nblk(320, 640, 1) == 20 * 10                    # ground, circular padding
+    assert lib.ccvpe_stem_dw_nblk(154, 231, 0) == 10 * 4                     # Oxford: 77 x 115 outputs, ragged tiles
+    assert lib.ccvpe_stem_dw_nblk(154, 231, 1) == 0                          # circular padding needs an even width: two launches
+    assert lib.ccvpe_stem_dw_nblk(2, 2, 0) == 0
+    d = _lib.ConvDesc()
+    d.src0 = d.w = d.dst = d.scale = d.shift = 256
+    d.c0, d.ld0, d.batch, d.in_h, d.in_w = 112, 112, 2, 32, 32
+    d.kh = d.kw = 1
+    d.stride, d.pad, d.n, d.kpad, d.ldd, d.act = 1, 0, 672, 112, 672, 2     # expand conv of blocks 9-11: BN + swish
+    fam = lambda r: r & 0xff
+    for bf16 in (0, 1):
+        d.kpad = 128 if bf16 else 112                                        # packed K: whole 64-byte pieces of the element type
+        assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), bf16, 0)) == 4, "pw_ring expected"
+    d.kpad = 112
+    prev = lib.ccvpe_set_pw_ring_kernels(0)
+    try:
+        assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 1  # the switch brings pw_gemm_kernel back
+    finally:
+        lib.ccvpe_set_pw_ring_kernels(prev)
+    d.batch, d.in_h, d.in_w = 3, 19, 23                                      # M = 1311: not a multiple of the 128-row tile
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 1
+    d.batch, d.in_h, d.in_w, d.gate = 64, 20, 40, 256                        # ground encoder: a gated tile would span two samples
+    d.c0, d.ld0, d.kpad, d.n, d.ldd, d.act = 672, 672, 672, 112, 112, 0
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 1
+    d.in_h, d.in_w = 32, 32                                                  # aerial: 1 024 pixels per sample = 8 tiles
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 4
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 1, 0)) == 4
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 1, 1)) == 1      # bf16 storage writing fp32: pw_gemm_kernel
