@@ -15,8 +15,8 @@
 // HBM-bound: bytes/pixel = esz*C read + esz*ldo write + 4*n_shifts scores; the arithmetic
 // (n_shifts*C FMAs per pixel) is <1% of the forward's FLOPs, so it stays on the VALU.
 //
-// Mapping: 256 threads; LPP lanes share one pixel (LPP = 1 for C <= 48 ... 32 for C = 1280), so a workgroup owns
-// TP = 256/LPP pixels and the tile is ~45 KB whatever the level (2-3 workgroups per CU, ~11 16-byte loads in flight per
+// Mapping: 256 threads; LPP lanes share one pixel (LPP = 1 for C <= 24, 2 for C = 40 ... 32 for C >= 400), so a workgroup owns
+// TP = 256/LPP pixels and the tile is ~22 KB whatever the level (4+ workgroups per CU, ~6 16-byte loads in flight per
 // thread).  The tile is stored pixel-major with a row pitch S chosen so that S/4 = LPP * odd: the ds_read_b128 of a lane
 // group (16 lanes = 16/LPP pixels x LPP consecutive 16-byte pieces) then covers all 64 banks exactly once.  Lane `sub` of
 // a pixel walks the 4-channel groups sub, sub + LPP, ...; the ground descriptor is shared by every pixel of a sample, so it
@@ -36,7 +36,16 @@ struct MatchOffsets {
 };
 
 // lanes per pixel and tile row pitch (floats) for C channels
-static inline int match_lpp(int C) { int l = 1; while (l < 32 && C > 48 * l) l *= 2; return l; }
+// Channels per lane before a pixel gets another lane.  24 since round 5 (48 before: one lane per pixel at C = 40, 256 pixels and
+// 70 KB of LDS per workgroup, two workgroups per CU): with 20 / 21 rotation hypotheses the three phases of a workgroup (tile in,
+// 20 x C FMAs per pixel, rows out) are each a few microseconds and two workgroups do not cover them — halving the tile doubles the
+// workgroups per CU: C2 (N_rot = 20, B = 32) 5.47 -> 5.36 ms, the one-hypothesis configurations unchanged (tools/gpu/ab_match_lpp.sh).
+#ifdef CCVPE_ABLATE   // diagnostics build: CCVPE_MATCH_LPP_DIV overrides it
+static inline int match_lpp_div() { static const int d = getenv("CCVPE_MATCH_LPP_DIV") ? atoi(getenv("CCVPE_MATCH_LPP_DIV")) : 24; return d; }
+#else
+static inline int match_lpp_div() { return 24; }
+#endif
+static inline int match_lpp(int C) { int l = 1; while (l < 32 && C > match_lpp_div() * l) l *= 2; return l; }
 static inline int match_pitch(int C, int lpp) {
   if (lpp >= 16) return C + 4;                    // a lane group reads 256 contiguous bytes of ONE pixel: any pitch works
   int s = C + 4;                                  // (C % 8 == 0)  ->  s/4 = lpp * odd
