@@ -27,3 +27,25 @@ def synth_sd():
             _SD_CACHE[key] = synth.synthetic_state_dict(kind, seed)
         return _SD_CACHE[key]
     return get
+
+
+_ORACLE_CACHE = {}
+
+
+@pytest.fixture(scope="session")
+def oracle_forward(synth_sd):
+    """(case dict, batch, input seed) -> (grd, sat, oracle outputs) on the CPU, cached for the session: the fp32 and the bf16
+    forward tests compare against the SAME oracle run on the same seeded inputs (30-40 s of CPU each on a GPU box)."""
+    import torch
+    from ccvpe_amd import synth
+    from oracle import ccvpe_oracle as O
+
+    def get(case, batch, seed):
+        key = (case["kind"], case["ori_noise"], case["circular"], case["wseed"], case["grd"], batch, seed)
+        if key not in _ORACLE_CACHE:
+            grd, sat = synth.synthetic_pair(batch, case["grd"], seed)
+            with torch.no_grad():
+                ref = O.forward(synth_sd(case["kind"], case["wseed"]), grd, sat, case["kind"], case["circular"], case["ori_noise"])
+            _ORACLE_CACHE[key] = (grd, sat, [t.detach() for t in ref])
+        return _ORACLE_CACHE[key]
+    return get

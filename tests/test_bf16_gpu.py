@@ -264,14 +264,12 @@ def test_stem_and_head_bf16(ops):
     dict(kind="vigor", ori_noise=180, circular=False, wseed=0, grd="vigor_fov180"),          # C4: FoV 180
     dict(kind="kitti", ori_noise=None, circular=False, wseed=1, grd="kitti"),
 ])
-def test_forward_bf16_vs_oracle(case, synth_sd):
+def test_forward_bf16_vs_oracle(case, synth_sd, oracle_forward):
     from test_forward_gpu import build
     net = build(case, synth_sd).set_precision("bf16")
-    grd, sat = synth.synthetic_pair(2, case["grd"], 991)
+    grd, sat, ref = oracle_forward(case, 2, 991)       # (the fp32 test of the same case uses the same inputs and oracle run)
     out = net(grd.cuda(), sat.cuda())
     torch.cuda.synchronize()
-    with torch.no_grad():
-        ref = O.forward(synth_sd(case["kind"], case["wseed"]), grd, sat, case["kind"], case["circular"], case["ori_noise"])
     assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
     assert all(t.dtype == torch.float32 for t in out)
     lg, rl = out[0].cpu(), ref[0]

@@ -63,15 +63,12 @@ def test_forward_vs_reference_golden(name, synth_sd):
     dict(kind="kitti", ori_noise=None, circular=False, wseed=1, grd="kitti"),
     dict(kind="oxford", ori_noise=None, circular=False, wseed=2, grd="oxford"),
 ])
-def test_forward_vs_oracle_batch2(case, synth_sd):
+def test_forward_vs_oracle_batch2(case, synth_sd, oracle_forward):
     """B=2 on fresh inputs: every output tensor in full against the oracle."""
     net = build(case, synth_sd)
-    grd, sat = synth.synthetic_pair(2, case["grd"], 991)
+    grd, sat, ref = oracle_forward(case, 2, 991)       # (shared with tests/test_bf16_gpu.py: one oracle run per case and session)
     out = net(grd.cuda(), sat.cuda())
     torch.cuda.synchronize()
-    with torch.no_grad():
-        ref = O.forward(synth_sd(case["kind"], case["wseed"]), grd, sat, case["kind"], case["circular"],
-                        case["ori_noise"])
     assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
     assert rel_err(out[0], ref[0]) < LOGIT_RTOL
     assert torch.equal(out[0].argmax(1).cpu(), ref[0].argmax(1)), "arg-max pixel differs"
