@@ -86,3 +86,24 @@ def test_paired_level6_halo_is_conflict_free_with_a_gap_of_eight_slots():
     for c in range(3):
         assert cyc(8, c) == (4, 4)
         assert cyc(2, c) == (8, 4)
+
+
+def test_round5_layouts_in_the_source_are_conflict_free():
+    """Round 5: the ring GEMM's 64-byte panel rows (csrc/conv_pw2_impl.h: piece ^ (-(row >> 2) & 3), the LDS side written lane-linearly by
+    the DMA) and the fused stem's tile (csrc/stem_dw.hip: 36 floats per pixel, 40 pixels per row; lane = channel group + 8 x row)."""
+    src = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "conv_pw2_impl.h")).read()
+    assert "const int fcol = ((lane >> 4) ^ ((0 - (frow >> 2)) & 3)) * 4;" in src, "the ring GEMM's fragment swizzle changed: update this test"
+    swz = lambda row: (0 - (row >> 2)) & 3
+    for base in range(0, 256, 16):                                  # fragment rows (wm MT + i) 16 + lane % 16: tile bases are multiples of 16
+        assert L.cycles("read_b128", L.fragment_b128(16, base=base, swizzle=swz)) == (4, 4)
+    assert L.cycles("read_b128", L.fragment_b128(16)) == (8, 4)     # (the same rows without the swizzle: 2-way conflicts)
+    src = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "stem_dw.hip")).read()
+    assert "constexpr int SD_PP = 36;" in src and "constexpr int SD_RP = 40;" in src, "the fused stem's tile pitches changed: update this test"
+    PP, RP = 36, 40
+    for col in range(0, 40, 3):                                     # depthwise window reads: lane = cg + 8 orow, any window column
+        rd = lambda lane, col=col: ((lane >> 3) * RP + col) * PP + (lane & 7) * 4
+        assert L.cycles("read_b128", rd) == (4, 4)
+    for first in (0, 5, 16, 34):                                    # stem epilogue: 16 consecutive halo pixels x 4 channel quads per store
+        wr = lambda lane, first=first: (first + (lane & 15)) * PP + 4 * (lane >> 4)
+        assert L.cycles("write_b128", wr) == (8, 8)
+    assert L.cycles("write_b128", lambda lane: (lane & 15) * 32 + 4 * (lane >> 4)) == (64, 8)   # (pitch 32: every group on one bank set)
