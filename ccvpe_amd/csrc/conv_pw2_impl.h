@@ -360,7 +360,10 @@ bool pw2_supported(const IgemmParams& p, int mt, int nt, int wn) {
   if (ES == 2 && p.out_f32) return false;                                        // bf16 storage writing fp32: pw_gemm_kernel
   const int bm = 16 * mt * (4 / wn), bn = 16 * nt * wn;
   const int hw = p.Ho * p.Wo;
-  if (p.c0 % 16 || p.c0 < 64 || p.c0 > 1152 || p.c1 != 0) return false;          // whole 16-byte pieces, more stages than the ring holds
+  if (p.c0 % 16 || p.c0 < 64 || p.c0 > 1152 || p.c1 != 0) return false;          // whole 16-byte pieces; the gate vector's LDS copy
+  // at least three K stages per tile: the requests run three stages ahead of the MFMAs, and the per-tile vectors (two LDS copies, by
+  // tile parity) of tile t + 2 must not be requested before every wave is past the epilogue of tile t
+  if ((p.c0 + 64 / ES - 1) / (64 / ES) < 3) return false;
   if (p.M % bm || p.N % bn || p.Npad % bn || p.N % 8 || p.Kpad % (64 / ES)) return false;
   if (p.gate && (hw % bm)) return false;                                          // a tile inside one sample: one gate vector
   const bool raw = !p.scale && !p.shift && p.act == CCVPE_ACT_NONE && !p.residual && ES == 4;      // train mode, 1x1 input gradients (fp32)
