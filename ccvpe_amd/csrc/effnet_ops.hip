@@ -2,6 +2,7 @@
 // All HBM-bound (AI < 10 F/B): the design rules are coalesced 16-byte NHWC
 // accesses, one pass over the tensor, and every elementwise op fused into the producing kernel.
 #include "common.h"
+#include "mbconv_plane.h"
 
 namespace ccvpe {
 
@@ -556,7 +557,10 @@ extern "C" int ccvpe_dwconv_nblk(int H, int W, int C, int stride) {
   // nblk does not depend on k for the SAME schedule (Ho = ceil-like of H/stride for both k)
   int cgx, P, yc, nblk, Ho, Wo, RB;
   if (C <= 0 || C % 4) return CCVPE_EINVAL;
-  if (dw_use_plane(H, W, C)) return 1;
+  if (dw_use_plane(H, W, C)) {
+    const int nb = (g_mbplane_mode & 2) ? mbplane_nblk(H, W, 0, C, 5, stride) : 0;   // row bands of csrc/mbconv_plane.hip
+    return nb > 0 ? nb : 1;
+  }
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, 3, &RB);
   return nblk;
 }
@@ -572,6 +576,9 @@ static int dwconv_any(const T* x, const float* w, const float* scale, const floa
   int cgx, P, yc, nblk, Ho, Wo, RB;
   dw_geometry(H, W, C, stride, &cgx, &P, &yc, &nblk, &Ho, &Wo, k, &RB);
   if (circular && (k / 2 + 1 > W)) return fail(CCVPE_EINVAL, "dwconv: W too small for circular wrap");
+  if (!RAW && dw_use_plane(H, W, C) && (g_mbplane_mode & 2) && mbplane_nblk(H, W, 0, C, k, stride) > 0)
+    return mbplane_launch(sizeof(T) == 2, 0, x, nullptr, 0, nullptr, nullptr, w, scale, shift, y, se_partial, B, H, W, 0, C, k,
+                          stride, circular, stream);
   if (dw_use_plane(H, W, C)) {
     constexpr int CH = DwpGeom<T>::CH;
     const size_t psm = ((size_t)H * W * 8 + (size_t)k * k * CH + 1024) * sizeof(float);

@@ -383,7 +383,7 @@ using namespace ccvpe;
 thread_local char ccvpe::g_err[512] = "";
 
 extern "C" const char* ccvpe_last_error(void) { return g_err; }
-extern "C" int ccvpe_abi_version(void) { return 6; }
+extern "C" int ccvpe_abi_version(void) { return 7; }
 
 extern "C" int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
                                            float* out, int B, int h, int w, void* stream) {

@@ -24,6 +24,7 @@
 // Halo recompute: ((TOH-1)*S+K)*(15*S+K) / (TOH*S*16*S) = 1.10 (k3 s2) ... 1.56 (k5 s1) of the expand work, which is the
 // cheap part (MFMA).
 #include "common.h"
+#include "mbconv_plane.h"
 #include <type_traits>
 
 namespace ccvpe {
@@ -265,7 +266,8 @@ using namespace ccvpe;
 // number of squeeze-partial rows per sample = spatial tiles per sample (0 => use the unfused kernels)
 extern "C" int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int k, int stride) {
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return CCVPE_EINVAL;
-  if (!mbf_supported(in_w, cin, mid, k, 16, stride)) return 0;
+  if (!mbf_supported(in_w, cin, mid, k, 16, stride))      // late blocks (small planes, wide inputs): csrc/mbconv_plane.hip
+    return (g_mbplane_mode & 1) ? mbplane_nblk(in_h, in_w, cin, mid, k, stride) : 0;
   const int total_pad = (stride == 1) ? (k - 1) : (k - 2);
   const int Ho = (in_h + total_pad - k) / stride + 1, Wo = (in_w + total_pad - k) / stride + 1;
   const int toh = mbf_toh(k, stride, cin);
@@ -278,6 +280,9 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
                             int H, int W, int cin, int mid, int k, int stride, int circular, void* stream) {
   constexpr int SK = 4 * (16 / (int)sizeof(TE));
   if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return fail(CCVPE_EINVAL, "mbconv_front: k/stride unsupported");
+  if (!mbf_supported(W, cin, mid, k, 16, stride) && (g_mbplane_mode & 1) && mbplane_nblk(H, W, cin, mid, k, stride) > 0)
+    return mbplane_launch(sizeof(TE) == 2, 1, x, w_exp, kpad, s0, b0, w_dw, s1, b1, y, se_partial, B, H, W, cin, mid, k, stride,
+                          circular, stream);
   if (!mbf_supported(W, cin, mid, k, SK, stride)) return fail(CCVPE_EINVAL, "mbconv_front: shape not supported (W=%d cin=%d mid=%d)", W, cin, mid);
   if (kpad % SK || kpad < cin) return fail(CCVPE_EINVAL, "mbconv_front: bad kpad");
   if (!aligned16(x) || !aligned16(w_exp) || !aligned16(s0) || !aligned16(b0) || !aligned16(s1) || !aligned16(b1) ||
@@ -310,9 +315,11 @@ static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const fl
   int rc = CCVPE_OK;
   auto go = [&](auto kern, int lds_floats) {
     const int lds = lds_floats * 4;
-    if (lds > 48 * 1024) {
+    static bool attr_set = false;                    // per instantiation (generic lambda)
+    if (lds > 48 * 1024 && !attr_set) {
       hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
       if (e != hipSuccess) { rc = fail(CCVPE_ELAUNCH, "mbconv_front: set smem attr: %s", hipGetErrorString(e)); return; }
+      attr_set = true;
     }
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(256), lds, st, p);
   };

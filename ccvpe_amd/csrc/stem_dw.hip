@@ -318,8 +318,12 @@ static int stem_dw_any(const float* x, const float* w, const float* s0, const fl
   if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "stem_dw: grid too large");
   constexpr int lds = SD_LDS_FLOATS * 4;
   static_assert(lds <= 80 * 1024, "two workgroups per CU");
-  hipError_t e = hipFuncSetAttribute((const void*)stem_dw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-  if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "stem_dw: set smem attr: %s", hipGetErrorString(e));
+  static bool attr_set = false;                       // per instantiation: a driver call, not one per launch
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)stem_dw_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "stem_dw: set smem attr: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
   if ((double)3 * H * W * 4 >= 2147483648.0) return fail(CCVPE_EINVAL, "stem_dw: image of one sample larger than 2 GB");
   // persistent: two workgroups per CU (LDS), a multiple of the 8 XCDs, never more than the tiles of the smallest XCD share
   static int cus = 0;

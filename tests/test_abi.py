@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), "libccvpe_hip.so does not export %s" % n
     assert sorted(_lib.PROTOTYPES) == names, "ctypes table and header disagree"
-    assert lib.ccvpe_abi_version() == 6
+    assert lib.ccvpe_abi_version() == 7
 
 
 def test_ctypes_prototypes_match_header_signatures():
@@ -146,7 +146,10 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert lib.ccvpe_head_conv3x3_f32(256, 256, 256, 256, 1, 8, 8, 3, 0, None) == EINVAL               # cout = 3
     assert lib.ccvpe_softmax_rows_f32(256, 256, 0, 8, None) == EINVAL
     assert lib.ccvpe_mbconv_front_nblk(8, 8, 16, 96, 4, 1) == EINVAL
-    assert lib.ccvpe_mbconv_front_nblk(16, 16, 192, 1152, 3, 1) == 0        # valid but unfused shape
+    assert lib.ccvpe_mbconv_front_nblk(16, 16, 192, 1152, 3, 1) == 1        # late block: csrc/mbconv_plane.hip, the plane is one band
+    assert lib.ccvpe_mbconv_front_nblk(32, 32, 112, 672, 5, 1) == 2         # 32 x 32 plane: two bands of 16 rows
+    assert lib.ccvpe_mbconv_front_nblk(16, 16, 96, 576, 3, 1) == 0          # valid but unfused shape (Cin not instantiated)
+    assert lib.ccvpe_dwconv_nblk(32, 32, 672, 1) == 2 and lib.ccvpe_dwconv_nblk(7, 9, 480, 1) == 1
     assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 1) == 32         # squeeze-partial rows = 8 x 16 output tiles: 8 x 4
     assert lib.ccvpe_mbconv_front_nblk(256, 256, 16, 96, 3, 2) == 128       # block 1: 128 x 128 outputs in 8 x 16 tiles
     assert lib.ccvpe_mbconv_front_nblk(64, 64, 40, 240, 5, 2) == 0          # k5 s2 with Cin > 32: not instantiated -> unfused

@@ -75,6 +75,35 @@ def test_igemm_bf16_1x1(ops, cin, cout):
     close(nchw(got32), want, 2e-3, "bf16 1x1 fp32-out")
 
 
+@pytest.mark.parametrize("k,s,cin,h,w,circ", [(3, 1, 80, 32, 32, False), (5, 1, 112, 32, 32, False), (5, 2, 112, 32, 32, False),
+                                              (5, 1, 192, 16, 16, False), (5, 1, 112, 20, 40, True), (5, 2, 112, 20, 40, True),
+                                              (3, 1, 192, 10, 20, True), (5, 1, 80, 7, 12, True)])
+def test_mbconv_plane_late_blocks_bf16(ops, k, s, cin, h, w, circ):
+    """bf16 storage of x / w_exp / y; the expanded plane and the depthwise arithmetic stay fp32 in LDS (better than the
+    round-5 chain, which rounded the expanded tensor to bf16 on its way through HBM)."""
+    b, mid = 3, 6 * cin
+    x = r(synth.normal((b, cin, h, w), 700 + cin + h))
+    w_exp = r(synth.normal((mid, cin, 1, 1), 701, (2.0 / cin) ** 0.5))
+    s0, b0 = synth.uniform((mid,), 702, 0.5, 1.5), synth.normal((mid,), 703, 0.2)
+    w_dw = synth.normal((mid, 1, k, k), 704, 1.0 / k)
+    s1, b1 = synth.uniform((mid,), 705, 0.5, 1.5), synth.normal((mid,), 706, 0.2)
+    t = O.swish(F.conv2d(x, w_exp) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    want = O.swish(O.same_conv(t, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    f32 = torch.float32
+    assert ops.mbconv_front_supported(h, w, cin, mid, k, s) > 0
+    wd = dev(w_dw.reshape(mid, k, k).permute(1, 2, 0), f32)
+    got, part = ops.mbconv_front(dev(nhwc(x)), dev(pack(w_exp)), dev(s0, f32), dev(b0, f32), wd, dev(s1, f32), dev(b1, f32),
+                                 mid, k, s, circ)
+    assert got.dtype == BF
+    close(nchw(got), want, 1e-2, "bf16 plane front k%d s%d" % (k, s))
+    close(part.sum(1), want.sum(dim=(2, 3)), 2e-3, "squeeze partials (fp32 sums of unrounded outputs)")
+    tr = r(t)
+    want2 = O.swish(O.same_conv(tr, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    got2, part2 = ops.dwconv(dev(nhwc(tr)), wd, dev(s1, f32), dev(b1, f32), k, s, circ)
+    close(nchw(got2), want2, 1e-2, "bf16 plane depthwise k%d s%d" % (k, s))
+    close(part2.sum(1), want2.sum(dim=(2, 3)), 2e-3, "squeeze partials (depthwise form)")
+
+
 def test_igemm_bf16_gate_residual(ops):
     b, h, w, cin, cout = 3, 7, 10, 96, 24
     x = r(synth.normal((b, cin, h, w), 1))

@@ -583,6 +583,54 @@ def test_mbconv_front_fused(ops, k, s, cin, h, w, circ):
     close(part.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials")
 
 
+PLANE_SHAPES = [(3, 1, 80, 32, 32, False), (5, 1, 80, 32, 32, False), (5, 1, 112, 32, 32, False), (5, 2, 112, 32, 32, False),
+                (5, 1, 192, 16, 16, False), (3, 1, 192, 16, 16, False), (3, 1, 80, 20, 40, True), (5, 1, 112, 20, 40, True),
+                (5, 2, 112, 20, 40, True), (5, 1, 192, 10, 20, True), (3, 1, 192, 10, 20, True), (5, 1, 80, 7, 12, True),
+                (5, 2, 112, 18, 16, False), (3, 1, 112, 5, 8, False)]
+
+
+def _plane_case(k, s, cin, h, w, circ, b=3, rnd=lambda t: t):
+    mid = 6 * cin
+    x = rnd(synth.normal((b, cin, h, w), 700 + cin + h))
+    w_exp = rnd(synth.normal((mid, cin, 1, 1), 701, (2.0 / cin) ** 0.5))
+    s0, b0 = synth.uniform((mid,), 702, 0.5, 1.5), synth.normal((mid,), 703, 0.2)
+    w_dw = synth.normal((mid, 1, k, k), 704, 1.0 / k)
+    s1, b1 = synth.uniform((mid,), 705, 0.5, 1.5), synth.normal((mid,), 706, 0.2)
+    t = O.swish(F.conv2d(x, w_exp) * s0.view(1, -1, 1, 1) + b0.view(1, -1, 1, 1))
+    want = O.swish(O.same_conv(t, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
+    return x, w_exp, s0, b0, w_dw, s1, b1, t, want
+
+
+@pytest.mark.parametrize("k,s,cin,h,w,circ", PLANE_SHAPES)
+def test_mbconv_plane_late_blocks(ops, k, s, cin, h, w, circ):
+    """The late-block front (csrc/mbconv_plane.hip: channel slices x whole-row bands, expanded plane in LDS) behind
+    ccvpe_mbconv_front_*, against the unfused oracle (efficientnet_pytorch/model.py:102-110,114); its depthwise-only
+    form behind ccvpe_dwconv_* on the same case; and the round-5 chain (switch off) as a third opinion."""
+    from ccvpe_amd.models import _pack_conv
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    mid = 6 * cin
+    x, w_exp, s0, b0, w_dw, s1, b1, t, want = _plane_case(k, s, cin, h, w, circ)
+    nblk = ops.mbconv_front_supported(h, w, cin, mid, k, s)
+    assert nblk > 0, "the plane kernel should take this shape"
+    wd = dev(w_dw.reshape(mid, k, k).permute(1, 2, 0))
+    got, part = ops.mbconv_front(dev(nhwc(x)), dev(_pack_conv(w_exp)), dev(s0), dev(b0), wd, dev(s1), dev(b1), mid, k, s, circ)
+    assert part.shape[1] == nblk
+    close(nchw(got), want, 1e-4, "plane front k%d s%d" % (k, s))
+    close(part.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials")
+    got2, part2 = ops.dwconv(dev(nhwc(t)), wd, dev(s1), dev(b1), k, s, circ)
+    close(nchw(got2), want, 1e-4, "plane depthwise k%d s%d" % (k, s))
+    close(part2.sum(1), want.sum(dim=(2, 3)), 1e-4, "squeeze partials (depthwise form)")
+    prev = lib.ccvpe_set_mbconv_plane_kernels(0)
+    try:
+        assert ops.mbconv_front_supported(h, w, cin, mid, k, s) == 0
+        got3, part3 = ops.dwconv(dev(nhwc(t)), wd, dev(s1), dev(b1), k, s, circ)
+    finally:
+        lib.ccvpe_set_mbconv_plane_kernels(prev)
+    assert part3.shape[1] == 1
+    close(got2, got3, 2e-6, "plane depthwise vs dwconv_plane_kernel")
+
+
 @pytest.mark.parametrize("circ", [True, False])
 def test_mbconv_blocks_golden_fused_front(ops, circ, synth_sd):
     """Blocks 1-5 through the fused front kernel against the reference-module goldens."""
