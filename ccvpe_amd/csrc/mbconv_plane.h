@@ -14,6 +14,6 @@ int mbplane_launch(int is_bf16, int expand, const void* x, const void* w_exp, in
                    int cin, int mid, int k, int stride, int circular, void* stream);
 
 // A/B switch (ccvpe_set_mbconv_plane_kernels): 0 = the round-5 chain (pointwise GEMM + dwconv_plane_kernel)
-extern int g_mbplane_mode;   // bit 0: fused expand + depthwise, bit 1: depthwise-only form
+extern int g_mbplane_mode;   // bit 0: fused expand + depthwise, bit 1: depthwise-only form, bit 2: band-owner kernel (bf16, fused)
 
 }  // namespace ccvpe

@@ -33,7 +33,9 @@
 
 namespace ccvpe {
 
-int g_mbplane_mode = 3;
+int num_cus();   // narrow_bf16.hip
+
+int g_mbplane_mode = 7;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -289,6 +291,277 @@ __global__ __launch_bounds__(256, 2) void mbconv_plane_kernel(const MbPlaneParam
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Band-owner form (bf16 storage, fused expand + depthwise): what the ablation of the kernel above showed (tools/gpu/
+// ablate_mbplane.sh, block 9 of the aerial encoder, 102.8 us): with EVERYTHING removed 30.7 us remain (5 376 workgroups, each
+// starting with a dependent weight load in front of its first barrier: 1.4 us of latency per workgroup generation), the expand
+// phase costs 37 us although its swish costs nothing (ten x tiles per wave fetched from L2 one tile ahead: latency), the window
+// reads 18, the FMAs 9, the stores 8.  So:
+//   * a workgroup (512 threads) owns (sample, band, a RANGE of channel slices) and loops over the slices: launch, zero fill and
+//     the x fetch are paid once;
+//   * waves 0-3 are PRODUCERS: they keep the band's x fragments in REGISTERS for the whole kernel (x is the same for every
+//     slice: up to 10 tiles x 4 pieces = 160 VGPRs) and per slice run MFMA + BN0 + swish -> ds_write into plane[slice & 1];
+//     waves 4-7 are CONSUMERS: they run the depthwise phase of the PREVIOUS slice from plane[(slice - 1) & 1].  One barrier per
+//     slice; a SIMD always holds one wave of each kind, so the producers' matrix / LDS-write phases and the consumers' window
+//     reads + FMAs overlap by construction instead of by luck;
+//   * no global load sits in front of anything: the consumers (who have registers to spare) fetch the NEXT slice's expand
+//     weights, BN vectors and depthwise weights during their depthwise phase and park them in LDS (expand weights / BN0 double
+//     buffered, depthwise weights / BN1 triple buffered: a consumer wave may still read slice s - 1's while another stores
+//     slice s + 1's);
+//   * circular padding: a producer lane whose pixel sits within the wrap distance of a border stores it twice.
+// CH = 16 for every plane size here (a step is half as long on the 16 x 16 planes, but both planes + parameters stay < 90 KB).
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MbBandParams {
+  const cc_bf16* x;
+  const cc_bf16* w_exp;
+  const float* s0;
+  const float* b0;
+  const float* w_dw;
+  const float* s1;
+  const float* b1;
+  cc_bf16* y;
+  float* se_partial;
+  int H, W, Cin, kpad, mid, Ho, Wo, circular;
+  int BH, nbands, nchunks, PWp, total_blocks, ngrp, cpg;
+  unsigned w_magic, xg_magic;
+};
+
+template <int K, int NKK> struct MbBandLds {
+  static constexpr int CH = 16;
+  static constexpr int WPITCH = 16 * NKK + 4;        // dwords per expand-weight row (64 NKK bytes + 16: rows on different banks)
+  static constexpr int WEXP = CH * WPITCH;           // dwords per buffer
+  static constexpr int WL = K * K * CH + 2 * CH;     // depthwise weights | BN1 scale | BN1 shift
+  static constexpr int PARAM_FLOATS = 2 * WEXP + 2 * 2 * CH + 3 * WL + 2 * 4 * 4 * 4;
+};
+
+template <int K, int S, int NKK, int TPW>
+__global__ __launch_bounds__(512) void mbconv_band_kernel(const MbBandParams p) {
+  constexpr int CH = 16, CG = 4, PITCH = 20, SK = 32, E = 8;
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int TP = (S == 1) ? (K - 1) : (K - 2);
+  constexpr int NOUT = (S == 1) ? 4 : 2;
+  constexpr int NCOL = (NOUT - 1) * S + K;
+  using L = MbBandLds<K, NKK>;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  const int IH = (p.BH - 1) * S + K;
+  const int plane_floats = IH * p.PWp * PITCH;
+  float* plane0 = sm;                                // [2][IH][PWp][PITCH]
+  float* wexp = sm + 2 * plane_floats;               // [2][CH][WPITCH] (bf16 rows)
+  float* bn0 = wexp + 2 * L::WEXP;                   // [2][scale CH | shift CH]
+  float* wlb = bn0 + 2 * 2 * CH;                     // [3][K*K*CH | s1 CH | b1 CH]
+  float* red = wlb + 3 * L::WL;                      // [2][4 waves][CG][4]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int lb;
+  {
+    const int q = p.total_blocks / 8, r = p.total_blocks % 8;
+    const int xcd = blockIdx.x % 8, loc = blockIdx.x / 8;
+    lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int grp = lb % p.ngrp;
+  lb /= p.ngrp;
+  const int band = lb % p.nbands;
+  const int b = lb / p.nbands;
+  const int chunk_begin = grp * p.cpg;
+  const int nch = min(p.nchunks, chunk_begin + p.cpg) - chunk_begin;
+  const int oy0 = band * p.BH;
+  const int bh = min(p.BH, p.Ho - oy0);
+  const int IHb = (bh - 1) * S + K;
+  const int iy0 = oy0 * S - PB;
+  const int r_lo = max(0, -iy0), r_hi = min(IHb, p.H - iy0);
+  const int PW = p.W + TP;
+  const int npx = (r_hi - r_lo) * p.W;
+  const size_t gp0 = (size_t)b * p.H * p.W + (size_t)(iy0 + r_lo) * p.W;
+
+  // ---- zeros of BOTH planes (the same band for every slice of this workgroup: written once) ---------------------------------------
+  for (int idx = tid; idx < IHb * 64; idx += 512) {
+    const int r = idx >> 6, j = idx & 63;
+    if (j < PW && ((!p.circular && (j < PB || j >= PB + p.W)) || r < r_lo || r >= r_hi)) {
+      float* d = plane0 + (r * p.PWp + j) * PITCH;
+#pragma unroll
+      for (int g = 0; g < CG; ++g) {
+        *reinterpret_cast<f32x4*>(d + 4 * g) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(d + plane_floats + 4 * g) = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+
+  if (wave < 4) {
+    // =============================== producers ===============================================================================
+    const int px = lane & 15;
+    const int kq = (lane >> 4) * E;
+    const int q4 = (lane >> 4) * 4;
+    const cc_bf16* xb = p.x + gp0 * p.Cin;
+    const int ntile = (npx + 15) >> 4;
+    f32x4 xr[TPW][NKK];
+    int dst[TPW], alt[TPW];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+      const int t = wave + 4 * i;
+      const int qq = 16 * t + px;
+      const int q = min(qq, npx - 1);
+      const cc_bf16* src = xb + (size_t)q * p.Cin;
+#pragma unroll
+      for (int kk = 0; kk < NKK; ++kk) {
+        const int ch = kk * SK + kq;
+        xr[i][kk] = *reinterpret_cast<const f32x4*>(src + (ch < p.Cin ? ch : 0));
+      }
+      const bool valid = qq < npx;
+      const int r = (int)(((unsigned)q * p.w_magic) >> 20);
+      const int c = q - r * p.W;
+      const int rowb = (r_lo + r) * p.PWp;
+      dst[i] = valid ? (rowb + PB + c) * PITCH + q4 : -1;
+      int ac = -1;
+      if (p.circular) ac = c < TP - PB ? PB + p.W + c : (c >= p.W - PB ? c - (p.W - PB) : -1);
+      alt[i] = (valid && ac >= 0) ? (rowb + ac) * PITCH + q4 : -1;
+    }
+    __syncthreads();                                 // slice 0's expand weights are in LDS (consumers' prologue)
+    for (int s = 0; s <= nch; ++s) {
+      if (s < nch) {
+        const float* we = wexp + (s & 1) * L::WEXP;
+        f32x4 wf[NKK];
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) wf[kk] = *reinterpret_cast<const f32x4*>(we + px * L::WPITCH + kk * 16 + (lane >> 4) * 4);
+        const f32x4 sc0 = *reinterpret_cast<const f32x4*>(bn0 + (s & 1) * 2 * CH + q4);
+        const f32x4 sh0 = *reinterpret_cast<const f32x4*>(bn0 + (s & 1) * 2 * CH + CH + q4);
+        float* pl = plane0 + (s & 1) * plane_floats;
+#pragma unroll
+        for (int i = 0; i < TPW; ++i) {
+          if (wave + 4 * i < ntile) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+              acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]), __builtin_bit_cast(cc_bf16x8, xr[i][kk]), acc, 0, 0, 0);
+            f32x4 o;
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) o[rr] = swishf(acc[rr] * sc0[rr] + sh0[rr]);
+            if (dst[i] >= 0) *reinterpret_cast<f32x4*>(pl + dst[i]) = o;
+            if (alt[i] >= 0) *reinterpret_cast<f32x4*>(pl + alt[i]) = o;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  } else {
+    // =============================== consumers ===============================================================================
+    const int ct = tid - 256, cwave = wave - 4;
+    const int cg = ct % CG;
+    const int XG = p.Wo / NOUT;
+    const int nitem = bh * XG;
+    cc_bf16* yb = p.y + ((size_t)b * p.Ho + oy0) * p.Wo * p.mid + 4 * cg;
+    float* sp = p.se_partial + ((size_t)b * p.nbands + band) * p.mid;
+    // the parameters of one slice as this thread's share: NKK / 4 .. pieces of the expand weights, one piece of the depthwise
+    // weights (threads < K*K*4), BN0 / BN1 (threads < 8 / the next 8)
+    constexpr int WPT = (CH * NKK * 4 + 255) / 256;  // 16-byte pieces of w_exp per thread (a row = NKK * 4 pieces)
+    f32x4 pw[WPT], pd, pb;
+    auto fetch = [&](int cl) {                       // cl: slice index inside this workgroup's range (clamped)
+      const int c0 = (chunk_begin + min(cl, nch - 1)) * CH;
+#pragma unroll
+      for (int u = 0; u < WPT; ++u) {
+        const int pc = min(ct + 256 * u, CH * NKK * 4 - 1);
+        pw[u] = *reinterpret_cast<const f32x4*>(p.w_exp + (size_t)(c0 + pc / (NKK * 4)) * p.kpad + (pc % (NKK * 4)) * E);
+      }
+      const int wi = ct < K * K * CG ? ct : 0;
+      pd = *reinterpret_cast<const f32x4*>(p.w_dw + (size_t)(wi / CG) * p.mid + c0 + (wi % CG) * 4);
+      const int bi = ct & 15;                        // 0-3 s0, 4-7 b0, 8-11 s1, 12-15 b1
+      const float* bsrc = bi < 4 ? p.s0 : (bi < 8 ? p.b0 : (bi < 12 ? p.s1 : p.b1));
+      pb = *reinterpret_cast<const f32x4*>(bsrc + c0 + (bi & 3) * 4);
+    };
+    auto park = [&](int cl) {                        // into the buffers slice cl will be read from
+      float* we = wexp + (cl & 1) * L::WEXP;
+#pragma unroll
+      for (int u = 0; u < WPT; ++u) {
+        const int pc = ct + 256 * u;
+        if (pc < CH * NKK * 4) *reinterpret_cast<f32x4*>(we + (pc / (NKK * 4)) * L::WPITCH + (pc % (NKK * 4)) * 4) = pw[u];
+      }
+      float* wl = wlb + (cl % 3) * L::WL;
+      if (ct < K * K * CG) *reinterpret_cast<f32x4*>(wl + ct * 4) = pd;
+      if (ct < 16) {
+        const int bi = ct;
+        float* bd = bi < 8 ? bn0 + (cl & 1) * 2 * CH + (bi >> 2) * CH + (bi & 3) * 4 : wl + K * K * CH + ((bi - 8) >> 2) * CH + (bi & 3) * 4;
+        *reinterpret_cast<f32x4*>(bd) = pb;
+      }
+    };
+    fetch(0);
+    park(0);
+    fetch(1);
+    __syncthreads();
+    for (int s = 0; s <= nch; ++s) {
+      if (s >= 1) {
+        const int cl = s - 1;
+        const int c0 = (chunk_begin + cl) * CH;
+        if (s >= 2 && ct < CG) {                     // squeeze sums of slice s - 2 (its four wave rows were published at the last barrier)
+          const float* rd = red + ((s - 2) & 1) * 64;
+          f32x4 t = *reinterpret_cast<const f32x4*>(rd + ct * 4);
+#pragma unroll
+          for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(rd + (w * CG + ct) * 4);
+          *reinterpret_cast<f32x4*>(sp + (chunk_begin + s - 2) * CH + 4 * ct) = t;
+        }
+        const float* pl = plane0 + (cl & 1) * plane_floats;
+        const float* wl = wlb + (cl % 3) * L::WL;
+        const f32x4 sc1 = *reinterpret_cast<const f32x4*>(wl + K * K * CH + 4 * cg);
+        const f32x4 sh1 = *reinterpret_cast<const f32x4*>(wl + K * K * CH + CH + 4 * cg);
+        f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+        for (int it = ct / CG; it < nitem; it += 256 / CG) {
+          const int oyl = (int)(((unsigned)it * p.xg_magic) >> 20);
+          const int ox0 = (it - oyl * XG) * NOUT;
+          const float* trow = pl + ((oyl * S) * p.PWp + ox0 * S) * PITCH + 4 * cg;
+          int wofs = 4 * cg;
+          asm volatile("" : "+v"(wofs));
+          f32x4 acc[NOUT];
+#pragma unroll
+          for (int t = 0; t < NOUT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          f32x4 col[2][NCOL];
+#pragma unroll
+          for (int j = 0; j < NCOL; ++j) col[0][j] = *reinterpret_cast<const f32x4*>(trow + j * PITCH);
+#pragma unroll
+          for (int ky = 0; ky < K; ++ky) {
+            if (ky + 1 < K) {
+#pragma unroll
+              for (int j = 0; j < NCOL; ++j) col[(ky + 1) & 1][j] = *reinterpret_cast<const f32x4*>(trow + ((ky + 1) * p.PWp + j) * PITCH);
+            }
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+              const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * CH + wofs);
+#pragma unroll
+              for (int t = 0; t < NOUT; ++t) acc[t] += col[ky & 1][t * S + kx] * wv;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          cc_bf16* yrow = yb + (size_t)oyl * p.Wo * p.mid + c0;
+#pragma unroll
+          for (int t = 0; t < NOUT; ++t) {
+            f32x4 o = acc[t] * sc1 + sh1;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = swishf(o[r]);
+            st4<cc_bf16>(yrow + (size_t)(ox0 + t) * p.mid, o);
+            sum += o;
+          }
+        }
+#pragma unroll
+        for (int o = CG; o < 64; o <<= 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sum[r] += __shfl_xor(sum[r], o, 64);
+        }
+        if (lane < CG) *reinterpret_cast<f32x4*>(red + (cl & 1) * 64 + (cwave * CG + lane) * 4) = sum;
+      }
+      if (s + 1 < nch) {                             // slice s + 1: read by the producers at step s + 1, by us at step s + 2
+        park(s + 1);
+        fetch(s + 2);
+      }
+      __syncthreads();
+    }
+    if (ct < CG) {                                   // the last slice's squeeze sums (published at the final barrier)
+      const int cl = nch - 1;
+      const float* rd = red + (cl & 1) * 64;
+      f32x4 t = *reinterpret_cast<const f32x4*>(rd + ct * 4);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) t += *reinterpret_cast<const f32x4*>(rd + (w * CG + ct) * 4);
+      *reinterpret_cast<f32x4*>(sp + (chunk_begin + cl) * CH + 4 * ct) = t;
+    }
+  }
+}
+
 // ---- host: geometry ------------------------------------------------------------------------------------------------------------
 // ds_read_b128 lane groups and 64 four-byte banks (MI355X_MICROARCH.md, LDS section; tools/lds_layout.py is the same model)
 static int mbp_read_cycles(int CG, int pitch, int PWp, int XG, int S, int nitem) {
@@ -399,6 +672,88 @@ int mbplane_nblk(int H, int W, int cin, int mid, int k, int stride) {
   return g.nbands;
 }
 
+// the band-owner kernel (bf16, fused form): same bands as the geometry above (the squeeze-partial rows must not depend on the
+// kernel), its own CH = 16 row pitch, chunk groups so that the launch is about one workgroup per CU
+static int mbband_launch(const MbpGeom& g, const void* x, const void* w_exp, int kpad, const float* s0, const float* b0,
+                         const float* w_dw, const float* s1, const float* b1, void* y, float* se_partial, int B, int H, int W,
+                         int cin, int mid, int k, int stride, int circular, void* stream) {
+  const int tp = stride == 1 ? k - 1 : k - 2;
+  const int Ho = (H + tp - k) / stride + 1, Wo = (W + tp - k) / stride + 1;
+  const int nout = stride == 1 ? 4 : 2;
+  const int XG = Wo / nout;
+  const int IH = (g.BH - 1) * stride + k, PW = W + tp;
+  const int rows = IH < H ? IH : H;
+  const int ntile = (rows * W + 15) / 16;
+  const int tpw = (ntile + 3) / 4;
+  const int nkk = kpad / 32;
+  if (k == 3 && stride == 2) return -1000;
+  if (!((tpw <= 10 && (nkk == 3 || nkk == 4)) || (tpw <= 4 && nkk == 6))) return -1000;
+  struct PitchKey { int k[5]; int pwp; };
+  static thread_local PitchKey pk[16];
+  static thread_local int pk_used = 0, pk_next = 0;
+  int pwp = -1;
+  for (int i = 0; i < pk_used; ++i)
+    if (pk[i].k[0] == PW && pk[i].k[1] == XG && pk[i].k[2] == stride && pk[i].k[3] == g.BH && pk[i].k[4] == IH) pwp = pk[i].pwp;
+  if (pwp < 0) {
+    int bestc = 1 << 30;
+    for (int c = PW; c < PW + 16; ++c) {
+      const int cyc = mbp_read_cycles(4, 20, c, XG, stride, g.BH * XG);
+      if (cyc < bestc) { bestc = cyc; pwp = c; }
+    }
+    pk[pk_next] = PitchKey{{PW, XG, stride, g.BH, IH}, pwp};
+    pk_next = (pk_next + 1) % 16;
+    if (pk_used < 16) ++pk_used;
+  }
+  const int param_floats = nkk == 3 ? (k == 3 ? MbBandLds<3, 3>::PARAM_FLOATS : MbBandLds<5, 3>::PARAM_FLOATS)
+                         : nkk == 4 ? (k == 3 ? MbBandLds<3, 4>::PARAM_FLOATS : MbBandLds<5, 4>::PARAM_FLOATS)
+                                    : (k == 3 ? MbBandLds<3, 6>::PARAM_FLOATS : MbBandLds<5, 6>::PARAM_FLOATS);
+  const int lds = (2 * IH * pwp * 20 + param_floats) * 4;
+  if (lds > 160 * 1024) return -1000;
+  MbBandParams p;
+  p.x = reinterpret_cast<const cc_bf16*>(x); p.w_exp = reinterpret_cast<const cc_bf16*>(w_exp);
+  p.s0 = s0; p.b0 = b0; p.w_dw = w_dw; p.s1 = s1; p.b1 = b1; p.y = reinterpret_cast<cc_bf16*>(y); p.se_partial = se_partial;
+  p.H = H; p.W = W; p.Cin = cin; p.kpad = kpad; p.mid = mid; p.Ho = Ho; p.Wo = Wo; p.circular = circular;
+  p.BH = g.BH; p.nbands = g.nbands; p.nchunks = mid / 16; p.PWp = pwp;
+  // chunk groups: fewest rounds of (one workgroup per CU) x slices per workgroup
+  const long base = (long)B * p.nbands;
+  const int cus = num_cus();
+  int best_g = 1;
+  long best_cost = 1L << 60;
+  for (int ng = 1; ng <= p.nchunks; ++ng) {
+    const int cpg = (p.nchunks + ng - 1) / ng;
+    const int ngr = (p.nchunks + cpg - 1) / cpg;
+    const long rounds = (base * ngr + cus - 1) / cus;
+    const long cost = rounds * (cpg + 2);            // + 2: prologue / drain steps of a workgroup
+    if (cost < best_cost) { best_cost = cost; best_g = ngr; }
+  }
+  p.cpg = (p.nchunks + best_g - 1) / best_g;
+  p.ngrp = (p.nchunks + p.cpg - 1) / p.cpg;
+  const long total = base * p.ngrp;
+  if (total > 0x7fffffffL) return fail(CCVPE_EINVAL, "mbconv_band: grid too large");
+  p.total_blocks = (int)total;
+  p.w_magic = (unsigned)((1048576 + W - 1) / W);
+  p.xg_magic = (unsigned)((1048576 + XG - 1) / XG);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = CCVPE_OK;
+  bool launched = false;
+  auto go = [&](auto kern) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) { rc = fail(CCVPE_ELAUNCH, "mbconv_band: set smem attr: %s", hipGetErrorString(e)); return; }
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(512), lds, st, p);
+    launched = true;
+  };
+#define MBB(K_, S_, NKK_, TPW_) if (k == K_ && stride == S_ && nkk == NKK_ && tpw <= TPW_ && !launched && !rc) go(mbconv_band_kernel<K_, S_, NKK_, TPW_>);
+  MBB(3, 1, 3, 10) MBB(5, 1, 3, 10) MBB(3, 1, 4, 10) MBB(5, 1, 4, 10) MBB(5, 2, 3, 10) MBB(5, 2, 4, 10) MBB(3, 1, 6, 4) MBB(5, 1, 6, 4) MBB(5, 2, 6, 4)
+#undef MBB
+  if (rc) return rc;
+  if (!launched) return -1000;
+  return check_launch("mbconv_band_kernel");
+}
+
 template <typename TE>
 static int mbplane_any(int expand, const void* x, const void* w_exp, int kpad, const float* s0, const float* b0, const float* w_dw,
                        const float* s1, const float* b1, void* y, float* se_partial, int B, int H, int W, int cin, int mid, int k,
@@ -412,6 +767,12 @@ static int mbplane_any(int expand, const void* x, const void* w_exp, int kpad, c
       (expand && (!aligned16(w_exp) || !aligned16(s0) || !aligned16(b0))))
     return fail(CCVPE_EINVAL, "mbconv_plane: pointers must be 16-byte aligned");
   if (circular && W < k) return fail(CCVPE_EINVAL, "mbconv_plane: W too small for circular wrap");
+  if constexpr (sizeof(TE) == 2) {
+    if (expand && (g_mbplane_mode & 4)) {
+      const int rc2 = mbband_launch(g, x, w_exp, kpad, s0, b0, w_dw, s1, b1, y, se_partial, B, H, W, cin, mid, k, stride, circular, stream);
+      if (rc2 != -1000) return rc2;                  // -1000: the band kernel does not take the shape
+    }
+  }
   MbPlaneParams p;
   p.x = x; p.w_exp = w_exp; p.s0 = s0; p.b0 = b0; p.w_dw = w_dw; p.s1 = s1; p.b1 = b1; p.y = y; p.se_partial = se_partial;
   p.H = H; p.W = W; p.Cin = cin; p.kpad = kpad; p.mid = mid; p.circular = circular;
@@ -468,7 +829,7 @@ int mbplane_launch(int is_bf16, int expand, const void* x, const void* w_exp, in
 
 extern "C" int ccvpe_set_mbconv_plane_kernels(int mode) {
   const int old = ccvpe::g_mbplane_mode;
-  ccvpe::g_mbplane_mode = mode & 3;
+  ccvpe::g_mbplane_mode = mode & 7;
   if ((mode >> 8) > 0) ccvpe::g_mbp_plane_kb = (mode >> 8) > 76 ? 76 : (mode >> 8);   // measurements only: LDS budget in KB
   return old;
 }

@@ -112,7 +112,7 @@ int ccvpe_set_pw_ring_kernels(int on);
 /* (ABI 7) The same kind of switch for the late-block MBConv front (csrc/mbconv_plane.hip: planes of <= 1024 pixels, Cin in
  * {80, 112, 192}), which runs behind the UNCHANGED ccvpe_mbconv_front_* / ccvpe_dwconv_* entry points and their *_nblk queries:
  * bit 0 = the fused expand + depthwise form (ccvpe_mbconv_front_nblk reports it), bit 1 = the depthwise-only form
- * (ccvpe_dwconv_*).  0 restores the round-5 chain (pointwise GEMM + dwconv_plane_kernel).  Returns the previous mode; change
+ * (ccvpe_dwconv_*), bit 2 = the band-owner kernel for the fused form in bf16 storage (producer / consumer waves).  0 restores the round-5 chain (pointwise GEMM + dwconv_plane_kernel).  Returns the previous mode; change
  * it only between forwards (the *_nblk queries size the caller's squeeze-partial buffers). */
 int ccvpe_set_mbconv_plane_kernels(int mode);
 /* A 3x3 layer (desc: bf16 storage, one source, bias, no activation — convK.2 of double_conv, models.py:42-47) WITH the next

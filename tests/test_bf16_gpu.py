@@ -97,6 +97,19 @@ def test_mbconv_plane_late_blocks_bf16(ops, k, s, cin, h, w, circ):
     assert got.dtype == BF
     close(nchw(got), want, 1e-2, "bf16 plane front k%d s%d" % (k, s))
     close(part.sum(1), want.sum(dim=(2, 3)), 2e-3, "squeeze partials (fp32 sums of unrounded outputs)")
+    # the default above is the band-owner kernel (producer / consumer waves); the slice-per-workgroup kernel behind the same entry
+    # point must agree with it to the last bf16 bit or two (same arithmetic, another summation order inside the MFMA chain)
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    prev = lib.ccvpe_set_mbconv_plane_kernels(3)
+    try:
+        got1, part1 = ops.mbconv_front(dev(nhwc(x)), dev(pack(w_exp)), dev(s0, f32), dev(b0, f32), wd, dev(s1, f32), dev(b1, f32),
+                                       mid, k, s, circ)
+    finally:
+        lib.ccvpe_set_mbconv_plane_kernels(prev)
+    close(nchw(got1), want, 1e-2, "bf16 plane front (slice kernel) k%d s%d" % (k, s))
+    close(got1, got.float().cpu(), 8e-3, "slice kernel vs band kernel")
+    close(part1, part.cpu(), 1e-4, "squeeze partials: slice kernel vs band kernel")
     tr = r(t)
     want2 = O.swish(O.same_conv(tr, w_dw, k, s, 224, circ, groups=mid) * s1.view(1, -1, 1, 1) + b1.view(1, -1, 1, 1))
     got2, part2 = ops.dwconv(dev(nhwc(tr)), wd, dev(s1, f32), dev(b1, f32), k, s, circ)

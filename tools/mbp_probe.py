@@ -2,7 +2,7 @@
 B = 64, against the round-5 chain on the same tensors, interleaved in one process:
     python tools/mbp_probe.py [reps] [bf16|fp32] [plane KB ...]
 columns: chain = pointwise GEMM + dwconv_plane_kernel (mode 0); dw = pointwise GEMM + the depthwise-only form (mode 2);
-fused = one launch (mode 3), once per LDS budget given."""
+fused = one launch (mode 3), once per LDS budget given; band = the band-owner kernel (mode 7, bf16 only)."""
 import os
 import sys
 
@@ -69,7 +69,10 @@ for (blk, k, s, cin, mid, h, w, circ) in blocks:
         lib.ccvpe_set_mbconv_plane_kernels(3 | (kb << 8))
         nb = ops.mbconv_front_supported(h, w, cin, mid, k, s)
         res.append(("fused@%dKB(nb%d)" % (kb, nb), timed(fused)))
-    lib.ccvpe_set_mbconv_plane_kernels(3 | (72 << 8))
+    if dt == torch.bfloat16:
+        lib.ccvpe_set_mbconv_plane_kernels(7 | (72 << 8))
+        res.append(("band", timed(fused)))
+    lib.ccvpe_set_mbconv_plane_kernels(7 | (72 << 8))
     for nm, us in res:
         tot[nm.split("(")[0]] = tot.get(nm.split("(")[0], 0.0) + us
     print("block %2d k%d s%d %3d->%4d %2dx%-2d  " % (blk, k, s, cin, mid, h, w) + "  ".join("%s %6.1f" % r for r in res), flush=True)
