@@ -24,6 +24,16 @@
 //   dot_i = sum_c' x[c'] * gg[c' + off_i],  off_i = (-i*stride - window_offset) mod C;
 // the LPP partial sums are combined with a butterfly.  For partial windows (L < C: FoV < 360, KITTI) the window norm uses the
 // same trick with a 0/1 table; for L == C it is the pixel's total norm.
+//
+// Round 6 — the N_rot >= 9 configurations on the matrix cores (MFMA = true).  With 20 / 21 hypotheses the per-pixel work is a
+// dense contraction: scores[i][p] = sum_c G[i][c] X[c][p] with the CIRCULANT G[i][c] = gg[c + off_i] of the sample's ground
+// descriptor — on the VALU it was 20 x C scalar FMAs per pixel, each group of four fed by its own 16-byte
+// read of the doubled table (the kernel ran at a third of the rate of its one-hypothesis form: LDS-issue bound).  Now phase 2 is
+// v_mfma_f32_16x16x4_f32 (exact fp32, an fmaf chain: no precision change): A = 16 hypotheses x 4 channels read straight from
+// the doubled table (lane = hypothesis row, the lane's offset off_i folded into its address: one 16- or 8-byte read per four
+// matrix instructions), B = 16 pixels x 4 channels = the tile row piece the VALU form read anyway; the window norms of partial
+// windows (FoV < 360, KITTI) are the same product with the 0/1 table and x^2.  A wave owns pixel tiles (C <= 80) or a K slice
+// of one tile (C >= 160: partial sums meet in LDS in fixed order).  Norms, max, normalised copy and the stores are unchanged.
 #include "common.h"
 
 namespace ccvpe {
@@ -53,8 +63,11 @@ static inline int match_pitch(int C, int lpp) {
   return s;
 }
 
+static inline int match_pitch_mfma(int C) { return ((C + 15) & ~15) + 4; }   // rows zero-padded to 16 channels; S/4 odd
+
 // TX = storage type of X and of the concat output (float or bf16); scores, g and all math are fp32.
-template <typename TX, int NPAD, bool PARTIAL, int VEC>
+// MFMA: phase 2 on the matrix cores (NPAD = 16 or 32 hypothesis rows, VEC >= 2); see the header.
+template <typename TX, int NPAD, bool PARTIAL, int VEC, bool MFMA = false>
 __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, int ldx, const float* __restrict__ g,
                                                     int ldg, int L, const MatchOffsets mo, int n_shifts, int n_max,
                                                     int n_tail, float* __restrict__ scores,
@@ -62,13 +75,15 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int LPP = 1 << lpp_log2;
   const int TP = 256 >> lpp_log2;                   // pixels per workgroup
-  float* gg = sm;                                   // [2C]
-  float* ww = gg + 2 * C;                           // [2C] (PARTIAL only)
-  float* xs = ww + (PARTIAL ? 2 * C : 0);           // [TP][S]   the tile, pixel-major
-  float* sc_s = xs + TP * S;                        // [NPAD][TP] scores of the tile (written out coalesced)
-  float* inv_s = sc_s + NPAD * TP;                  // [TP]  1 / max(||x||, 1e-12)
+  const int TL = MFMA ? 2 * C + 16 : 2 * C;          // table length (MFMA: the zero-padded last 16-channel block reads past 2C)
+  float* gg = sm;                                   // [TL]
+  float* ww = gg + TL;                              // [TL] (PARTIAL only)
+  float* xs = ww + (PARTIAL ? TL : 0);              // [TP][S]   the tile, pixel-major
+  float* sc_s = xs + TP * S;                        // [n_shifts][TP] scores of the tile (written out coalesced)
+  float* inv_s = sc_s + n_shifts * TP;              // [TP]  1 / max(||x||, 1e-12)
   float* mx_s = inv_s + TP;                         // [TP]  max score
   float* red = mx_s + TP;                           // [4]
+  float* pbuf = red + 4;                            // MFMA, K slices: [4 waves][(1 + PARTIAL) * NPAD + 1][16] partial sums
 
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -81,13 +96,14 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   constexpr int EPR = 16 / (int)sizeof(TX);         // elements per request
   const int c4n = C >> 2;
   {
+    constexpr int LIF = MFMA ? 8 : 4;                // requests in flight per thread
     const int gpr = C / EPR;                         // requests per pixel row (C % 8 == 0)
     const int total = npx * gpr;
-    for (int i0 = tid; i0 < total; i0 += 4 * 256) {
-      f32x4 v[4];
-      int dsto[4];
+    for (int i0 = tid; i0 < total; i0 += LIF * 256) {
+      f32x4 v[LIF];
+      int dsto[LIF];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
+      for (int u = 0; u < LIF; ++u) {
         const int idx = min(i0 + u * 256, total - 1);
         const int pp = idx / gpr;
         const int cq = (idx - pp * gpr) * EPR;
@@ -95,7 +111,7 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
         dsto[u] = pp * S + cq;
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+      for (int u = 0; u < LIF; ++u)
         if (i0 + u * 256 < total) {
           if (sizeof(TX) == 4) {
             *reinterpret_cast<f32x4*>(xs + dsto[u]) = v[u];
@@ -108,6 +124,14 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
             *reinterpret_cast<f32x4*>(xs + dsto[u] + 4) = hi;
           }
         }
+    }
+  }
+  if (MFMA) {                                        // zero the pad channels C .. roundup16(C) of every tile row + the table tails
+    const int padc = ((C + 15) & ~15) - C;
+    for (int i = tid; i < TP * padc; i += 256) xs[(i / padc) * S + C + (i % padc)] = 0.f;
+    if (tid < 16) {
+      gg[2 * C + tid] = 0.f;
+      if (PARTIAL) ww[2 * C + tid] = 0.f;
     }
   }
   // descriptor tables + ||g||
@@ -127,6 +151,122 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   const float gnorm = sqrtf(red[0] + red[1] + red[2] + red[3]);
 
   // ---- phase 2: lane (pixel pl, part sub) walks its 4-channel groups ---------------------------------------------------
+  if constexpr (MFMA) {
+    // ---- phase 2 on the matrix cores ----------------------------------------------------------------------------------
+    constexpr int MTL = NPAD / 16;                  // 16-row hypothesis tiles
+    constexpr int NR = (PARTIAL ? 2 : 1) * NPAD + 1;  // rows of a partial-sum block: scores | window norms | total norm
+    const int lane = tid & 63, wave = tid >> 6;
+    const int pxl = lane & 15, kq = lane >> 4;
+    const int NPT = TP >= 16 ? TP >> 4 : 1;         // 16-pixel tiles of the workgroup (TP = 8: half a tile is padding)
+    const int KS = NPT >= 4 ? 1 : 4 / NPT;          // K slices per tile (4 waves)
+    const int nb16 = (C + 15) >> 4;
+    int aoff[MTL];                                  // A operand: lane & 15 = hypothesis row; its table offset + this lane's k group
+#pragma unroll
+    for (int m = 0; m < MTL; ++m) {                 // (a select chain: a lane-indexed read of the kernel argument would go through scratch)
+      int o = mo.off[0];
+#pragma unroll
+      for (int i = 1; i < 16; ++i)
+        if (16 * m + i < CCVPE_MAX_SHIFTS) o = (pxl == i && 16 * m + i < n_shifts) ? mo.off[16 * m + i] : o;
+      if (m > 0 && 16 * m < CCVPE_MAX_SHIFTS) o = (pxl == 0 && 16 * m < n_shifts) ? mo.off[16 * m] : o;
+      aoff[m] = o + 4 * kq;
+    }
+    const int slice = KS == 1 ? 0 : (NPT == 2 ? wave >> 1 : wave);
+    const int kb0 = slice * nb16 / KS, kb1 = (slice + 1) * nb16 / KS;
+    for (int tile = (KS == 1 ? wave : (NPT == 2 ? wave & 1 : 0)); tile < NPT; tile += 4) {
+      const int pp = tile * 16 + pxl;               // rows past npx hold stale LDS: a pixel's column never mixes with another's
+      const float* xrow = xs + min(pp, TP - 1) * S + 4 * kq;
+      f32x4 acc[MTL], nrm[PARTIAL ? MTL : 1];
+#pragma unroll
+      for (int m = 0; m < MTL; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int m = 0; m < (PARTIAL ? MTL : 1); ++m) nrm[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float tot = 0.f;
+      for (int blk = kb0; blk < kb1; ++blk) {
+        const f32x4 xq = *reinterpret_cast<const f32x4*>(xrow + 16 * blk);
+        f32x4 x2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { x2[j] = xq[j] * xq[j]; tot += x2[j]; }
+#pragma unroll
+        for (int m = 0; m < MTL; ++m) {
+          const float* gp = gg + 16 * blk + aoff[m];
+          f32x4 ga;
+          if (VEC == 4) {
+            ga = *reinterpret_cast<const f32x4*>(gp);
+          } else {
+            const f32x2 t0 = *reinterpret_cast<const f32x2*>(gp), t1 = *reinterpret_cast<const f32x2*>(gp + 2);
+            ga = (f32x4){t0[0], t0[1], t1[0], t1[1]};
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[j], xq[j], acc[m], 0, 0, 0);
+          if (PARTIAL) {
+            const float* wp = ww + 16 * blk + aoff[m];
+            f32x4 wa;
+            if (VEC == 4) {
+              wa = *reinterpret_cast<const f32x4*>(wp);
+            } else {
+              const f32x2 t0 = *reinterpret_cast<const f32x2*>(wp), t1 = *reinterpret_cast<const f32x2*>(wp + 2);
+              wa = (f32x4){t0[0], t0[1], t1[0], t1[1]};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nrm[PARTIAL ? m : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j], x2[j], nrm[PARTIAL ? m : 0], 0, 0, 0);
+          }
+        }
+      }
+      tot += __shfl_xor(tot, 16, 64);               // the four k groups of a pixel
+      tot += __shfl_xor(tot, 32, 64);
+      if (KS > 1) {                                 // publish this slice's block; the slice-0 wave of the tile adds them up below
+        float* pb = pbuf + wave * NR * 16;
+#pragma unroll
+        for (int m = 0; m < MTL; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            pb[(16 * m + 4 * kq + r) * 16 + pxl] = acc[m][r];
+            if (PARTIAL) pb[(NPAD + 16 * m + 4 * kq + r) * 16 + pxl] = nrm[PARTIAL ? m : 0][r];
+          }
+        if (kq == 0) pb[(NR - 1) * 16 + pxl] = tot;
+        __syncthreads();                            // (KS > 1: exactly one tile per wave, so every wave arrives once)
+        if (slice == 0) {
+          const int wstep = NPT == 2 ? 2 : 1;       // waves holding the other slices of this tile
+          for (int q = 1; q < KS; ++q) {
+            const float* ob = pbuf + (wave + q * wstep) * NR * 16;
+#pragma unroll
+            for (int m = 0; m < MTL; ++m)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) {
+                acc[m][r] += ob[(16 * m + 4 * kq + r) * 16 + pxl];
+                if (PARTIAL) nrm[PARTIAL ? m : 0][r] += ob[(NPAD + 16 * m + 4 * kq + r) * 16 + pxl];
+              }
+            tot += ob[(NR - 1) * 16 + pxl];
+          }
+        }
+      }
+      if (slice == 0 && pp < npx) {
+        // lane (pixel pp, k group kq) holds hypotheses 16 m + 4 kq + r
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int m = 0; m < MTL; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * m + 4 * kq + r;
+            if (i < n_shifts) {
+              const float wn = sqrtf(PARTIAL ? nrm[PARTIAL ? m : 0][r] : tot);
+              const float sv = acc[m][r] / (wn * gnorm);
+              sc_s[i * TP + pp] = sv;
+              if (i < n_max && (sv > mx || sv != sv)) mx = sv;
+            }
+          }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {         // NaN-propagating like torch.max, any order
+          const float other = __shfl_xor(mx, o, 64);
+          mx = (other > mx || other != other) ? other : mx;
+        }
+        if (kq == 0) {
+          mx_s[pp] = mx;
+          inv_s[pp] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+        }
+      }
+    }
+  } else {
   const int sub = tid & (LPP - 1);
   const int pl = tid >> lpp_log2;
   float acc[NPAD], nrm[PARTIAL ? NPAD : 1];
@@ -207,6 +347,7 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
     mx_s[pl] = mx;
     inv_s[pl] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   }
+  }
   __syncthreads();
 
   // ---- phase 3: whole output rows [X * inv_norm | max | tail scores | 0-pad], and the score volume (NCHW), coalesced -----
@@ -254,21 +395,25 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
 
 using namespace ccvpe;
 
-template <typename TX, int NPAD, bool PARTIAL, int VEC>
+template <typename TX, int NPAD, bool PARTIAL, int VEC, bool MFMA = false>
 static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, const MatchOffsets& mo, int n_shifts,
                         int n_max, int n_tail, float* scores, TX* dstx, int ldo, int B, int hw, int C,
                         hipStream_t st) {
   const int lpp = match_lpp(C);
   int lpp_log2 = 0;
   while ((1 << lpp_log2) < lpp) ++lpp_log2;
-  const int S = match_pitch(C, lpp);
+  const int S = MFMA ? match_pitch_mfma(C) : match_pitch(C, lpp);
   const int tp = 256 / lpp;
-  const size_t smem = sizeof(float) * ((size_t)2 * C * (PARTIAL ? 2 : 1) + (size_t)tp * S + (size_t)NPAD * tp + 2 * tp + 4);
+  const int tl = MFMA ? 2 * C + 16 : 2 * C;
+  const int pbuf = (MFMA && tp < 64) ? 4 * ((PARTIAL ? 2 : 1) * NPAD + 1) * 16 : 0;
+  const size_t smem = sizeof(float) * ((size_t)tl * (PARTIAL ? 2 : 1) + (size_t)tp * S + (size_t)n_shifts * tp + 2 * tp + 4 + pbuf);
   if (smem > 160 * 1024) return fail(CCVPE_EINVAL, "match_level: C=%d needs %zu B of LDS", C, smem);
-  auto kern = match_kernel<TX, NPAD, PARTIAL, VEC>;
-  if (smem > 64 * 1024) {
+  auto kern = match_kernel<TX, NPAD, PARTIAL, VEC, MFMA>;
+  static size_t attr_smem = 64 * 1024;             // per instantiation: the largest size asked for so far
+  if (smem > attr_smem) {
     hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return fail(CCVPE_ELAUNCH, "match_level: set smem attr: %s", hipGetErrorString(e));
+    attr_smem = smem;
   }
   if (B > 65535) return fail(CCVPE_EINVAL, "match_level: batch > 65535");
   dim3 grid((hw + tp - 1) / tp, B);
@@ -276,6 +421,8 @@ static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, co
                      ldo, hw, C, lpp_log2, S);
   return check_launch("match_kernel");
 }
+
+static int g_match_mfma = 1;
 
 template <typename TX>
 static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts, int n_max,
@@ -304,6 +451,18 @@ static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const
   }
   hipStream_t st = (hipStream_t)stream;
 #define M_ARGS x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dstx, ldo, B, hw, C, st
+  if (g_match_mfma && n_shifts >= 9 && n_shifts <= 32 && vec >= 2) {       // many hypotheses: the circulant product on the matrix cores
+#define M_MFMA(NP)                                                          \
+    if (partial) {                                                          \
+      if (vec == 4) return launch_match<TX, NP, true, 4, true>(M_ARGS);     \
+      return launch_match<TX, NP, true, 2, true>(M_ARGS);                   \
+    }                                                                       \
+    if (vec == 4) return launch_match<TX, NP, false, 4, true>(M_ARGS);      \
+    return launch_match<TX, NP, false, 2, true>(M_ARGS);
+    if (n_shifts <= 16) { M_MFMA(16) }
+    M_MFMA(32)
+#undef M_MFMA
+  }
 #define M_DISPATCH(NP)                                              \
   if (n_shifts <= NP) {                                             \
     if (partial) {                                                  \
@@ -319,6 +478,12 @@ static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const
 #undef M_DISPATCH
 #undef M_ARGS
   return fail(CCVPE_EINVAL, "match_level: unreachable");
+}
+
+extern "C" int ccvpe_set_match_mfma(int on) {
+  const int old = g_match_mfma;
+  g_match_mfma = on ? 1 : 0;
+  return old;
 }
 
 extern "C" int ccvpe_match_level_f32(const float* x, int ldx, const float* g, int ldg, int L, const int* shifts,

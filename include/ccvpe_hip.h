@@ -289,6 +289,10 @@ int ccvpe_se_gate_f32(const float* se_partial, int nblk, float inv_hw, const flo
 int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const float* bh, const int* cd,
                                 float* out, int batch, int h, int w, void* stream);
 
+/* (ABI 7) A/B switch of the matrix-core form of ccvpe_match_level_* (9 <= n_shifts <= 32, even table offsets: the circulant
+ * [n_shifts x C] of the ground descriptor times the [C x pixels] tile as v_mfma_f32_16x16x4_f32, exact fp32).  0 = the vector-ALU
+ * form for every configuration.  Returns the previous setting. */
+int ccvpe_set_match_mfma(int on);
 /* -------------------------------------------------------------------------------------------
  * Rotational matching + LMU concat, fused (models.py:186-205 and the five blocks after it;
  * ori_prior :484-514; KITTI :788-806):

@@ -702,6 +702,55 @@ def test_match_level(ops, C, L, stride, hw, shifts, n_max, n_tail):
     assert (catc[:, C + 1 + n_tail:] == 0).all()
 
 
+@pytest.mark.parametrize("C,L,stride,hw,nsh,n_tail", [(80, 80, 4, 19, 20, 0), (160, 160, 8, 13, 20, 0), (320, 320, 16, 9, 20, 0),
+                                                      (80, 40, 4, 12, 21, 0), (160, 80, 8, 11, 12, 0), (320, 160, 16, 7, 9, 9),
+                                                      (640, 320, 32, 5, 21, 0), (40, 40, 2, 33, 32, 0), (40, 20, 2, 17, 16, 0),
+                                                      (1280, 1280, 64, 3, 20, 20), (48, 48, 4, 21, 11, 0)])
+def test_match_level_matrix_core_form(ops, C, L, stride, hw, nsh, n_tail):
+    """9 <= N_rot <= 32: the circulant [N_rot x C] of the ground descriptor times the [C x pixels] tile on v_mfma_f32_16x16x4_f32
+    (models.py:191-202 and the five blocks after it as one dense contraction; north_star's "MFMA for the descriptor x aerial-patch
+    inner product").  Against the oracle, and against the vector-ALU form of the same kernel (switch off): pixel tiles per wave
+    (C <= 80), K slices per wave (C >= 160), half-filled tiles (C >= 640), ragged pixel counts, partial windows, 1 and 2 row tiles."""
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    b = 3
+    shifts = list(range(-(nsh // 2), nsh - nsh // 2)) if L < C else list(range(nsh))
+    x = synth.normal((b, C, hw, hw), 170 + C)
+    g = synth.normal((b, L + 3), 171 + L)
+    ldo = (C + 1 + n_tail + 7) // 8 * 8
+    n_max = nsh
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g)[:, :L], L, shifts, n_max, n_tail, stride, ldo)
+    want = O.rotational_matching(x, g[:, :L], shifts, stride)
+    close(sc, want, 2e-5, "scores (matrix cores)")
+    catc = nchw(cat).cpu()
+    close(catc[:, :C], F.normalize(x, p=2, dim=1), 1e-5, "normalised features")
+    close(catc[:, C], want[:, :n_max].max(dim=1)[0], 2e-5, "max over rotations")
+    if n_tail:
+        close(catc[:, C + 1:C + 1 + n_tail], want[:, len(shifts) - n_tail:], 2e-5, "tail scores")
+    assert (catc[:, C + 1 + n_tail:] == 0).all()
+    prev = lib.ccvpe_set_match_mfma(0)
+    try:
+        sc2, cat2 = ops.match_level(dev(nhwc(x)), dev(g)[:, :L], L, shifts, n_max, n_tail, stride, ldo)
+    finally:
+        lib.ccvpe_set_match_mfma(prev)
+    close(sc, sc2.cpu(), 4e-6, "matrix-core form vs vector-ALU form")
+    close(cat, cat2.cpu(), 4e-6, "concat rows, both forms")
+
+
+def test_match_level_matrix_core_form_propagates_nan_like_torch_max(ops):
+    """A zero-norm window (models.py:196 has no eps) makes that hypothesis NaN; torch.max over the stack then returns NaN."""
+    b, C, hw = 1, 40, 8
+    x = synth.normal((b, C, hw, hw), 190)
+    x[:, :, 2, 3] = 0.0
+    g = synth.normal((b, C), 191)
+    shifts = list(range(20))
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g), C, shifts, 20, 0, 2, 48)
+    want = O.rotational_matching(x, g, shifts, 2)
+    assert not torch.isfinite(sc[0, :, 2, 3]).any() and not torch.isfinite(want[0, :, 2, 3]).any()
+    assert not torch.isfinite(nchw(cat)[0, C, 2, 3])
+    assert torch.isfinite(sc[0, :, 0, 0]).all() and (nchw(cat)[0, :C, 2, 3] == 0).all()
+
+
 def test_match_level_zero_window_gives_nonfinite_like_reference(ops):
     """models.py:196 has no eps: a zero-norm window divides by zero.  Reproduced, not 'fixed'."""
     b, C, hw = 1, 40, 8
