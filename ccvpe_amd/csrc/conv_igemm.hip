@@ -432,6 +432,18 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
                      d->n > 48 &&      // narrow outputs (N <= 48: 16-48 column tiles) stay with the generic kernel
                      d->out_mode == CCVPE_OUT_NHWC && (d->ldd * (out32 ? 4 : 2)) % 16 == 0 &&
                      (!d->residual || (d->ldres * esz) % 16 == 0);
+  // bf16 1x1 layers the ring / pointwise kernels take, with >= 200 of their tiles (B = 64: the late MBConv projections 1152 -> 192
+  // / 320 at 16 x 16 and 10 x 20): one pass beats the split gather kernel + its second pass there (round 6, same-box A/B of the
+  // C1 forward: 8.94 -> 8.87 ms; at B = 32 — 100-128 tiles — the split still wins: C2 5.17 vs 5.25 ms)
+  if (want_floats && !route && sizeof(T) == 2 && is_pw && 16 * c.nt * c.wn > 48) {
+    const bool rr = c.mt == 4 && c.nt == 5 && c.wn == 1;             // (re-routed to the 128 x 96 tile below)
+    const int bm = 16 * c.mt * (4 / (rr ? 2 : c.wn)), bn = 16 * (rr ? 3 : c.nt) * (rr ? 2 : c.wn);
+    const long tiles = (long)((p.M + bm - 1) / bm) * ((p.Npad + bn - 1) / bn);
+    if (tiles >= 200) {
+      *want_floats = 0;
+      return CCVPE_OK;
+    }
+  }
   // the 256 x 80 tile needs more than 256 VGPRs in the persistent pointwise kernel (staging registers live across the
   // epilogue): N = 65..80 pointwise layers take the 128 x 96 tile there
   if (route) {

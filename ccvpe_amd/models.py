@@ -556,13 +556,15 @@ class _CVMBase(nn.Module):
         """Orientation decoder (models.py:323-341): six (deconv -> cat skip -> double_conv) levels and the
         final 3x3 conv to (cos, sin) + F.normalize."""
         xo = cat6
+        # test hook (tests/test_bf16_gpu.py, tools/ori_norm_scan.py): the UN-normalised conv1_ori output, i.e. models.py:341's input
+        normalize = not getattr(self, "ori_raw_output", False)
         for j in range(6):
             ov = pk.ori[j]
             hw = xo.shape[1]
             skip = sfeats[SKIP_BLOCKS[j]] if j < 5 else None
             if j == 5 and FUSE_TAIL and j in FOLD_LEVELS and ops.tail512_ok(hw, hw, ov.n_a):
                 # the whole 512 x 512 level in one launch: deconv1_ori + conv1_ori + F.normalize (models.py:145-148,341)
-                return ops.tail512(xo, ov.k, ov.fw, ov.fshift, ov.w_b, ov.b_b, 2, True, batch=batch, h1=hw, w1=hw)
+                return ops.tail512(xo, ov.k, ov.fw, ov.fshift, ov.w_b, ov.b_b, 2, normalize, batch=batch, h1=hw, w1=hw)
             if j in FOLD_LEVELS and batch * hw * hw >= FOLD_MIN_PIXELS:
                 y = ops.upconv3x3(xo, ov.k, ov.fw, ov.fshift, ov.n_a, batch=batch, h1=hw, w1=hw,
                                   src1=skip, c1=ov.c1, act=ops.ACT_RELU)
@@ -574,7 +576,7 @@ class _CVMBase(nn.Module):
                 xo = ops.conv_igemm(y, ov.n_a, ov.w_b, ov.n_b, batch=batch, in_h=2 * hw, in_w=2 * hw,
                                     kh=3, kw=3, pad=1, shift=ov.b_b)
             else:
-                return ops.head_conv3x3(y, ov.w_b, ov.b_b, 2, True)            # + F.normalize (:341)
+                return ops.head_conv3x3(y, ov.w_b, ov.b_b, 2, normalize)       # + F.normalize (:341)
 
     def _loc_shifts(self):
         n_rot = MODEL_SPECS[self.kind]["n_rot"]

@@ -263,6 +263,7 @@ def forward(sd, grd, sat, kind="vigor", circular_padding=True, ori_noise=None,
         if lvl < 5:
             xo = torch.cat([xo, sfeats[SKIP_BLOCKS[lvl]]], dim=1)
         xo = double_conv(xo, sd, "conv%d_ori" % (6 - lvl))
+    inter["ori_raw"] = xo                              # conv1_ori's output before models.py:341 (tests: where |raw| is small F.normalize amplifies any error)
     xo = F.normalize(xo, p=2, dim=1)                   # models.py:341
 
     out = (logits, heatmap, xo) + tuple(scores)

@@ -341,14 +341,22 @@ def test_forward_bf16_vs_oracle(case, synth_sd, oracle_forward):
 
 LOGIT_ERR_BOUND = 6e-3        # bf16 storage path (default fp32 tail): max |logit error| / logit range, asserted below (measured 4.5e-3)
 ORI_EDGE_DEG = 2.0            # asin(3e-2): the angle the asserted orientation-vector bound can move (the B = 2 cases above)
-# The (cos, sin) error over hundreds of samples is heavy-tailed: F.normalize amplifies the error where the raw 2-vector is small, and
-# WHICH sample has the smallest raw vector at its arg-max pixel is an accident of the rounding pattern (measured over these 256 pairs:
-# p50 3.9e-3, p99 3.5e-2, max 5.4e-2 with the stem tensor rounded to bf16 (CCVPE_FUSE_STEM=0); p50 3.8e-3, p99 3.5e-2 and ONE sample at
-# 1.2e-1 with the stem tensor kept in fp32 by csrc/stem_dw.hip — the more accurate encoder: 252 instead of 250 equal arg-max pixels).  So the bound holds for all but 1 % of the samples and a second, absolute bound
-# for every sample; an orientation bin may differ away from a bin edge only on those counted outliers.
-ORI_VEC_BOUND_AT_SCALE = 6e-2  # asin(6e-2) = 3.4 deg is the angle it can move
-ORI_EDGE_DEG_AT_SCALE = 3.5
-ORI_VEC_MAX_AT_SCALE = 0.2     # no sample beyond this (11.5 deg)
+# The (cos, sin) error over hundreds of samples is heavy-tailed, and round 6 pinned down why (tools/ori_norm_scan.py over these 256
+# pairs): F.normalize (models.py:341) divides by the norm of conv1_ori's raw 2-vector, whose median is 0.37 but which drops to 0.012 at
+# one sample's arg-max pixel — exactly the sample with the 1.05e-1 unit-vector error; error x |raw| never exceeds 7.5e-3.  So the
+# invariant is a bound on the error of the RAW vector, and it holds for EVERY sample (no excused outliers):
+#     |unit-vector error| <= ORI_RAW_ERR_BOUND / |raw|          (and therefore <= ORI_VEC_BOUND_AT_SCALE wherever |raw| >= 1/6)
+# the orientation bin must be equal unless the fp32 angle is within the angle that bound allows, asin(ORI_RAW_ERR_BOUND / |raw|) + 0.5
+# degrees, of a bin edge; the samples with |raw| < ORI_SMALL_NORM (where that angle exceeds 5.7 degrees) are counted and reported.
+ORI_RAW_ERR_BOUND = 1e-2       # measured 7.5e-3 (max over 256 + 64 pairs of |bf16 unit vector - fp32 unit vector| x |fp32 raw vector|)
+ORI_VEC_BOUND_AT_SCALE = 6e-2  # what the raw bound implies for |raw| >= 1/6 (asin(6e-2) = 3.4 deg)
+ORI_SMALL_NORM = 0.1
+
+
+def ori_edge_deg(raw_norm):
+    """The angle (degrees) the raw-vector error bound can turn a vector of this norm, + 0.5 degrees of slack."""
+    import math
+    return math.degrees(math.asin(min(1.0, ORI_RAW_ERR_BOUND / max(raw_norm, 1e-30)))) + 0.5
 
 
 def ori_bin_check(o_got, o_ref, edge_deg=ORI_EDGE_DEG):
@@ -381,10 +389,11 @@ def test_bf16_argmax_margin_rule(synth_sd):
     pixel of every sample; (2) wherever the fp32 top-1 / top-2 margin exceeds TWICE that bound the arg-max pixel is EQUAL — and
     that case must actually occur: >= 25 % of the default-weight samples and >= 60 % of the peaked ones (measured 53 % / 73 %);
     (3) the samples inside the bound ("near ties") are counted and reported, and if the bf16 arg-max moves there it moves to a
-    pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) the (cos, sin) vector at the fp32
-    arg-max pixel is within ORI_VEC_BOUND_AT_SCALE of the fp32 one on all but 1 % of the samples (within ORI_VEC_MAX_AT_SCALE on
-    every one), and on the samples inside the bound the orientation bin is equal wherever the fp32 angle is further from a bin
-    edge than the angle that bound can move (ORI_EDGE_DEG_AT_SCALE).  Pure bf16 storage
+    pixel whose fp32 logit is within twice the bound of the maximum — never anywhere else; (4) for EVERY sample the (cos, sin) vector at the
+    fp32 arg-max pixel is within ORI_RAW_ERR_BOUND / |raw| of the fp32 one (|raw| = norm of the fp32 path's un-normalised
+    conv1_ori output there: the test runs the fp32 model with its raw-output hook and normalises in torch), and the orientation
+    bin is equal wherever the fp32 angle is further from a bin edge than the angle that bound can move; small-norm samples are
+    counted, not excused.  Pure bf16 storage
     (fp32_tail_levels = 0) is held to the same rule with its own measured bound (first 32 pairs).
     Three model instances (fp32, bf16, pure bf16) share the weights: no re-pack per chunk."""
     from ccvpe_amd import models
@@ -395,11 +404,12 @@ def test_bf16_argmax_margin_rule(synth_sd):
         return net.to("cuda:0").eval().set_precision(precision, fp32_tail_levels=tail) if precision == "bf16" else net.to("cuda:0").eval()
 
     def fresh():
-        return dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0, ori_worst=0.0, ori_errs=[])
+        return dict(n=0, same=0, near=0, moved_far=0, worst=0.0, bins_bad=0, bins_edge=0, ori_worst=0.0, ori_errs=[], raw_worst=0.0, small=0)
     stats = {"tail": fresh(), "pure": fresh(), "peaked": fresh()}
     bound = {"tail": LOGIT_ERR_BOUND, "pure": 8e-3, "peaked": 7e-3}
 
-    def account(st, E, ref, got, ref_ori, got_ori):
+    def account(st, E, ref, got, ref_raw, got_ori):
+        ref_ori = F.normalize(ref_raw, p=2, dim=1)                     # models.py:341 on the fp32 path's raw output
         rng = ref.max(1)[0] - ref.min(1)[0]
         err = (got - ref).abs().max(1)[0] / rng
         top2 = ref.topk(2, dim=1)[0]
@@ -418,15 +428,20 @@ def test_bf16_argmax_margin_rule(synth_sd):
                 st["moved_far"] += int(drop > 2 * E)
             o_g = got_ori[b].reshape(2, -1)[:, ia[b]].cpu()
             o_r = ref_ori[b].reshape(2, -1)[:, ia[b]].cpu()
-            same, edge = ori_bin_check(o_g, o_r, ORI_EDGE_DEG_AT_SCALE)
+            raw_norm = float(ref_raw[b].reshape(2, -1)[:, ia[b]].norm())
+            same, edge = ori_bin_check(o_g, o_r, ori_edge_deg(raw_norm))
             oerr = float((o_g - o_r).abs().max())
             st["ori_worst"] = max(st["ori_worst"], oerr)
+            st["raw_worst"] = max(st["raw_worst"], oerr * raw_norm)
             st["ori_errs"].append(oerr)
+            st["small"] += int(raw_norm < ORI_SMALL_NORM)
             st["bins_edge"] += int(edge)
-            st["bins_bad"] += int(not same and not edge and oerr <= ORI_VEC_BOUND_AT_SCALE)
+            st["bins_bad"] += int(not same and not edge)
+            assert oerr * raw_norm <= ORI_RAW_ERR_BOUND, "orientation: unit-vector error %.3e at |raw| = %.3e" % (oerr, raw_norm)
 
     sd = synth_sd("vigor", 0)
     n32, nbf, npure = build(sd, "fp32"), build(sd, "bf16"), build(sd, "bf16", 0)
+    n32.ori_raw_output = True                    # test hook: conv1_ori's output before F.normalize (models.py:341)
     for c0 in range(0, 256, 16):
         grd, sat = synth.synthetic_pair(16, "vigor", 5000 + c0, device="cuda")
         r = n32(grd, sat)
@@ -439,6 +454,7 @@ def test_bf16_argmax_margin_rule(synth_sd):
     del n32, nbf, npure
     sdp = _centre_tap_head(sd)
     n32, nbf = build(sdp, "fp32"), build(sdp, "bf16")
+    n32.ori_raw_output = True
     for c0 in range(0, 64, 16):
         grd, sat = synth.synthetic_pair(16, "vigor", 9000 + c0, device="cuda")
         r = n32(grd, sat)
@@ -447,14 +463,13 @@ def test_bf16_argmax_margin_rule(synth_sd):
         account(stats["peaked"], bound["peaked"], ref, g[0], ref_ori, g[2])
     for k, st in stats.items():
         print("bf16 (%s): arg-max equal %d/%d, near ties (margin <= 2 x %.0e of range) %d, worst logit error %.2e of range, "
-              "orientation: vector error p50 %.2e p99 %.2e, largest %s, bins: %d at a bin edge, %d wrong"
+              "orientation: vector error p50 %.2e p99 %.2e, largest %s, worst error x |raw| %.2e, %d samples with |raw| < %.2f, bins: %d at a "
+              "bin edge, %d wrong"
               % (k, st["same"], st["n"], bound[k], st["near"], st["worst"], sorted(st["ori_errs"])[len(st["ori_errs"]) // 2],
                  sorted(st["ori_errs"])[int(0.99 * (len(st["ori_errs"]) - 1))], ["%.2e" % e for e in sorted(st["ori_errs"])[-4:]],
-                 st["bins_edge"], st["bins_bad"]))
+                 st["raw_worst"], st["small"], ORI_SMALL_NORM, st["bins_edge"], st["bins_bad"]))
         assert st["worst"] <= bound[k], "logit error bound exceeded"
-        outliers = sum(e > ORI_VEC_BOUND_AT_SCALE for e in st["ori_errs"])
-        assert outliers <= max(1, st["n"] // 100), "orientation vector error above %.0e on %d of %d samples" % (ORI_VEC_BOUND_AT_SCALE, outliers, st["n"])
-        assert st["ori_worst"] <= ORI_VEC_MAX_AT_SCALE, "orientation vector error bound exceeded"
+        assert st["raw_worst"] <= ORI_RAW_ERR_BOUND, "orientation: raw-vector error bound exceeded"
         assert st["moved_far"] == 0, "the arg-max moved to a pixel outside the error bound"
         # an absolute floor next to the margin rule: however many near ties the synthetic weights produce, the arg-max must not
         # move on more than 6 % of the samples with the fp32 tail / 6 % in pure bf16 (round 4, 64 pairs: 64/64 and 63/64)

@@ -20,6 +20,8 @@ from oracle import ccvpe_oracle as O
 
 FP32_LOGIT_RTOL = 1e-5          # of max |logit|   (observed ~1e-6)
 BF16_LOGIT_BOUND = 6e-3         # of the logit range (tests/test_bf16_gpu.py LOGIT_ERR_BOUND)
+ORI_RAW_ERR_BOUND = 1e-2        # |bf16 unit vector - oracle unit vector| x |oracle raw vector| at the arg-max pixel (tests/test_bf16_gpu.py)
+ORI_RAW_FIELD_BOUND = 1.5e-2    # the same product over every pixel of the 512 x 512 field (measured 0.99-1.07e-2 on the six benched samples)
 
 pytestmark = pytest.mark.gpu
 
@@ -62,7 +64,10 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
     """Samples `picks` of the benched batch against the CPU oracle run on those samples alone."""
     idx = torch.tensor(list(picks))
     with torch.no_grad():
-        ref = O.forward(synth_sd(kind, 0), grd[idx.to(grd.device)].cpu(), sat[idx.to(sat.device)].cpu(), kind, circular, ori_noise)
+        ref, inter = O.forward(synth_sd(kind, 0), grd[idx.to(grd.device)].cpu(), sat[idx.to(sat.device)].cpu(), kind, circular, ori_noise,
+                               return_intermediates=True)
+    ori_raw = inter["ori_raw"]                           # conv1_ori's output before F.normalize (models.py:341)
+    del inter
     got = [t[idx.to(t.device)].cpu() for t in out]
     assert [tuple(t.shape) for t in got] == [tuple(t.shape) for t in ref]
     for j, i in enumerate(picks):
@@ -87,14 +92,24 @@ def _check_oracle(synth_sd, out, grd, sat, picks, circular, ori_noise, precision
                 assert float(rl[ia] - rl[ib]) / rng <= 2 * BF16_LOGIT_BOUND
             for a, b in zip(got[3:], ref[3:]):
                 assert float((a[j] - b[j]).abs().max()) <= 2e-2
-            # orientation field: F.normalize amplifies the error where the raw 2-vector is small, so the error at ONE pixel is
-            # heavy-tailed (tests/test_bf16_gpu.py: over 256 samples p99 3.5e-2 with single samples at 5e-2 ... 1.2e-1, and WHICH
-            # sample is an accident of the rounding pattern) — the field is held to 5e-2 on 99 % of its 262 144 pixels and the
-            # arg-max pixel to the absolute bound of that test.  (Measured on the benched C2 batches: p50 2.3e-3, p99 2.9-3.2e-2,
-            # p99.9 9-10e-2, field maximum 0.7-1.6 — a near-zero raw vector flips; at the arg-max pixels 1.8e-3 ... 6.2e-2.)
+            # orientation field: F.normalize (models.py:341) divides by the norm of the raw 2-vector, so what bf16 storage bounds is
+            # the error of the RAW vector: |unit-vector error| x |oracle raw vector| <= ORI_RAW_ERR_BOUND at EVERY pixel of the field
+            # (tools/ori_norm_scan.py: at 320 arg-max pixels max 7.5e-3; over the 3 x 262 144 pixels here the maximum is printed), and
+            # at the arg-max pixel — the only place the evaluation reads it, train_VIGOR.py:310-324 — additionally the 18-degree bin
+            # is the oracle's unless the oracle's angle is within the angle that bound can move of a bin edge.
+            raw_n = ori_raw[j].reshape(2, -1).norm(dim=0)
             oerr = (got[2][j] - ref[2][j]).abs().reshape(2, -1).max(0)[0]
-            assert float(torch.quantile(oerr[::7].float(), 0.99)) <= 5e-2, "orientation field: p99 error %.3e" % float(torch.quantile(oerr[::7].float(), 0.99))
-            assert float(oerr[ia]) <= 0.2, "orientation vector at the arg-max pixel: error %.3e" % float(oerr[ia])
+            worst = float((oerr * raw_n).max())
+            print("bf16 orientation field of sample %d: max error x |raw| %.3e, at the arg-max pixel error %.3e with |raw| %.3e"
+                  % (i, worst, float(oerr[ia]), float(raw_n[ia])))
+            assert worst <= ORI_RAW_FIELD_BOUND, "orientation field: raw-vector error %.3e" % worst
+            assert float(oerr[ia] * raw_n[ia]) <= ORI_RAW_ERR_BOUND, "orientation vector at the arg-max pixel: error %.3e at |raw| %.3e" % (float(oerr[ia]), float(raw_n[ia]))
+            import math
+            ang = lambda v: math.degrees(math.atan2(float(v[1]), float(v[0]))) % 360
+            a_g, a_r = ang(got[2][j].reshape(2, -1)[:, ia]), ang(ref[2][j].reshape(2, -1)[:, ia])
+            edge = math.degrees(math.asin(min(1.0, ORI_RAW_ERR_BOUND / max(float(raw_n[ia]), 1e-30)))) + 0.5
+            d = a_r % 18.0
+            assert int(a_g // 18) == int(a_r // 18) or min(d, 18.0 - d) < edge, "bf16 orientation bin of sample %d differs away from a bin edge" % i
 
 
 @pytest.mark.parametrize("name,ori_noise,circular,gshape,batch,precision,rtol", [

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Per-dispatch durations of ONE forward, in dispatch order (single stream): bash tools/gpu/fwd_trace.sh [fp32|bf16] -> gpurun_out/fwd_trace_<prec>.csv
+# Per-dispatch durations of ONE forward, in dispatch order (single stream): bash tools/gpu/fwd_trace.sh [fp32|bf16] [tag] -> gpurun_out/fwd_trace_<prec><tag>.csv
+# EXTRA="--model vigor20 --batch 32" selects another configuration (tag it: _c2)
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 P=${1:-bf16}
+TAG=${2:-}
 export TMPDIR=/tmp
 export CCVPE_EVAL_TWO_STREAMS=0 CCVPE_OVERLAP_DECODERS=0
 cd /tmp
 rm -rf /tmp/fw_tr
-rocprofv3 --kernel-trace --output-format csv -d /tmp/fw_tr -o t -- python3 $R/bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-events > /dev/null 2>&1
-python3 - "$R/gpurun_out/fwd_trace_$P.csv" <<'PY'
+rocprofv3 --kernel-trace --output-format csv -d /tmp/fw_tr -o t -- python3 $R/bench.py --precision $P --steps 2 --warmup 1 --no-cpu-baseline --no-extra --no-kernel-events $EXTRA > /dev/null 2>&1
+python3 - "$R/gpurun_out/fwd_trace_$P$TAG.csv" <<'PY'
 import csv, glob, sys
 f = glob.glob('/tmp/fw_tr/**/*kernel_trace.csv', recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
