@@ -172,23 +172,51 @@ def cpu_baseline_train(sd, kind="vigor", batch=2, reps=2):
 # ------------------------------------------------------------------------------------------------------
 # roofline from the HIP-event launch records
 # ------------------------------------------------------------------------------------------------------
-def _traffic(name, workload):
-    """PMC HBM bytes per launch of kernel `name` from the committed counter pass of `workload` ("f32" forward, "bf16"
-    forward or "train"), with its provenance."""
+def _traffic_table(workload):
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.isfile(tpath):
-        return None, None
+        return {}
     try:
-        d = json.load(open(tpath)).get(workload, {})
+        return json.load(open(tpath)).get(workload, {})
     except Exception:
+        return {}
+
+
+def traffic_key(name, table):
+    """The entry of a pmc_traffic.json workload table a recorder name resolves to: the name itself, else the kernel's family
+    name (template arguments dropped: the counter pass keys some families without them), else None."""
+    if name in table:
+        return name
+    base = name.split("<", 1)[0]
+    return base if base in table else None
+
+
+def _traffic(name, workload):
+    """PMC HBM bytes per launch of kernel `name` from the committed counter pass of `workload` ("f32" forward, "bf16"
+    forward, "bf16_c2" or "train"), with its provenance."""
+    d = _traffic_table(workload)
+    if not d:
         return None, None
     meta = d.get("#meta", {})
-    src = "profiles/pmc_traffic.json[%s] @%s (static rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes, not re-measured here)" \
-          % (workload, meta.get("commit", "unknown"))
-    return d.get(name), src
+    key = traffic_key(name, d)
+    src = "profiles/pmc_traffic.json[%s][%s] @%s (static rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes, not re-measured here)" \
+          % (workload, key, meta.get("commit", "unknown"))
+    return (d.get(key) if key else None), src
 
 
-def whole_step_roof(precision, batch, kind, ms_step, train=False, work_key=None):
+def pmc_step_bytes(workload, ms_step):
+    """What the COUNTERS say a whole step of this workload moves (sum over every kernel family of the committed pass: bytes per
+    launch x launches per step, written by tools/pmc_traffic.py as #meta.gb_per_step) and the HBM utilisation that is at this
+    run's step time — next to the rule-based `frac`, which prices the step with ALGORITHMIC bytes."""
+    meta = _traffic_table(workload).get("#meta", {})
+    gb = meta.get("gb_per_step")
+    if not gb or not ms_step:
+        return {}
+    return {"pmc_gb_per_step": round(gb, 2), "hbm_util": round(gb / ms_step / (HBM_PEAK_GBS / 1e3), 4),
+            "pmc_source": "profiles/pmc_traffic.json[%s] @%s" % (workload, meta.get("commit", "unknown"))}
+
+
+def whole_step_roof(precision, batch, kind, ms_step, train=False, work_key=None, pmc_workload=None):
     """The whole step against the governing roof (forward GFLOP / activation MB per pair; fwd+bwd =
     3 x forward FLOPs).  Needs only the wall time of a step: also available for hipGraph replays.  `work_key` prices the step
     with ITS configuration's work (profiles/algo_work.json) instead of the family's FoV-360 constants."""
@@ -207,14 +235,18 @@ def whole_step_roof(precision, batch, kind, ms_step, train=False, work_key=None)
                   mfma_bf16_frac=round(step_tf / BF16_MATRIX_PEAK_TFLOPS, 4))
     else:
         ws.update(bound="mfma", frac=round(step_tf / FP32_MATRIX_PEAK_TFLOPS, 4))
+    if pmc_workload:
+        ws.update(pmc_step_bytes(pmc_workload, ms_step))
     return ws
 
 
-def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False, work_key=None):
+def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False, work_key=None, pmc_workload=None):
     """summ: ops.LaunchRecorder.summary() (None / empty for a hipGraph replay: events cannot be recorded inside one — the
     roofline then prices the whole step only).  Dominant kernel = the largest total time among the recorded dense launches.
     Returns (roofline dict, per-kernel table or None)."""
-    ws = whole_step_roof(precision, batch, kind, ms_step, train, work_key)
+    if pmc_workload is None:
+        pmc_workload = "train" if train else ("f32" if precision == "fp32" else None)
+    ws = whole_step_roof(precision, batch, kind, ms_step, train, work_key, pmc_workload)
     if ws is not None and work_key:
         ws["work"] = work_key
     if not summ:
@@ -259,6 +291,21 @@ def roofline_from(summ, steps, precision, batch, kind, ms_step, train=False, wor
                 algorithmic_gflop_per_launch=round(d["flops"] / d["calls"] / 1e9, 3),
                 algorithmic_mb_per_launch=round(d["bytes"] / d["calls"] / 1e6, 2),
                 share_of_recorded_time=round(d["ms"] / tot_ms, 3))
+    # the three largest families by recorded time, each against its own roof (a "dominant" kernel alone is 8-10 % of a step)
+    top3 = []
+    for nm, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"])[:3]:
+        t_tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+        t_gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        is_f32 = "f32" in nm or nm.startswith("conv_wgrad") or precision == "fp32"
+        if not is_f32:
+            t_ai = v["flops"] / max(v["bytes"], 1.0)
+            t_bound = "mfma" if t_ai > BF16_MATRIX_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS else "hbm"
+            t_frac = t_tf / BF16_MATRIX_PEAK_TFLOPS if t_bound == "mfma" else t_gb / HBM_PEAK_GBS
+        else:
+            t_bound, t_frac = "mfma", t_tf / FP32_MATRIX_PEAK_TFLOPS
+        top3.append({"kernel": nm, "share_of_recorded_time": round(v["ms"] / tot_ms, 3), "bound": t_bound, "frac": round(t_frac, 4),
+                     "ms_per_step": round(v["ms"] / steps, 3)})
+    roof["top3"] = top3
     if ws is not None:
         roof["whole_step"] = ws
     table = {k: {"ms_per_step": round(v["ms"] / steps, 3),
@@ -292,6 +339,8 @@ def compact(tag, entry):
     out = {k + "_pairs_per_s": entry["value"], k + "_ms": entry["ms_per_step"]}
     ws = (entry.get("roofline") or {}).get("whole_step") or {}
     out[k + "_frac"] = ws.get("frac")
+    if ws.get("hbm_util") is not None:
+        out[k + "_hbm_util"] = ws.get("hbm_util")          # what the COUNTERS say (profiles/pmc_traffic.json), beside the byte-rule frac
     cb = entry.get("cpu_baseline")
     if cb:
         out[k + "_cpu_pairs_per_s"] = round(cb["value"], 3)
@@ -472,7 +521,7 @@ def launch_ranks(n, argv, script=None, timeout=None):
             # torch.distributed.run starts every rank in a session of its OWN, so the launcher's process group does not contain
             # them: collect the descendants first, ask the launcher to stop (its SIGTERM handler stops its workers), then kill
             # whatever is still alive — launcher group and every rank by exact pid
-            ranks = _descendants(proc.pid)
+            ranks = [(pid, _start_time(pid)) for pid in _descendants(proc.pid)]
             try:
                 os.killpg(proc.pid, signal.SIGTERM)
             except ProcessLookupError:
@@ -481,12 +530,18 @@ def launch_ranks(n, argv, script=None, timeout=None):
                 proc.wait(timeout=10)
             except subprocess.TimeoutExpired:
                 pass
-            for pid in [proc.pid] + ranks:
-                for kill in (os.killpg, os.kill):
-                    try:
-                        kill(pid, signal.SIGKILL)
-                    except (ProcessLookupError, PermissionError):
-                        pass
+            # a pid may have been recycled during the 10 s: kill only what is still THE SAME process (same start time in
+            # /proc/<pid>/stat), and a process group only when it is the rank's own session (pgid == pid)
+            victims = [(proc.pid, _start_time(proc.pid))] + ranks
+            for pid, born in victims:
+                if born is None or _start_time(pid) != born:
+                    continue
+                try:
+                    if os.getpgid(pid) == pid:
+                        os.killpg(pid, signal.SIGKILL)
+                    os.kill(pid, signal.SIGKILL)
+                except (ProcessLookupError, PermissionError):
+                    pass
             proc.wait()
             print("bench.py: %s: killed the launcher and its %d rank process(es)" % (type(ex).__name__, len(ranks)), file=sys.stderr)
             return 124
@@ -503,6 +558,15 @@ def launch_ranks(n, argv, script=None, timeout=None):
         print("bench.py: the ranks exited 0 without printing a line", file=sys.stderr)
         return 1
     return rc
+
+
+def _start_time(pid):
+    """Start time (clock ticks since boot, field 22 of /proc/<pid>/stat) — identifies a process across pid reuse; None if gone."""
+    try:
+        with open("/proc/%d/stat" % pid) as f:
+            return int(f.read().rsplit(")", 1)[1].split()[19])
+    except (OSError, ValueError, IndexError):
+        return None
 
 
 def _descendants(root):
@@ -528,19 +592,25 @@ def _count_gpus_without_hip():
     """GPUs of this node WITHOUT loading the HIP runtime in this (parent) process: the KFD topology lists one node per agent,
     GPUs are the nodes with SIMDs.  None if the topology is not readable (then the ranks themselves will fail loudly)."""
     if os.environ.get("CCVPE_BENCH_FAKE_GPUS"):                 # tests only (CPU boxes have no KFD topology)
-        return int(os.environ["CCVPE_BENCH_FAKE_GPUS"])
-    top = "/sys/class/kfd/kfd/topology/nodes"
-    try:
-        n = 0
-        for d in os.listdir(top):
-            with open(os.path.join(top, d, "properties")) as f:
-                for line in f:
-                    k, _, v = line.partition(" ")
-                    if k == "simd_count" and int(v) > 0:
-                        n += 1
-        return n
-    except (OSError, ValueError):
-        return None
+        n = int(os.environ["CCVPE_BENCH_FAKE_GPUS"])
+    else:
+        top = "/sys/class/kfd/kfd/topology/nodes"
+        try:
+            n = 0
+            for d in os.listdir(top):
+                with open(os.path.join(top, d, "properties")) as f:
+                    for line in f:
+                        k, _, v = line.partition(" ")
+                        if k == "simd_count" and int(v) > 0:
+                            n += 1
+        except (OSError, ValueError):
+            return None
+    # a visibility mask narrows what the ranks will see: the guard must not pass on devices they cannot open
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
 
 
 def check_world(args, world):
@@ -682,8 +752,13 @@ def main():
             # RobotCar variant, hardware not stated (/root/reference/README.md:21)
             line["vs_baseline"] = round(value / 14.0, 2)
             line["config"]["baseline"] = "14 FPS per frame (reference README, hardware not stated)"
+        pmc_wl = None
+        if args.precision == "bf16" and args.batch == {"prior0": 64, "vigor20": 32}.get(args.model):
+            pmc_wl = {"prior0": "bf16", "vigor20": "bf16_c2"}[args.model]     # the configurations the counter passes were taken on
+        elif args.precision == "fp32" and not (args.model == "prior0" and args.batch == 64):
+            pmc_wl = ""                                                       # another fp32 configuration: no counter pass for it
         line["roofline"], table = roofline_from(rec.summary() if rec is not None else None, args.steps, args.precision,
-                                                args.batch, kind, ms_step, work_key=WORK_KEY.get(args.model))
+                                                args.batch, kind, ms_step, work_key=WORK_KEY.get(args.model), pmc_workload=pmc_wl)
         emit_kernel_table("headline", table)
         if rec is not None and args.per_layer:
             per_layer_table(rec, args.steps)
@@ -752,7 +827,8 @@ def main():
                 if rank == 0:
                     roof, table = roofline_from(r2.summary() if r2 is not None else None, 3, "bf16", b2, "vigor", 1e3 * e2 / ns2,
                                                 work_key={"C2_bf16": "vigor20", "C1_bf16": "vigor_prior0",
-                                                          "C4_bf16_graph_b256": "vigor_prior180_fov180"}[tag])
+                                                          "C4_bf16_graph_b256": "vigor_prior180_fov180"}[tag],
+                                                pmc_workload={"C2_bf16": "bf16_c2", "C1_bf16": "bf16"}.get(tag))
                     emit_kernel_table(tag, table)
                     legs[tag] = {"workload": what, "value": round(b2 * world * ns2 / e2, 2), "n_gpus": world, "batch_per_gpu": b2,
                                  "ms_per_step": round(1e3 * e2 / ns2, 3), "steps": ns2, "dtype": "bf16", "roofline": roof,

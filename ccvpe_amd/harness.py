@@ -192,6 +192,13 @@ class GradientAllReducer:
         self._done_in_backward = False
 
     def begin(self):
+        # step_in_backward: the previous backward's in-backward updates are only "consumed" by optimizer.step(); a second
+        # backward without it (gradient accumulation, a step skipped after an inf / nan check) would find every parameter
+        # marked as already stepped — its step_subset() a silent no-op and the following step() skipping everything
+        opt = getattr(self, "_optimizer", None)
+        if getattr(self, "_step_in_backward", False) and opt is not None and getattr(opt, "_pre_stepped", None):
+            raise RuntimeError("GradientAllReducer(step_in_backward=True): optimizer.step() was not called since the last "
+                               "in-backward update; gradient accumulation / skipped steps are not supported in this mode")
         self._pending, self._sent = [], set()
         self._done_in_backward = False
         self._group = 0

@@ -35,6 +35,9 @@ ZERO_PAD_BLOCKS = (0, 1, 3, 5, 8, 11, 15)  # subset stored for the non-circular 
 
 
 TRAIN_CASE = dict(kind="vigor", circular=True, wseed=0, pseed=2024, batch=2, grd="vigor")
+# BASELINE config C3's model in .train(): CVM_KITTI (models.py:752-950), 256 x 1024 ground image, 16 rotation hypotheses
+TRAIN_CASE_KITTI = dict(kind="kitti", circular=False, wseed=1, pseed=2025, batch=2, grd="kitti")
+TRAIN_CASES = {"vigor": TRAIN_CASE, "kitti": TRAIN_CASE_KITTI}
 
 
 def train_drop_masks(batch):

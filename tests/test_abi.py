@@ -222,3 +222,26 @@ def test_round5_queries_without_a_gpu():
     assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 4
     assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 1, 0)) == 4
     assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 1, 1)) == 1      # bf16 storage writing fp32: pw_gemm_kernel
+
+
+def test_pw_ring_is_never_routed_with_fewer_than_three_k_stages():
+    """csrc/conv_pw2_impl.h: the ring's DMA requests run three K stages ahead of the matrix instructions and the per-tile vectors
+    (two LDS copies by tile parity) of tile t + 2 must not be requested before every wave is past tile t's epilogue — a hazard that
+    is excluded by ROUTING (pw2_supported), so the route is what this pins: a bf16 layer with K = 64 is exactly two 32-channel stages
+    and must stay on pw_gemm_kernel, K = 96 (three stages) may take the ring; fp32 needs K >= 64 = four 16-channel stages anyway."""
+    import ctypes
+    lib = _lib.load()
+    fam = lambda r: r & 0xff
+    d = _lib.ConvDesc()
+    d.src0 = d.w = d.dst = d.scale = d.shift = 256
+    d.batch, d.in_h, d.in_w = 4, 32, 32
+    d.kh = d.kw = 1
+    d.stride, d.pad, d.n, d.ldd, d.act = 1, 0, 384, 384, 2                    # an expand-shaped layer: BN + swish, N = 384
+    for c0, want in ((64, 1), (96, 4), (128, 4)):                             # 2, 3, 4 bf16 K stages
+        d.c0, d.ld0, d.kpad = c0, c0, c0
+        r = lib.ccvpe_conv_igemm_route(ctypes.byref(d), 1, 0)
+        assert fam(r) == want, "bf16 K = %d: route %d, expected %d" % (c0, fam(r), want)
+    d.c0, d.ld0, d.kpad = 64, 64, 64
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 4        # fp32 K = 64: four stages
+    d.c0, d.ld0, d.kpad = 48, 48, 48
+    assert fam(lib.ccvpe_conv_igemm_route(ctypes.byref(d), 0, 0)) == 1        # fp32 K = 48 (three stages): below the ring's minimum K

@@ -138,3 +138,23 @@ def test_per_configuration_work_prices_fov180_below_fov360():
     ws360 = bench.whole_step_roof("bf16", 256, "vigor", 44.0, work_key="vigor20")
     ws180 = bench.whole_step_roof("bf16", 256, "vigor", 44.0, work_key="vigor_prior180_fov180")
     assert ws180["frac"] < ws360["frac"] and ws180["bound"] == "hbm"
+
+
+def test_gpu_count_guard_respects_visibility_masks(monkeypatch):
+    """`--gpus N` on a node that SHOWS fewer devices to the ranks (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES) must be
+    refused by the parent's guard, not discovered as rank crashes; and the timeout path identifies processes by (pid, start time)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("CCVPE_BENCH_FAKE_GPUS", "8")
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(var, raising=False)
+    assert bench._count_gpus_without_hip() == 8
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,1,2")
+    assert bench._count_gpus_without_hip() == 3
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "4")
+    assert bench._count_gpus_without_hip() == 1
+    me = os.getpid()
+    assert bench._start_time(me) is not None and bench._start_time(me) == bench._start_time(me)
+    assert bench._start_time(2 ** 22 + 12345) is None

@@ -283,3 +283,27 @@ def test_two_rank_exact_infonce_equals_one_rank_big_batch(tmp_path):
     assert abs(float(loss2) - float(big.detach())) <= 1e-6 * abs(float(big.detach()))
     assert torch.allclose(grad2, w.grad, rtol=1e-4, atol=1e-7)
     assert abs(float(local0) - float(big.detach())) > 1e-4 * abs(float(big.detach()))      # the per-rank loss is a different number
+
+
+def test_step_in_backward_refuses_a_backward_without_the_optimizer_step_in_between():
+    """with step_in_backward=True a second backward without optimizer.step() (gradient accumulation, a step
+    skipped after an inf / nan check) used to make step_subset() a silent no-op and the next step() skip every parameter."""
+    import pytest
+    import torch
+    from ccvpe_amd import harness
+
+    class Opt(object):
+        _pre_stepped = set()
+
+        def step_subset(self, params):
+            pass
+
+    p = torch.nn.Parameter(torch.zeros(4))
+    red = harness.GradientAllReducer([p])
+    red._optimizer, red._step_in_backward = Opt(), True
+    red.begin()                                   # nothing pending: fine
+    red._optimizer._pre_stepped = {id(p)}         # an in-backward update happened, optimizer.step() did not
+    with pytest.raises(RuntimeError, match="optimizer.step"):
+        red.begin()
+    red._optimizer._pre_stepped = set()           # what optimizer.step() leaves behind
+    red.begin()

@@ -44,10 +44,12 @@ def test_forward_matches_reference_golden(name, synth_sd):
         G.assert_close(t[:, :, ::st, ::st].numpy(), want["sat_block%d_s" % blk], RTOL, ATOL, "skip")
 
 
-def test_train_mode_forward_matches_reference_golden(synth_sd):
-    """Batch-statistic BN + injected drop_connect draws + running-stat updates (reference in .train())."""
-    c = G.TRAIN_CASE
-    want = G.load("fwd_vigor_trainmode")
+@pytest.mark.parametrize("case", ["vigor", "kitti"])
+def test_train_mode_forward_matches_reference_golden(synth_sd, case):
+    """Batch-statistic BN + injected drop_connect draws + running-stat updates (reference in .train()): CVM_VIGOR
+    (models.py:150-343) and CVM_KITTI (models.py:752-950, BASELINE config C3's model)."""
+    c = G.TRAIN_CASES[case]
+    want = G.load("fwd_%s_trainmode" % case)
     sd = synth_sd(c["kind"], c["wseed"])
     grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
     _, scales, _ = G.train_drop_masks(c["batch"])
@@ -117,13 +119,14 @@ PINNED_HASH = [4181168224, 2125990995, 531683462]
 PINNED_UNIFORM = [0.5901376008987427, 0.5631661415100098, 0.5688017010688782, 0.8550075888633728]
 
 
-def test_oracle_train_mode_gradients_vs_reference_autograd():
+@pytest.mark.parametrize("case", ["vigor", "kitti"])
+def test_oracle_train_mode_gradients_vs_reference_autograd(case):
     """The oracle is differentiable torch code: its train-mode gradients for the shared deterministic loss must
-    match the gradients autograd produced through the REFERENCE (grad_vigor_trainmode.npz)."""
+    match the gradients autograd produced through the REFERENCE (grad_vigor_trainmode.npz, grad_kitti_trainmode.npz)."""
     import torch
     from ccvpe_amd import synth
-    c = G.TRAIN_CASE
-    want = G.load("grad_vigor_trainmode")
+    c = G.TRAIN_CASES[case]
+    want = G.load("grad_%s_trainmode" % case)
     sd = synth.synthetic_state_dict(c["kind"], c["wseed"])
     params = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone())
               for k, v in sd.items()}

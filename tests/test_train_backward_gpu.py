@@ -14,10 +14,10 @@ from ccvpe_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _train_step(synth_sd):
+def _train_step(synth_sd, case="vigor"):
     from ccvpe_amd import models
-    c = G.TRAIN_CASE
-    net = models.CVM_VIGOR("cuda", c["circular"])
+    c = G.TRAIN_CASES[case]
+    net = models.CVM_KITTI("cuda") if c["kind"] == "kitti" else models.CVM_VIGOR("cuda", c["circular"])
     net.load_state_dict(synth_sd(c["kind"], c["wseed"]), strict=True)
     net = net.to("cuda:0").train()
     grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
@@ -44,6 +44,18 @@ def test_full_backward_vs_reference_autograd(synth_sd):
     print("median rel err vs f64: reference %.3e, hip %.3e; vs reference %.3e; worst ratios %s" % (m_ref, m_got, med, worst))
     assert m_got <= 3.0 * m_ref + 1e-3, (m_got, m_ref)
     assert all(e_got[n] <= max(3e-2, 4.0 * e_ref[n]) for n in e_got), worst
+
+
+def test_full_backward_kitti_vs_reference_autograd(synth_sd):
+    """BASELINE config C3's model: CVM_KITTI in .train() against the gradients autograd produced through the REFERENCE class
+    (models.py:752-950; tests/golden/grad_kitti_trainmode.npz from tools/make_golden.py) — not only against the oracle's."""
+    net, out, loss = _train_step(synth_sd, "kitti")
+    want = G.load("grad_kitti_trainmode")
+    got = G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()])
+    bad, med = G.compare_grads(got, want)
+    print("CVM_KITTI train mode: %d tensors with a gradient, median relative L2 vs the reference's autograd %.3e" % (len(want["names"]), med))
+    assert not bad, "%d/%d parameter gradients off: %s" % (len(bad), len(want["names"]), bad[:12])
+    assert med < 6e-3, med
 
 
 def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):

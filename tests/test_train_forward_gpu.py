@@ -57,12 +57,14 @@ def test_bn_act_matches_torch_batch_norm(ops):
     close(y2.permute(0, 3, 1, 2), want * dcs.view(-1, 1, 1, 1) + res, 1e-5, "bn * drop_connect + residual")
 
 
-def test_train_mode_forward_vs_reference_golden(synth_sd):
+@pytest.mark.parametrize("case", ["vigor", "kitti"])
+def test_train_mode_forward_vs_reference_golden(synth_sd, case):
+    """CVM_VIGOR and CVM_KITTI (BASELINE config C3's model) in .train() against the reference classes' own outputs."""
     from ccvpe_amd import models
-    c = G.TRAIN_CASE
-    want = G.load("fwd_vigor_trainmode")
+    c = G.TRAIN_CASES[case]
+    want = G.load("fwd_%s_trainmode" % case)
     sd = synth_sd(c["kind"], c["wseed"])
-    net = models.CVM_VIGOR("cuda", c["circular"])
+    net = models.CVM_KITTI("cuda") if c["kind"] == "kitti" else models.CVM_VIGOR("cuda", c["circular"])
     net.load_state_dict(sd, strict=True)
     net = net.to("cuda:0").train()
     grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])

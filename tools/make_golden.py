@@ -71,38 +71,41 @@ def main():
             return
         # ---- train-mode forward (batch-stat BN, injected drop_connect draws) ----------------------------
         import efficientnet_pytorch.model as effmodel
-        c = G.TRAIN_CASE
-        if (c["kind"], c["wseed"]) not in sds:
-            sds[(c["kind"], c["wseed"])] = synth.synthetic_state_dict(c["kind"], c["wseed"])
-        sd = sds[(c["kind"], c["wseed"])]
-        masks, _, skip = G.train_drop_masks(c["batch"])
-        order = [("grd_efficientnet", i) for i in skip] + [("sat_efficientnet", i) for i in skip]
-        calls = []
+        train_only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--train-case=")]
+        for tname, c in G.TRAIN_CASES.items():
+            if train_only and tname not in train_only:
+                continue
+            if (c["kind"], c["wseed"]) not in sds:
+                sds[(c["kind"], c["wseed"])] = synth.synthetic_state_dict(c["kind"], c["wseed"])
+            sd = sds[(c["kind"], c["wseed"])]
+            masks, _, skip = G.train_drop_masks(c["batch"])
+            order = [("grd_efficientnet", i) for i in skip] + [("sat_efficientnet", i) for i in skip]
+            calls = []
 
-        def injected_drop_connect(inputs, p, training):
-            key = order[len(calls)]
-            calls.append(key)
-            return inputs / (1 - p) * masks[key].view(-1, 1, 1, 1)
-        real_dc = effmodel.drop_connect
-        effmodel.drop_connect = injected_drop_connect
-        net = ref_models.CVM_VIGOR("cpu", c["circular"])
-        net.load_state_dict(sd, strict=True)
-        net.train()
-        grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
-        with torch.enable_grad():
-            out = net(grd, sat)
-            effmodel.drop_connect = real_dc
-            assert len(calls) == len(order)
-            # ---- gradients of the shared deterministic loss through the REFERENCE (autograd on the CPU) --------
-            G.train_loss(out).backward()
-        save("grad_vigor_trainmode", G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()]))
-        out = [t.detach() for t in out]
-        d = G.summarize_forward(out)
-        after = net.state_dict()
-        for k in G.RUNNING_STAT_SAMPLES:
-            d["rm:" + k] = after[k + ".running_mean"].numpy()
-            d["rv:" + k] = after[k + ".running_var"].numpy()
-        save("fwd_vigor_trainmode", d)
+            def injected_drop_connect(inputs, p, training):
+                key = order[len(calls)]
+                calls.append(key)
+                return inputs / (1 - p) * masks[key].view(-1, 1, 1, 1)
+            real_dc = effmodel.drop_connect
+            effmodel.drop_connect = injected_drop_connect
+            net = ref_models.CVM_KITTI("cpu") if c["kind"] == "kitti" else ref_models.CVM_VIGOR("cpu", c["circular"])
+            net.load_state_dict(sd, strict=True)
+            net.train()
+            grd, sat = synth.synthetic_pair(c["batch"], c["grd"], c["pseed"])
+            with torch.enable_grad():
+                out = net(grd, sat)
+                effmodel.drop_connect = real_dc
+                assert len(calls) == len(order)
+                # ---- gradients of the shared deterministic loss through the REFERENCE (autograd on the CPU) --------
+                G.train_loss(out).backward()
+            save("grad_%s_trainmode" % tname, G.summarize_grads([(n, p.grad) for n, p in net.named_parameters()]))
+            out = [t.detach() for t in out]
+            d = G.summarize_forward(out)
+            after = net.state_dict()
+            for k in G.RUNNING_STAT_SAMPLES:
+                d["rm:" + k] = after[k + ".running_mean"].numpy()
+                d["rv:" + k] = after[k + ".running_var"].numpy()
+            save("fwd_%s_trainmode" % tname, d)
         if only_train:
             return
 

@@ -82,12 +82,21 @@ def main():
                      "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (KiB); FETCH_SIZE x 2 "
                                "(gfx950 reports half of a 16 B/lane coalesced read, MI355X_MICROARCH.md HBM section), "
                                "WRITE_SIZE as is (uncalibrated); mean bytes per launch of each kernel family"}}
+    # bytes a whole STEP moves according to the counters: every family's bytes per launch x its launches, over the executed
+    # steps (counted from the stem launches: two per forward — ground and aerial)
+    stem = max([n1.get(k, 0) for k in n1 if k.startswith("stem_dw_kernel") or k.startswith("stem_conv_kernel")] or [0])
+    steps = stem / 2.0 if stem else 0.0
+    total = 0.0
     for k in sorted(set(fetch) | set(write)):
         rd = 2.0 * fetch.get(k, 0.0) * 1024.0
         wr = write.get(k, 0.0) * 1024.0
+        total += rd * n1.get(k, 0) + wr * n2.get(k, n1.get(k, 0))
         out[k] = round(rd + wr)
         out[k + "#detail"] = {"read_bytes_corrected_x2": round(rd), "write_bytes": round(wr),
                               "launches_sampled": int(n1.get(k, 0))}
+    if steps:
+        out["#meta"]["steps_executed"] = steps
+        out["#meta"]["gb_per_step"] = round(total / steps / 1e9, 3)
     json.dump(out, open(sys.argv[3], "w"), indent=1, sort_keys=True)
     print("wrote", sys.argv[3])
 
