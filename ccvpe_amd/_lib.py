@@ -79,6 +79,7 @@ PROTOTYPES = {
     "ccvpe_set_narrow_kernels": (c_int, [c_int]),
     "ccvpe_set_pw_ring_kernels": (c_int, [c_int]),
     "ccvpe_set_mbconv_plane_kernels": (c_int, [c_int]),
+    "ccvpe_mbconv_front_route": (c_int, [c_int] * 8),
     "ccvpe_set_match_mfma": (c_int, [c_int]),
     "ccvpe_conv3x3_match1_ok": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_conv3x3_match1_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -274,6 +274,16 @@ extern "C" int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int
   return ((Ho + toh - 1) / toh) * ((Wo + 15) / 16);
 }
 
+// which kernel ccvpe_mbconv_front_* runs for a shape (reporting: bench.py's launch recorder, tests): 0 = not served (use the
+// unfused calls), 1 = mbconv_front_kernel (early blocks), 2 = mbconv_plane_kernel (late blocks, one channel slice per workgroup),
+// 3 = mbconv_band_kernel (late blocks, bf16: producer / consumer waves)
+extern "C" int ccvpe_mbconv_front_route(int in_h, int in_w, int cin, int mid, int k, int stride, int is_bf16, int batch) {
+  if (!(k == 3 || k == 5) || !(stride == 1 || stride == 2)) return CCVPE_EINVAL;
+  if (mbf_supported(in_w, cin, mid, k, 16, stride)) return 1;
+  if (!(g_mbplane_mode & 1) || mbplane_nblk(in_h, in_w, cin, mid, k, stride) <= 0) return 0;
+  return (is_bf16 && (g_mbplane_mode & 4) && mbband_takes(in_h, in_w, cin, mid, k, stride, batch)) ? 3 : 2;
+}
+
 template <typename TE>
 static int mbconv_front_any(const void* x, const void* w_exp, int kpad, const float* s0, const float* b0,
                             const float* w_dw, const float* s1, const float* b1, void* y, float* se_partial, int B,

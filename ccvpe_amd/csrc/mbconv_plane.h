@@ -13,6 +13,9 @@ int mbplane_launch(int is_bf16, int expand, const void* x, const void* w_exp, in
                    const float* w_dw, const float* s1, const float* b1, void* y, float* se_partial, int B, int H, int W,
                    int cin, int mid, int k, int stride, int circular, void* stream);
 
+// does the band-owner kernel (bf16, fused form) take this shape?  (the same test mbplane_launch applies)
+bool mbband_takes(int H, int W, int cin, int mid, int k, int stride, int B);
+
 // A/B switch (ccvpe_set_mbconv_plane_kernels): 0 = the round-5 chain (pointwise GEMM + dwconv_plane_kernel)
 extern int g_mbplane_mode;   // bit 0: fused expand + depthwise, bit 1: depthwise-only form, bit 2: band-owner kernel (bf16, fused)
 

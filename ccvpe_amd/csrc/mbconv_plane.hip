@@ -230,14 +230,15 @@ __global__ __launch_bounds__(256, 2) void mbconv_plane_kernel(const MbPlaneParam
   const int nitem = bh * XG;
   TE* yb = reinterpret_cast<TE*>(p.y) + ((size_t)b * p.Ho + oy0) * p.Wo * p.mid + c0 + 4 * cg;
   f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+  // depthwise weights in registers for the whole workgroup (LDS returns in order: a weight read behind the next row's window reads,
+  // needed by the very next FMA, made every kernel row wait for the prefetch it was meant to overlap with — see mbconv_band_kernel)
+  f32x4 wr[K * K];
+#pragma unroll
+  for (int q = 0; q < K * K; ++q) wr[q] = *reinterpret_cast<const f32x4*>(wl + q * CH + 4 * cg);
   for (int it = tid / CG; it < nitem; it += 256 / CG) {
     const int oyl = (int)(((unsigned)it * p.xg_magic) >> 20);
     const int ox0 = (it - oyl * XG) * NOUT;
     const float* trow = plane + ((oyl * S) * p.PWp + ox0 * S) * PITCH + 4 * cg;
-    // the weight reads are invariant over the item loop: left visible, LICM parks all K*K vectors in registers (k = 5: 100
-    // VGPRs, the kernel spills); an opaque offset keeps them inside the iteration (LDS broadcast reads, one per tap)
-    int wofs = 4 * cg;
-    asm volatile("" : "+v"(wofs));
     f32x4 acc[NOUT];
 #pragma unroll
     for (int t = 0; t < NOUT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 2) void mbconv_plane_kernel(const MbPlaneParam
       }
 #pragma unroll
       for (int kx = 0; kx < ((MBP_ABL & 4) ? 1 : K); ++kx) {
-        const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * CH + wofs);
+        const f32x4 wv = wr[ky * K + kx];
 #pragma unroll
         for (int t = 0; t < NOUT; ++t) acc[t] += col[ky & 1][t * S + kx] * wv;
       }
@@ -334,7 +335,7 @@ template <int K, int NKK> struct MbBandLds {
   static constexpr int PARAM_FLOATS = 2 * WEXP + 2 * 2 * CH + 3 * WL + 2 * 4 * 4 * 4;
 };
 
-template <int K, int S, int NKK, int TPW>
+template <int K, int S, int NKK, int TPW, int RY>
 __global__ __launch_bounds__(512) void mbconv_band_kernel(const MbBandParams p) {
   constexpr int CH = 16, CG = 4, PITCH = 20, SK = 32, E = 8;
   constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
@@ -427,14 +428,14 @@ __global__ __launch_bounds__(512) void mbconv_band_kernel(const MbBandParams p) 
         float* pl = plane0 + (s & 1) * plane_floats;
 #pragma unroll
         for (int i = 0; i < TPW; ++i) {
-          if (wave + 4 * i < ntile) {
+          if (wave + 4 * i < ntile && !(MBP_ABL & 64)) {   // (computing the tiles past the last one unconditionally measured 3 % slower)
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
               acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(cc_bf16x8, wf[kk]), __builtin_bit_cast(cc_bf16x8, xr[i][kk]), acc, 0, 0, 0);
             f32x4 o;
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) o[rr] = swishf(acc[rr] * sc0[rr] + sh0[rr]);
+            for (int rr = 0; rr < 4; ++rr) o[rr] = (MBP_ABL & 16) ? acc[rr] * sc0[rr] + sh0[rr] : swishf(acc[rr] * sc0[rr] + sh0[rr]);
             if (dst[i] >= 0) *reinterpret_cast<f32x4*>(pl + dst[i]) = o;
             if (alt[i] >= 0) *reinterpret_cast<f32x4*>(pl + alt[i]) = o;
           }
@@ -447,7 +448,7 @@ __global__ __launch_bounds__(512) void mbconv_band_kernel(const MbBandParams p) 
     const int ct = tid - 256, cwave = wave - 4;
     const int cg = ct % CG;
     const int XG = p.Wo / NOUT;
-    const int nitem = bh * XG;
+    const int nitem = (bh / RY) * XG;               // RY = 2: the host guarantees an even band height
     cc_bf16* yb = p.y + ((size_t)b * p.Ho + oy0) * p.Wo * p.mid + 4 * cg;
     float* sp = p.se_partial + ((size_t)b * p.nbands + band) * p.mid;
     // the parameters of one slice as this thread's share: NKK / 4 .. pieces of the expand weights, one piece of the depthwise
@@ -502,40 +503,66 @@ __global__ __launch_bounds__(512) void mbconv_band_kernel(const MbBandParams p) 
         const f32x4 sc1 = *reinterpret_cast<const f32x4*>(wl + K * K * CH + 4 * cg);
         const f32x4 sh1 = *reinterpret_cast<const f32x4*>(wl + K * K * CH + CH + 4 * cg);
         f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-        for (int it = ct / CG; it < nitem; it += 256 / CG) {
-          const int oyl = (int)(((unsigned)it * p.xg_magic) >> 20);
-          const int ox0 = (it - oyl * XG) * NOUT;
-          const float* trow = pl + ((oyl * S) * p.PWp + ox0 * S) * PITCH + 4 * cg;
-          int wofs = 4 * cg;
-          asm volatile("" : "+v"(wofs));
-          f32x4 acc[NOUT];
+        // an item = RY adjacent output ROWS x NOUT adjacent columns x 4 channels: the (RY - 1) S + K window rows are read once
+        // and feed every output row they belong to (RY = 2, k = 5: 6 x 8 window reads for 8 outputs instead of 2 x 5 x 8 — the
+        // window reads were the largest single cost of this kernel: tools/gpu/ablate_mbplane.sh, 38 of 100 us on block 9)
+        constexpr int NR = (RY - 1) * S + K;
+        f32x4 wr[K * K];
 #pragma unroll
-          for (int t = 0; t < NOUT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < K * K; ++q) wr[q] = *reinterpret_cast<const f32x4*>(wl + q * CH + 4 * cg);
+        for (int it = ct / CG; it < nitem; it += 256 / CG) {
+          const int oyl = RY * (int)(((unsigned)it * p.xg_magic) >> 20);
+          const int ox0 = (it - (oyl / RY) * XG) * NOUT;
+          const float* trow = pl + ((oyl * S) * p.PWp + ox0 * S) * PITCH + 4 * cg;
+          f32x4 acc[RY][NOUT];
+#pragma unroll
+          for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int t = 0; t < NOUT; ++t) acc[r][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          // window row iy + 1 is requested before row iy is accumulated (two register sets).  The depthwise weights are NOT read
+          // inside this loop: LDS returns in order, so a weight read issued behind the next row's window reads — and needed by the
+          // very next FMA — made every row wait for the whole prefetch it was meant to overlap with (4 200 cycles per item for
+          // ~1 500 cycles of issue); they sit in registers for the whole slice (wr[], loaded in front of the item loop)
           f32x4 col[2][NCOL];
 #pragma unroll
-          for (int j = 0; j < NCOL; ++j) col[0][j] = *reinterpret_cast<const f32x4*>(trow + j * PITCH);
+          for (int j = 0; j < NCOL; ++j)
+            col[0][j] = (MBP_ABL & 8) ? (f32x4){1.f, 2.f, 3.f, (float)it} : *reinterpret_cast<const f32x4*>(trow + j * PITCH);
 #pragma unroll
-          for (int ky = 0; ky < K; ++ky) {
-            if (ky + 1 < K) {
+          for (int iy = 0; iy < NR; ++iy) {
+            if (iy + 1 < NR) {
 #pragma unroll
-              for (int j = 0; j < NCOL; ++j) col[(ky + 1) & 1][j] = *reinterpret_cast<const f32x4*>(trow + ((ky + 1) * p.PWp + j) * PITCH);
+              for (int j = 0; j < NCOL; ++j)
+                col[(iy + 1) & 1][j] = (MBP_ABL & 8) ? (f32x4){1.f, 2.f, 3.f, (float)(it + iy)} : *reinterpret_cast<const f32x4*>(trow + ((iy + 1) * p.PWp + j) * PITCH);
             }
 #pragma unroll
-            for (int kx = 0; kx < K; ++kx) {
-              const f32x4 wv = *reinterpret_cast<const f32x4*>(wl + (ky * K + kx) * CH + wofs);
+            for (int r = 0; r < RY; ++r) {
+              const int ky = iy - r * S;               // this window row is kernel row ky of output row r
+              if (ky >= 0 && ky < K) {
 #pragma unroll
-              for (int t = 0; t < NOUT; ++t) acc[t] += col[ky & 1][t * S + kx] * wv;
+                for (int kx = 0; kx < ((MBP_ABL & 4) ? 1 : K); ++kx) {
+                  const f32x4 wv = wr[ky * K + kx];
+#pragma unroll
+                  for (int t = 0; t < NOUT; ++t) acc[r][t] += col[iy & 1][t * S + kx] * wv;
+                }
+              }
+            }
+            if (MBP_ABL & 4) {
+#pragma unroll
+              for (int j = 0; j < NCOL; ++j) acc[0][j % NOUT] += col[iy & 1][j];
             }
             __builtin_amdgcn_sched_barrier(0);
           }
-          cc_bf16* yrow = yb + (size_t)oyl * p.Wo * p.mid + c0;
 #pragma unroll
-          for (int t = 0; t < NOUT; ++t) {
-            f32x4 o = acc[t] * sc1 + sh1;
+          for (int r = 0; r < RY; ++r) {
+            cc_bf16* yrow = yb + (size_t)(oyl + r) * p.Wo * p.mid + c0;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = swishf(o[r]);
-            st4<cc_bf16>(yrow + (size_t)(ox0 + t) * p.mid, o);
-            sum += o;
+            for (int t = 0; t < NOUT; ++t) {
+              f32x4 o = acc[r][t] * sc1 + sh1;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o[q] = (MBP_ABL & 2) ? o[q] : swishf(o[q]);
+              if (!(MBP_ABL & 1)) st4<cc_bf16>(yrow + (size_t)(ox0 + t) * p.mid, o);
+              sum += o;
+            }
           }
         }
 #pragma unroll
@@ -691,16 +718,19 @@ static int mbband_launch(const MbpGeom& g, const void* x, const void* w_exp, int
   struct PitchKey { int k[5]; int pwp; };
   static thread_local PitchKey pk[16];
   static thread_local int pk_used = 0, pk_next = 0;
+  // two output rows per depthwise thread when every band has an even height and the plane is large enough to keep the 256
+  // consumer threads busy (RY x fewer items)
+  const int ry = (tpw > 4 && g.BH % 2 == 0 && Ho % g.BH == 0 && (g.BH / 2) * XG * 4 >= 256) ? 2 : 1;
   int pwp = -1;
   for (int i = 0; i < pk_used; ++i)
-    if (pk[i].k[0] == PW && pk[i].k[1] == XG && pk[i].k[2] == stride && pk[i].k[3] == g.BH && pk[i].k[4] == IH) pwp = pk[i].pwp;
+    if (pk[i].k[0] == PW && pk[i].k[1] == XG && pk[i].k[2] == stride * ry && pk[i].k[3] == g.BH && pk[i].k[4] == IH) pwp = pk[i].pwp;
   if (pwp < 0) {
     int bestc = 1 << 30;
     for (int c = PW; c < PW + 16; ++c) {
-      const int cyc = mbp_read_cycles(4, 20, c, XG, stride, g.BH * XG);
+      const int cyc = mbp_read_cycles(4, 20, c, XG, stride * ry, (g.BH / ry) * XG);
       if (cyc < bestc) { bestc = cyc; pwp = c; }
     }
-    pk[pk_next] = PitchKey{{PW, XG, stride, g.BH, IH}, pwp};
+    pk[pk_next] = PitchKey{{PW, XG, stride * ry, g.BH, IH}, pwp};
     pk_next = (pk_next + 1) % 16;
     if (pk_used < 16) ++pk_used;
   }
@@ -746,12 +776,28 @@ static int mbband_launch(const MbpGeom& g, const void* x, const void* w_exp, int
     hipLaunchKernelGGL(kern, dim3(p.total_blocks), dim3(512), lds, st, p);
     launched = true;
   };
-#define MBB(K_, S_, NKK_, TPW_) if (k == K_ && stride == S_ && nkk == NKK_ && tpw <= TPW_ && !launched && !rc) go(mbconv_band_kernel<K_, S_, NKK_, TPW_>);
-  MBB(3, 1, 3, 10) MBB(5, 1, 3, 10) MBB(3, 1, 4, 10) MBB(5, 1, 4, 10) MBB(5, 2, 3, 10) MBB(5, 2, 4, 10) MBB(3, 1, 6, 4) MBB(5, 1, 6, 4) MBB(5, 2, 6, 4)
+#define MBB(K_, S_, NKK_, TPW_, RY_) if (k == K_ && stride == S_ && nkk == NKK_ && tpw <= TPW_ && ry == RY_ && !launched && !rc) go(mbconv_band_kernel<K_, S_, NKK_, TPW_, RY_>);
+  MBB(3, 1, 3, 10, 2) MBB(5, 1, 3, 10, 2) MBB(3, 1, 4, 10, 2) MBB(5, 1, 4, 10, 2) MBB(5, 2, 3, 10, 2) MBB(5, 2, 4, 10, 2)
+  MBB(3, 1, 3, 10, 1) MBB(5, 1, 3, 10, 1) MBB(3, 1, 4, 10, 1) MBB(5, 1, 4, 10, 1) MBB(5, 2, 3, 10, 1) MBB(5, 2, 4, 10, 1)
+  MBB(3, 1, 6, 4, 1) MBB(5, 1, 6, 4, 1) MBB(5, 2, 6, 4, 1)
 #undef MBB
   if (rc) return rc;
   if (!launched) return -1000;
   return check_launch("mbconv_band_kernel");
+}
+
+bool mbband_takes(int H, int W, int cin, int mid, int k, int stride, int B) {
+  MbpGeom g;
+  if (B <= 0 || !mbp_geometry(H, W, mid, k, stride, &g) || mbplane_nblk(H, W, cin, mid, k, stride) <= 0) return false;
+  const int tp = stride == 1 ? k - 1 : k - 2;
+  const int IH = (g.BH - 1) * stride + k;
+  const int rows = IH < H ? IH : H;
+  const int tpw = ((rows * W + 15) / 16 + 3) / 4;
+  const int nkk = (cin + 31) / 32;
+  if (k == 3 && stride == 2) return false;
+  if (!((tpw <= 10 && (nkk == 3 || nkk == 4)) || (tpw <= 4 && nkk == 6))) return false;
+  (void)tp;
+  return true;                                        // (the launcher re-checks the exact LDS size)
 }
 
 template <typename TE>

@@ -406,7 +406,9 @@ def mbconv_front(x, w_exp, s0, b0, w_dw, s1, b1, mid, k, stride, circular):
     if rec is not None:
         flops = 2.0 * b * h * wd * cin * mid + 2.0 * b * ho * wo * mid * k * k
         nbytes = (4.0 if dt == torch.float32 else 2.0) * (b * h * wd * cin + b * ho * wo * mid)
-        rec.end("mbconv_front_kernel<%d,%d>" % (k, stride), "in %dx%dx%d mid %d" % (h, wd, cin, mid), flops, nbytes, ev0)
+        route = lib.ccvpe_mbconv_front_route(h, wd, cin, mid, k, stride, int(dt != torch.float32), b)
+        kname = {1: "mbconv_front_kernel", 2: "mbconv_plane_kernel", 3: "mbconv_band_kernel"}.get(route, "mbconv_front_kernel")
+        rec.end("%s<%d,%d>" % (kname, k, stride), "in %dx%dx%d mid %d" % (h, wd, cin, mid), flops, nbytes, ev0)
     return y, part
 
 

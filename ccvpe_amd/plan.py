@@ -32,7 +32,7 @@ LAUNCHES = ("ccvpe_conv_igemm_f32", "ccvpe_conv_igemm_bf16", "ccvpe_conv_igemm_s
             "ccvpe_se_gate_f32", "ccvpe_ground_descriptor_f32", "ccvpe_match_level_f32", "ccvpe_match_level_bf16",
             "ccvpe_head_conv3x3_f32", "ccvpe_head_conv3x3_bf16", "ccvpe_softmax_rows_f32", "ccvpe_softmax_apply_f32", "ccvpe_cast_bf16_f32",
             "ccvpe_eval_postprocess_f32")
-QUERIES = ("ccvpe_tail512_partials", "ccvpe_conv3x3_match1_ok", "ccvpe_conv_igemm_splitk_floats", "ccvpe_conv_igemm_route", "ccvpe_upconv3x3_route", "ccvpe_dwconv_nblk", "ccvpe_mbconv_front_nblk", "ccvpe_stem_dw_nblk",
+QUERIES = ("ccvpe_tail512_partials", "ccvpe_conv3x3_match1_ok", "ccvpe_conv_igemm_splitk_floats", "ccvpe_conv_igemm_route", "ccvpe_upconv3x3_route", "ccvpe_dwconv_nblk", "ccvpe_mbconv_front_nblk", "ccvpe_mbconv_front_route", "ccvpe_stem_dw_nblk",
            "ccvpe_last_error", "ccvpe_abi_version")
 
 

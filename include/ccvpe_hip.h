@@ -269,6 +269,9 @@ int ccvpe_stem_dw_bf16(const float* x_nchw, const float* w, const float* s0, con
  *   x [B,H,W,cin], y [B,Ho,Wo,mid], se_partial [B][nblk][mid]
  * ----------------------------------------------------------------------------------------- */
 int ccvpe_mbconv_front_nblk(int in_h, int in_w, int cin, int mid, int k, int stride);
+/* (ABI 7) which kernel the fused call runs for a shape — 0 none (use the unfused calls), 1 mbconv_front_kernel (early blocks),
+ * 2 mbconv_plane_kernel, 3 mbconv_band_kernel (late blocks: planes of <= 1024 pixels; 3 = bf16 storage only).  Reporting only. */
+int ccvpe_mbconv_front_route(int in_h, int in_w, int cin, int mid, int k, int stride, int is_bf16, int batch);
 int ccvpe_mbconv_front_f32(const float* x, const float* w_exp, int kpad, const float* s0, const float* b0,
                            const float* w_dw, const float* s1, const float* b1, float* y, float* se_partial,
                            int batch, int in_h, int in_w, int cin, int mid, int k, int stride, int circular,

@@ -6,7 +6,7 @@
 # masks: 1 no y stores, 2 no output swish, 4 no depthwise FMAs, 8 no window reads, 16 no expand swish, 32 no x loads, 64 no expand
 R=${GRAFT_REPO_ROOT:-$(cd $(dirname $0)/../.. && pwd)}
 cd $R
-MASKS=${MASKS:-0 1 2 4 8 3 15 16 32 64 79}
+MASKS=${MASKS:-0 1 2 4 8 16 64 18 30 94 95}
 if [ "$1" = build ]; then
   mkdir -p gpurun_ab
   cd ccvpe_amd/csrc
@@ -20,5 +20,5 @@ if [ "$1" = build ]; then
 fi
 for m in $MASKS; do
   echo "== mask=$m"
-  CCVPE_LIB=$R/gpurun_ab/libccvpe_mbp_$m.so MBP_FEW=1 python3 tools/mbp_probe.py 20 ${DT:-bf16} ${KB:-72} 2>&1 | grep -v amdgpu.ids
+  CCVPE_LIB=$R/gpurun_ab/libccvpe_mbp_$m.so MBP_FEW=1 MBP_BAND_ONLY=${BAND_ONLY:-} python3 tools/mbp_probe.py 20 ${DT:-bf16} ${KB:-72} 2>&1 | grep -v amdgpu.ids
 done

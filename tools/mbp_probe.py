@@ -59,6 +59,10 @@ for (blk, k, s, cin, mid, h, w, circ) in blocks:
         return ops.mbconv_front(x, we, s0, b0, wd, s1, b1, mid, k, s, circ)
 
     res = []
+    if os.environ.get("MBP_BAND_ONLY"):
+        lib.ccvpe_set_mbconv_plane_kernels(7 | (72 << 8))
+        print("block %2d k%d s%d %3d->%4d %2dx%-2d  band %6.1f" % (blk, k, s, cin, mid, h, w, timed(fused)), flush=True)
+        continue
     lib.ccvpe_set_mbconv_plane_kernels(0)
     res.append(("expand", timed(expand_only)))
     res.append(("chain", timed(chain)))
