@@ -32,7 +32,7 @@ int c3n_supported(const IgemmParams& p, int batch) {
   if (p.Kpad < 32 * nch) return 0;
   const long tiles = (long)batch * (p.H / th) * (p.W / 16);
   if (tiles < 2L * num_cus()) return 0;                        // persistent workgroups: at least two tiles each, or the tiled kernel
-  if ((long)p.in_pixels * p.ld0 * 2 >= (1L << 32)) {}          // (DMA offsets are relative to the tile: always < 4 GB)
+  // (no size limit on the tensor: the DMA offsets are relative to the tile's first pixel, always < 4 GB)
   return id;
 }
 

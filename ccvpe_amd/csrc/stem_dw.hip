@@ -159,7 +159,11 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const float* __restrict
   // ---- depthwise weights and BN1 of this lane's 4 channels -------------------------------------------------------------------
   const int cg = lane & 7, orow = lane >> 3;           // channel group, output row of the tile
   for (int i = tid; i < 9 * 32; i += 256) wdl[i] = wdw[i];
-  const float* wdc = wdl + cg * 4;
+  // the nine depthwise weight vectors of this lane's channels live in registers for the whole (persistent) kernel: read from LDS
+  // inside the tile loop they sat behind the window reads in the in-order LDS return queue (round 6, see csrc/mbconv_plane.hip)
+  sd_f32x4 wreg[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) wreg[i] = *reinterpret_cast<const sd_f32x4*>(wdw + i * 32 + cg * 4);
   const sd_f32x4 sc1 = *reinterpret_cast<const sd_f32x4*>(s1 + cg * 4);
   const sd_f32x4 sh1 = *reinterpret_cast<const sd_f32x4*>(b1 + cg * 4);
   const float* trow = tile + (orow * SD_RP + 8 * wave) * SD_PP + cg * 4;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void stem_dw_kernel(const float* __restrict
         for (int j = 0; j < 10; ++j) col[j] = *reinterpret_cast<const sd_f32x4*>(trow + (ky * SD_RP + j) * SD_PP);
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
-          const sd_f32x4 wv = *reinterpret_cast<const sd_f32x4*>(wdc + (ky * 3 + kx) * 32);
+          const sd_f32x4 wv = wreg[ky * 3 + kx];
 #pragma unroll
           for (int t = 0; t < 8; ++t) acc[t] += col[t + kx] * wv;
         }
