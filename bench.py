@@ -877,6 +877,10 @@ def main():
                     line["config"].update(compact(tag, legs[tag]))
                     emit_leg_details(tag, legs[tag])
             line["config"].update(coll_flat)
+            # the counters' view of each leg goes LAST (the driver keeps the first 24 scalars: at N > 1 the legs + collective_* are
+            # exactly 24, and these must not push them out)
+            for k in [k for k in line["config"] if k.endswith("_hbm_util")]:
+                line["config"][k] = line["config"].pop(k)
             # the literal BASELINE metric's dominant kernel, flat, beside the headline's roofline (nested objects are dropped)
             fb = (legs.get("fwd_bwd_vigor_b64") or {}).get("roofline") or {}
             if fb.get("kernel"):
@@ -884,6 +888,10 @@ def main():
                                          "fwd_bwd_kernel_frac": fb.get("frac"), "fwd_bwd_kernel_avg_launch_ms": fb.get("avg_launch_ms"),
                                          "fwd_bwd_kernel_traffic": fb.get("traffic")})
     if rank == 0:
+        ws = (line.get("roofline") or {}).get("whole_step") or {}
+        if ws.get("hbm_util") is not None:          # flat copy (the driver's record drops nested objects)
+            line["roofline"].update({"whole_step_frac": ws.get("frac"), "whole_step_pmc_gb": ws.get("pmc_gb_per_step"),
+                                     "whole_step_hbm_util": ws.get("hbm_util")})
         print(json.dumps(line))
         sys.stdout.flush()
     if failed:
