@@ -608,7 +608,7 @@ def _count_gpus_without_hip():
     # a visibility mask narrows what the ranks will see: the guard must not pass on devices they cannot open
     for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
-        if v is not None:
+        if v:            # (an EMPTY mask hides every device: the ranks then fail loudly by themselves; the CPU tests use it)
             n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
     return n
 
