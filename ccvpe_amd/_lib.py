@@ -81,6 +81,7 @@ PROTOTYPES = {
     "ccvpe_set_mbconv_plane_kernels": (c_int, [c_int]),
     "ccvpe_mbconv_front_route": (c_int, [c_int] * 8),
     "ccvpe_set_match_mfma": (c_int, [c_int]),
+    "ccvpe_set_pwn_kernels": (c_int, [c_int]),
     "ccvpe_conv3x3_match1_ok": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_int]),
     "ccvpe_conv3x3_match1_bf16": (c_int, [ctypes.POINTER(ConvDesc), c_int, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "ccvpe_conv_igemm_splitk_f32": (c_int, [ctypes.POINTER(ConvDesc), c_void_p, c_void_p]),
@@ -212,6 +213,8 @@ def load():
         lib.ccvpe_set_pw_ring_kernels(0)          # A/B runs: pw_gemm_kernel for every pointwise layer
     if os.environ.get("CCVPE_MATCH_MFMA") == "0" and hasattr(lib, "ccvpe_set_match_mfma"):
         lib.ccvpe_set_match_mfma(0)               # A/B runs: the vector-ALU matching kernel for every configuration
+    if os.environ.get("CCVPE_PWN") == "0" and hasattr(lib, "ccvpe_set_pwn_kernels"):
+        lib.ccvpe_set_pwn_kernels(0)              # A/B runs: the generic kernel for the narrow projections
     if os.environ.get("CCVPE_MBPLANE") is not None and hasattr(lib, "ccvpe_set_mbconv_plane_kernels"):
         lib.ccvpe_set_mbconv_plane_kernels(int(os.environ["CCVPE_MBPLANE"]))   # A/B runs: 0 = pointwise GEMM + dwconv_plane_kernel
     _lib = lib

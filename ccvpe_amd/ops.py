@@ -73,7 +73,7 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-ROUTE_FAMILIES = {0: "igemm", 1: "pw_gemm", 2: "conv3x3", 3: "c3n", 4: "pw_ring"}
+ROUTE_FAMILIES = {0: "igemm", 1: "pw_gemm", 2: "conv3x3", 3: "c3n", 4: "pw_ring", 5: "pwn"}
 
 
 def conv_route(desc, is_bf16, out_f32=False):

@@ -102,6 +102,7 @@ int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* desc, int is_bf16);
 #define CCVPE_ROUTE_CONV3X3 2 /* LDS-halo 3x3 kernel */
 #define CCVPE_ROUTE_C3N 3     /* bf16 narrow 3x3 kernel: weights in registers, persistent workgroups (csrc/narrow_impl.h) */
 #define CCVPE_ROUTE_PW_RING 4 /* pointwise kernel with a three-stage LDS-DMA ring, two workgroups per CU, fp32 and bf16 (csrc/conv_pw2_impl.h) */
+#define CCVPE_ROUTE_PWN 5     /* (ABI 7) bf16 narrow projection kernel: N <= 48, K <= 256, weights x SE gate in registers, waves stream 16-pixel tiles (csrc/pwn_bf16.hip); the route's MT / NT fields hold N / 16 and K / 32 */
 int ccvpe_conv_igemm_route(const ccvpe_conv_desc* desc, int is_bf16, int out_f32);
 /* A/B switch for measurements (process-wide, default on): 0 sends the narrow bf16 decoder layers (CCVPE_ROUTE_C3N, and the
  * narrow form of ccvpe_upconv3x3_bf16) back to the tiled kernels.  Returns the previous setting. */
@@ -109,6 +110,8 @@ int ccvpe_set_narrow_kernels(int on);
 /* The same kind of switch for CCVPE_ROUTE_PW_RING: 0 sends those fp32 pointwise layers back to CCVPE_ROUTE_PW_GEMM (bit-identical
  * results either way).  Returns the previous setting. */
 int ccvpe_set_pw_ring_kernels(int on);
+/* (ABI 7) The same kind of switch for CCVPE_ROUTE_PWN: 0 sends the narrow bf16 projections back to the generic kernel. */
+int ccvpe_set_pwn_kernels(int on);
 /* (ABI 7) The same kind of switch for the late-block MBConv front (csrc/mbconv_plane.hip: planes of <= 1024 pixels, Cin in
  * {80, 112, 192}), which runs behind the UNCHANGED ccvpe_mbconv_front_* / ccvpe_dwconv_* entry points and their *_nblk queries:
  * bit 0 = the fused expand + depthwise form (ccvpe_mbconv_front_nblk reports it), bit 1 = the depthwise-only form

@@ -117,6 +117,43 @@ def test_mbconv_plane_late_blocks_bf16(ops, k, s, cin, h, w, circ):
     close(part2.sum(1), want2.sum(dim=(2, 3)), 2e-3, "squeeze partials (depthwise form)")
 
 
+@pytest.mark.parametrize("cin,cout,b,hw,with_res", [(32, 16, 1, 256, False), (96, 24, 4, 128, False), (144, 24, 4, 128, True),
+                                                     (144, 40, 16, 64, False), (240, 40, 17, 64, True), (96, 24, 3, 160, False)])
+def test_narrow_projection_kernel(ops, cin, cout, b, hw, with_res):
+    """The MBConv projections of the early blocks (efficientnet_pytorch/model.py:118-131: SE gate on the input, 1x1 conv, BN, skip)
+    on the streaming kernel with the weights x gate in registers (csrc/pwn_bf16.hip, route CCVPE_ROUTE_PWN) behind the unchanged
+    ccvpe_conv_igemm_bf16: against the fp32 oracle on bf16-rounded inputs, and against the generic kernel (switch off).  A wave's run
+    of tiles crosses sample boundaries (B = 17: per-sample gates are re-folded), the last tile is ragged (160 x 160 x 3 pixels)."""
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    w_ = hw if hw != 160 else 137                      # 160 x 137 x 3 = 65 760 pixels: not a multiple of 16 per sample -> ungated case only
+    gated = (hw * w_) % 16 == 0
+    x = r(synth.normal((b, cin, hw, w_), 900 + cin))
+    wt = r(synth.normal((cout, cin, 1, 1), 901 + cout, (1.0 / cin) ** 0.5))
+    sc, sh = synth.uniform((cout,), 902, 0.5, 1.5), synth.normal((cout,), 903, 0.1)
+    gate = synth.uniform((b, cin), 904, 0.1, 1.0) if gated else None
+    res = r(synth.normal((b, cout, hw, w_), 905)) if with_res else None
+    xin = x * gate.view(b, cin, 1, 1) if gated else x
+    want = F.conv2d(xin, wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if with_res:
+        want = want + res
+    f32 = torch.float32
+    kw = dict(batch=b, in_h=hw, in_w=w_, scale=dev(sc, f32), shift=dev(sh, f32), gate=dev(gate, f32) if gated else None,
+              residual=dev(nhwc(res)) if with_res else None)
+    xd, wd = dev(nhwc(x)), dev(pack(wt))
+    assert ops.conv_igemm(xd, cin, wd, cout, route_only=True, **kw)[0] == "pwn"
+    got = ops.conv_igemm(xd, cin, wd, cout, **kw)
+    assert got.dtype == BF
+    close(nchw(got), want, 1e-2, "narrow projection %d->%d" % (cin, cout))
+    prev = lib.ccvpe_set_pwn_kernels(0)
+    try:
+        assert ops.conv_igemm(xd, cin, wd, cout, route_only=True, **kw)[0] == "igemm"
+        ref = ops.conv_igemm(xd, cin, wd, cout, **kw)
+    finally:
+        lib.ccvpe_set_pwn_kernels(prev)
+    close(got, ref.float().cpu(), 8e-3, "streaming kernel vs generic kernel (the gate is folded into W instead of x: one bf16 rounding elsewhere)")
+
+
 def test_igemm_bf16_gate_residual(ops):
     b, h, w, cin, cout = 3, 7, 10, 96, 24
     x = r(synth.normal((b, cin, h, w), 1))
