@@ -391,6 +391,163 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Streaming form for the NARROW levels (C <= 80: the 128 x 128 and 256 x 256 levels, where almost all of the matching's bytes are),
+// 9 <= N_rot <= 32, no tail scores.  The tiled kernel above runs three phases per workgroup in series (tile in -> product -> rows
+// out) and reaches 3.1-3.6 TB/s there; with C this small a pixel's whole channel vector fits a few registers, so — as in
+// csrc/pwn_bf16.hip — every WAVE streams its own contiguous run of 16-pixel tiles with no LDS and no barrier: x pieces come from
+// global memory straight in MFMA B layout (lane = pixel l & 15, channels 16 blk + 4 (l >> 4) .. + 3), PF tiles ahead; the circulant A
+// fragments of the current sample's ground descriptor (and the 0/1 window table for partial windows) are built in registers from g
+// itself (any offset parity) and rebuilt when the run reaches the next sample; |x|^2 by two cross-lane adds; scores / max as in the
+// tiled kernel; the normalised row, the max column and the zero padding leave from the registers that hold x.
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MatchStreamParams {
+  const void* x;
+  const float* g;
+  float* scores;
+  void* dstx;
+  MatchOffsets mo;
+  int ldx, ldg, L, n_shifts, n_max, ldo, hw, C, tiles, tpw;
+};
+
+template <typename TX, int MTL, bool PARTIAL, int NB>
+__global__ __launch_bounds__(256) void match_stream_kernel(const MatchStreamParams p) {
+  constexpr int PF = NB >= 4 ? 2 : 3;                // x register sets (tiles in flight)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int pxl = lane & 15, kq = lane >> 4;
+  // a workgroup owns a contiguous run of 4 tpw tiles and its four waves take them INTERLEAVED (tile = run start + 4 k + wave): the
+  // 64-byte pieces the four waves store into one NCHW score row at about the same time are one 256-byte run (L2 merges them)
+  constexpr int TS = 4;
+  const int t0 = blockIdx.x * 4 * p.tpw + (tid >> 6);
+  const int t1 = min((int)(blockIdx.x + 1) * 4 * p.tpw, p.tiles);
+  if (t0 >= t1) return;
+  const TX* x = reinterpret_cast<const TX*>(p.x);
+  TX* dstx = reinterpret_cast<TX*>(p.dstx);
+  const int C = p.C, L = p.L;
+  const int tiles_per_sample = p.hw >> 4;
+
+  // this lane's table offsets as a hypothesis ROW (A operand: row = lane & 15 of tile m)
+  int roff[MTL];
+#pragma unroll
+  for (int m = 0; m < MTL; ++m) {
+    int o = p.mo.off[0];
+#pragma unroll
+    for (int i = 1; i < 16; ++i)
+      if (16 * m + i < CCVPE_MAX_SHIFTS) o = (pxl == i && 16 * m + i < p.n_shifts) ? p.mo.off[16 * m + i] : o;
+    if (m > 0 && 16 * m < CCVPE_MAX_SHIFTS) o = (pxl == 0 && 16 * m < p.n_shifts) ? p.mo.off[16 * m] : o;
+    roff[m] = o;
+  }
+  f32x4 ga[MTL][NB], wa[PARTIAL ? MTL : 1][PARTIAL ? NB : 1];
+  float gnorm = 1.f;
+  auto load_tables = [&](int b) {
+    const float* gb = p.g + (size_t)b * p.ldg;
+    float gsq = 0.f;
+    for (int k = lane; k < L; k += 64) gsq = fmaf(gb[k], gb[k], gsq);
+    gnorm = sqrtf(wave_sum(gsq));
+#pragma unroll
+    for (int m = 0; m < MTL; ++m)
+#pragma unroll
+      for (int blk = 0; blk < NB; ++blk) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int k = 16 * blk + 4 * kq + j + roff[m];   // index into the doubled table gg[k] = g_ext[k mod C]
+          k = k >= C ? k - C : k;
+          k = k >= C ? k - C : k;                    // (pad channels of the last block: k < 2C + 16)
+          const float gv = gb[min(k, L - 1)];
+          ga[m][blk][j] = k < L ? gv : 0.f;
+          if (PARTIAL) wa[PARTIAL ? m : 0][PARTIAL ? blk : 0][j] = k < L ? 1.f : 0.f;
+        }
+      }
+  };
+  int cur_b = t0 / tiles_per_sample;
+  load_tables(cur_b);
+
+  f32x4 xf[PF][NB];
+  auto load_tile = [&](int s, int t) {
+    const size_t pi = (size_t)(t < t1 ? t : t0) * 16 + pxl;          // (past the run: a valid re-read, never used)
+    const TX* src = x + pi * p.ldx + 4 * kq;
+#pragma unroll
+    for (int blk = 0; blk < NB; ++blk) {
+      const bool in = 16 * blk + 4 * kq < C;          // pad channels of the last block (C % 16 = 8): zero
+      const f32x4 v = ld4<TX>(src + (in ? 16 * blk : 0));
+      xf[s][blk] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < PF - 1; ++s) load_tile(s, t0 + TS * s);
+
+  for (int t = t0; t < t1; t += TS * PF) {
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+      const int tt = t + TS * s;
+      if (tt < t1) {                                  // wave-uniform
+        load_tile((s + PF - 1) % PF, tt + TS * (PF - 1));
+        const int b = tt / tiles_per_sample;
+        if (b != cur_b) {                             // wave-uniform: next sample's descriptor
+          cur_b = b;
+          load_tables(b);
+        }
+        f32x4 acc[MTL], nrm[PARTIAL ? MTL : 1];
+#pragma unroll
+        for (int m = 0; m < MTL; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int m = 0; m < (PARTIAL ? MTL : 1); ++m) nrm[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        float tot = 0.f;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk) {
+          const f32x4 xq = xf[s][blk];
+          f32x4 x2;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { x2[j] = xq[j] * xq[j]; tot += x2[j]; }
+#pragma unroll
+          for (int m = 0; m < MTL; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ga[m][blk][j], xq[j], acc[m], 0, 0, 0);
+            if (PARTIAL) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                nrm[PARTIAL ? m : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[PARTIAL ? m : 0][PARTIAL ? blk : 0][j], x2[j], nrm[PARTIAL ? m : 0], 0, 0, 0);
+            }
+          }
+        }
+        tot += __shfl_xor(tot, 16, 64);
+        tot += __shfl_xor(tot, 32, 64);
+        const size_t pi = (size_t)tt * 16 + pxl;      // global pixel index (all samples); hw % 16 == 0: the tile is inside sample b
+        const size_t pin = pi - (size_t)b * p.hw;     // pixel inside the sample
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int m = 0; m < MTL; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = 16 * m + 4 * kq + r;
+            if (i < p.n_shifts) {
+              const float wn = sqrtf(PARTIAL ? nrm[PARTIAL ? m : 0][r] : tot);
+              const float sv = acc[m][r] / (wn * gnorm);
+              p.scores[((size_t)b * p.n_shifts + i) * p.hw + pin] = sv;
+              if (i < p.n_max && (sv > mx || sv != sv)) mx = sv;
+            }
+          }
+#pragma unroll
+        for (int o = 16; o < 64; o <<= 1) {
+          const float other = __shfl_xor(mx, o, 64);
+          mx = (other > mx || other != other) ? other : mx;
+        }
+        const float inv = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+        TX* drow = dstx + pi * p.ldo + 4 * kq;
+#pragma unroll
+        for (int blk = 0; blk < NB; ++blk)
+          if (16 * blk + 4 * kq < C) st4<TX>(drow + 16 * blk, xf[s][blk] * inv);
+        // [max | zero padding]: ldo - C floats in 16-byte pieces, piece e written by the lane with kq == e & 3
+        const int extra = (p.ldo - C) >> 2;
+        for (int e = kq; e < extra; e += 4)
+          st4<TX>(dstx + pi * p.ldo + C + 4 * e, (f32x4){e == 0 ? mx : 0.f, 0.f, 0.f, 0.f});
+      }
+    }
+  }
+}
+
+int num_cus();   // narrow_bf16.hip
+
 }  // namespace ccvpe
 
 using namespace ccvpe;
@@ -422,7 +579,7 @@ static int launch_match(const TX* x, int ldx, const float* g, int ldg, int L, co
   return check_launch("match_kernel");
 }
 
-static int g_match_mfma = 1;
+static int g_match_mfma = 2;   // 0 vector-ALU form everywhere, 1 + the tiled matrix-core form, 2 + the streaming form of the narrow levels
 
 template <typename TX>
 static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const int* shifts, int n_shifts, int n_max,
@@ -451,6 +608,26 @@ static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const
   }
   hipStream_t st = (hipStream_t)stream;
 #define M_ARGS x, ldx, g, ldg, L, mo, n_shifts, n_max, n_tail, scores, dstx, ldo, B, hw, C, st
+  // narrow levels with many hypotheses: every wave streams its own run of 16-pixel tiles (no LDS tile, no barriers)
+  if (g_match_mfma >= 2 && n_shifts >= 9 && n_shifts <= 32 && n_tail == 0 && C <= 80 && hw % 16 == 0 && (long)B * hw >= 65536 &&
+      ldo - C <= 64 && (sizeof(TX) == 4 || ldo % 4 == 0)) {
+    MatchStreamParams q;
+    q.x = x; q.g = g; q.scores = scores; q.dstx = dstx; q.mo = mo;
+    q.ldx = ldx; q.ldg = ldg; q.L = L; q.n_shifts = n_shifts; q.n_max = n_max; q.ldo = ldo; q.hw = hw; q.C = C;
+    q.tiles = (int)((long)B * hw / 16);
+    const int waves = 2 * num_cus() * 4;
+    q.tpw = (q.tiles + waves - 1) / waves;
+    const int wgs = ((q.tiles + q.tpw - 1) / q.tpw + 3) / 4;
+    const int nb = (C + 15) / 16;
+#define MS_GO(MTL_, P_, NB_) hipLaunchKernelGGL((match_stream_kernel<TX, MTL_, P_, NB_>), dim3(wgs), dim3(256), 0, st, q)
+#define MS_NB(MTL_, P_) \
+    if (nb <= 2) MS_GO(MTL_, P_, 2); else if (nb == 3) MS_GO(MTL_, P_, 3); else if (nb == 4) MS_GO(MTL_, P_, 4); else MS_GO(MTL_, P_, 5)
+    if (n_shifts <= 16) { if (partial) { MS_NB(1, true); } else { MS_NB(1, false); } }
+    else { if (partial) { MS_NB(2, true); } else { MS_NB(2, false); } }
+#undef MS_NB
+#undef MS_GO
+    return check_launch("match_stream_kernel");
+  }
   if (g_match_mfma && n_shifts >= 9 && n_shifts <= 32 && vec >= 2) {       // many hypotheses: the circulant product on the matrix cores
 #define M_MFMA(NP)                                                          \
     if (partial) {                                                          \
@@ -482,7 +659,7 @@ static int match_any(const TX* x, int ldx, const float* g, int ldg, int L, const
 
 extern "C" int ccvpe_set_match_mfma(int on) {
   const int old = g_match_mfma;
-  g_match_mfma = on ? 1 : 0;
+  g_match_mfma = on < 0 ? 0 : (on > 2 ? 2 : on);
   return old;
 }
 

@@ -297,7 +297,8 @@ int ccvpe_ground_descriptor_f32(const float* y1, int ld, const float* wh, const 
 
 /* (ABI 7) A/B switch of the matrix-core form of ccvpe_match_level_* (9 <= n_shifts <= 32, even table offsets: the circulant
  * [n_shifts x C] of the ground descriptor times the [C x pixels] tile as v_mfma_f32_16x16x4_f32, exact fp32).  0 = the vector-ALU
- * form for every configuration.  Returns the previous setting. */
+ * form for every configuration, 1 = the tiled matrix-core form, 2 (default) = additionally the streaming form of the narrow levels
+ * (C <= 80, no tail scores, >= 65 536 pixels: every wave streams 16-pixel tiles, no LDS).  Returns the previous setting. */
 int ccvpe_set_match_mfma(int on);
 /* -------------------------------------------------------------------------------------------
  * Rotational matching + LMU concat, fused (models.py:186-205 and the five blocks after it;

@@ -737,6 +737,51 @@ def test_match_level_matrix_core_form(ops, C, L, stride, hw, nsh, n_tail):
     close(cat, cat2.cpu(), 4e-6, "concat rows, both forms")
 
 
+@pytest.mark.parametrize("C,L,stride,side,nsh,b,bf16", [(40, 40, 2, 256, 20, 1, False), (40, 20, 2, 256, 21, 1, False), (80, 80, 4, 128, 20, 4, False),
+                                                          (80, 40, 4, 128, 16, 5, False), (48, 48, 4, 192, 11, 2, False), (64, 64, 4, 144, 9, 4, False),
+                                                          (40, 40, 2, 256, 20, 2, True), (80, 40, 4, 128, 21, 4, True), (40, 40, 3, 256, 20, 1, False)])
+def test_match_level_streaming_form(ops, C, L, stride, side, nsh, b, bf16):
+    """The narrow levels (C <= 80, >= 65 536 pixels, no tail scores) as a streaming kernel: every wave walks its own run of 16-pixel
+    tiles, x straight from global memory in MFMA layout, the circulant fragments of the sample's descriptor rebuilt in registers at
+    sample boundaries (match_stream_kernel).  Against the oracle and against the tiled matrix-core form (switch = 1); odd offsets
+    (stride 3) are served too — the fragments are built element by element."""
+    from ccvpe_amd import _lib
+    lib = _lib.load()
+    shifts = list(range(-(nsh // 2), nsh - nsh // 2)) if L < C else list(range(nsh))
+    x = synth.normal((b, C, side, side), 270 + C)
+    g = synth.normal((b, L + 3), 271 + L)
+    if bf16:
+        x = x.to(torch.bfloat16).float()
+    xd = dev(nhwc(x)).to(torch.bfloat16) if bf16 else dev(nhwc(x))
+    ldo = (C + 1 + 7) // 8 * 8
+    sc, cat = ops.match_level(xd, dev(g)[:, :L], L, shifts, nsh, 0, stride, ldo)
+    want = O.rotational_matching(x, g[:, :L], shifts, stride)
+    close(sc, want, 2e-5, "scores (streaming form)")
+    catc = nchw(cat.float()).cpu()
+    tol = 1e-2 if bf16 else 1e-5
+    close(catc[:, :C], F.normalize(x, p=2, dim=1), tol, "normalised features")
+    close(catc[:, C], want.max(dim=1)[0], 1e-2 if bf16 else 2e-5, "max over rotations")
+    assert (catc[:, C + 1:] == 0).all()
+    prev = lib.ccvpe_set_match_mfma(1)
+    try:
+        sc2, cat2 = ops.match_level(xd, dev(g)[:, :L], L, shifts, nsh, 0, stride, ldo)
+    finally:
+        lib.ccvpe_set_match_mfma(prev)
+    close(sc, sc2.cpu(), 4e-6, "streaming form vs tiled form")
+    close(cat.float(), cat2.float().cpu(), 1e-2 if bf16 else 4e-6, "concat rows, both forms")
+
+
+def test_match_level_streaming_form_propagates_nan_like_torch_max(ops):
+    b, C, side = 1, 40, 256
+    x = synth.normal((b, C, side, side), 290)
+    x[:, :, 100, 37] = 0.0
+    g = synth.normal((b, C), 291)
+    shifts = list(range(20))
+    sc, cat = ops.match_level(dev(nhwc(x)), dev(g), C, shifts, 20, 0, 2, 48)
+    assert not torch.isfinite(sc[0, :, 100, 37]).any() and not torch.isfinite(nchw(cat)[0, C, 100, 37])
+    assert torch.isfinite(sc[0, :, 100, 36]).all() and (nchw(cat)[0, :C, 100, 37] == 0).all()
+
+
 def test_match_level_matrix_core_form_propagates_nan_like_torch_max(ops):
     """A zero-norm window (models.py:196 has no eps) makes that hypothesis NaN; torch.max over the stack then returns NaN."""
     b, C, hw = 1, 40, 8

@@ -34,7 +34,7 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-tot = [0.0, 0.0]
+tot = [0.0, 0.0, 0.0]
 for (label, b, c, L, st, hw, nsh, dt) in cases:
     x = torch.randn((b, hw, hw, c), device="cuda").to(dt)
     g = torch.randn((b, L), device="cuda")
@@ -45,10 +45,13 @@ for (label, b, c, L, st, hw, nsh, dt) in cases:
     t0 = timed(fn)
     lib.ccvpe_set_match_mfma(1)
     t1 = timed(fn)
+    lib.ccvpe_set_match_mfma(2)
+    t2 = timed(fn)
     esz = 2 if dt == BF else 4
     nbytes = b * hw * hw * (esz * c + esz * ldo + 4 * nsh)
     tot[0] += t0
     tot[1] += t1
-    print("%-8s B%-3d C%-4d L%-4d %3dx%-3d n%-2d %s  valu %7.1f us (%4.2f TB/s)   mfma %7.1f us (%4.2f TB/s)" % (
-        label, b, c, L, hw, hw, nsh, "bf16" if dt == BF else "fp32", t0, nbytes / t0 / 1e6, t1, nbytes / t1 / 1e6), flush=True)
-print("sum: valu %.0f us, mfma %.0f us" % tuple(tot))
+    tot[2] += t2
+    print("%-8s B%-3d C%-4d L%-4d %3dx%-3d n%-2d %s  valu %7.1f us (%4.2f TB/s)   mfma tiled %7.1f us (%4.2f TB/s)   + streaming %7.1f us (%4.2f TB/s)" % (
+        label, b, c, L, hw, hw, nsh, "bf16" if dt == BF else "fp32", t0, nbytes / t0 / 1e6, t1, nbytes / t1 / 1e6, t2, nbytes / t2 / 1e6), flush=True)
+print("sum: valu %.0f us, mfma tiled %.0f us, with the streaming form of the narrow levels %.0f us" % tuple(tot))
