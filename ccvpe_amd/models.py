@@ -150,8 +150,14 @@ _UP_R = {0: (1, 2), 1: (0, 1, 2), 2: (0, 1)}      # 3x3 taps inside the image fo
 _OVERLAP_ENV = __import__("os").environ.get("CCVPE_OVERLAP_DECODERS", "auto")
 
 
-def _overlap_decoders(precision):
-    return _OVERLAP_ENV == "1" or (_OVERLAP_ENV == "auto" and precision == "bf16")
+# Round 6, same-box A/B (bf16, ms per forward, decoders on two streams / on one): B = 32 (C2) 4.97 / 5.25, B = 64 (C1) 8.47 / 8.54, but
+# B = 256 (C4, hipGraph replay) 34.5 / 32.8 and eager 34.1 / 32.8 — at that size every decoder kernel fills the chip by itself and
+# two of them only fight over L2 / the Infinity Cache.  (The two ENCODERS on two streams pay at every size measured.)
+OVERLAP_DECODERS_MAX_BATCH = 128
+
+
+def _overlap_decoders(precision, batch=1):
+    return _OVERLAP_ENV == "1" or (_OVERLAP_ENV == "auto" and precision == "bf16" and batch <= OVERLAP_DECODERS_MAX_BATCH)
 FOLD_LEVELS = tuple(int(c) for c in __import__("os").environ.get("CCVPE_FOLD_LEVELS", "012345"))
 # Below this many low-res pixels (batch * h * w) the folded GEMM has too few output tiles to fill the chip and walks
 # K = 4*c0 + 9*c1 serially (B = 8, level 6: 2 x 1.05 ms at 20 TF/s); the unfused pair goes through the split-K igemm
@@ -648,7 +654,7 @@ class _CVMBase(nn.Module):
             sdesc = ops.conv_igemm(svol, 1280, pk.sd_w, pk.sd_n, batch=batch, in_h=svol.shape[1],
                                    in_w=svol.shape[2], kh=2, kw=2, stride=2, shift=pk.sd_bias)
 
-            overlap = _overlap_decoders(self.precision)
+            overlap = _overlap_decoders(self.precision, batch)
             loc_shifts = self._loc_shifts()
             fused = None
             scores_out = []
