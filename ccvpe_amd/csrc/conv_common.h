@@ -279,10 +279,10 @@ int c3n_supported(const IgemmParams& p, int batch);      // 0 = not served, else
 int c3n_dispatch(const IgemmParams& p, int batch, hipStream_t stream);
 int c3n_match_supported(const IgemmParams& p, int batch, int L);
 int c3n_match_dispatch(const IgemmParams& p, int batch, const float* g, int ldg, int L, int off, float* scores, hipStream_t stream);
-// pwn_bf16.hip: bf16 1x1 projections with N <= 48 and K <= 256 on large planes — weights (x SE gate) resident in registers, waves stream tiles
+// pwn.hip: 1x1 projections with N <= 48 and K <= 256 (fp32: <= 144) on large planes — weights (x SE gate) resident in registers, waves stream tiles
 extern bool g_use_pwn;                                    // ccvpe_set_pwn_kernels
-bool pwn_supported(const IgemmParams& p, int batch);
-int pwn_dispatch(const IgemmParams& p, int batch, hipStream_t stream);
+bool pwn_supported(const IgemmParams& p, int batch, int esz);
+int pwn_dispatch(const IgemmParams& p, int batch, int esz, hipStream_t stream);
 int up2_supported(int c0, int c1, int n, int kpad, int h1, int w1, int batch);
 int up2_dispatch(const void* src0, const void* src1, const void* w, const float* shift9, void* dst, int c0, int ld0, int c1, int ld1,
                  int h1, int w1, int n, int kpad, int ldd, int act, int batch, hipStream_t stream);

@@ -446,15 +446,13 @@ static int conv_igemm_any(const ccvpe_conv_desc* d, void* stream, int out_f32, f
   }
   // the 256 x 80 tile needs more than 256 VGPRs in the persistent pointwise kernel (staging registers live across the
   // epilogue): N = 65..80 pointwise layers take the 128 x 96 tile there
-  // bf16 projections with N <= 48 and K <= 256 on large planes: the streaming kernel with the weights (x SE gate) in registers
-  if constexpr (sizeof(T) == 2) {
-    if (!scratch && !mf && pwn_supported(p, d->batch)) {
-      if (route) {
-        *route = CCVPE_ROUTE_PWN | ((p.Npad / 16) << 8) | ((p.Kpad / 32) << 12);
-        return CCVPE_OK;
-      }
-      if (!want_floats) return pwn_dispatch(p, d->batch, st);
+  // projections with N <= 48 and K <= 256 (fp32: 144) on large planes: the streaming kernel with the weights (x SE gate) in registers
+  if (!scratch && !mf && pwn_supported(p, d->batch, (int)sizeof(T))) {
+    if (route) {
+      *route = CCVPE_ROUTE_PWN | ((p.Npad / 16) << 8) | (((p.Kpad * (int)sizeof(T)) / 64) << 12);
+      return CCVPE_OK;
     }
+    if (!want_floats) return pwn_dispatch(p, d->batch, (int)sizeof(T), st);
   }
   if (route) {
     const bool pw_tile = 16 * c.nt * c.wn > 48;      // (the 256 x 80 tile is re-routed to 128 x 96 below)

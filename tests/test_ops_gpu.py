@@ -655,6 +655,39 @@ def test_mbconv_blocks_golden_fused_front(ops, circ, synth_sd):
     assert n >= 3
 
 
+@pytest.mark.parametrize("cin,cout,b,hw,with_res", [(32, 16, 1, 256, False), (96, 24, 4, 128, False), (144, 24, 5, 128, True), (144, 40, 17, 64, False)])
+def test_narrow_projection_kernel_fp32(ops, cin, cout, b, hw, with_res):
+    """fp32 storage of csrc/pwn.hip (route CCVPE_ROUTE_PWN behind ccvpe_conv_igemm_f32): the early-block MBConv projections
+    (efficientnet_pytorch/model.py:118-131) with the weights x SE gate in registers, exact fp32 matrix instructions — against the
+    oracle and against the generic kernel (switch off).  240 -> 40 keeps the generic kernel in fp32 (registers)."""
+    from ccvpe_amd import _lib
+    from ccvpe_amd.models import _pack_conv
+    lib = _lib.load()
+    x = synth.normal((b, cin, hw, hw), 910 + cin)
+    wt = synth.normal((cout, cin, 1, 1), 911 + cout, (1.0 / cin) ** 0.5)
+    sc, sh = synth.uniform((cout,), 912, 0.5, 1.5), synth.normal((cout,), 913, 0.1)
+    gate = synth.uniform((b, cin), 914, 0.1, 1.0)
+    res = synth.normal((b, cout, hw, hw), 915) if with_res else None
+    want = F.conv2d(x * gate.view(b, cin, 1, 1), wt) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    if with_res:
+        want = want + res
+    kw = dict(batch=b, in_h=hw, in_w=hw, scale=dev(sc), shift=dev(sh), gate=dev(gate), residual=dev(nhwc(res)) if with_res else None)
+    xd, wd = dev(nhwc(x)), dev(_pack_conv(wt))
+    assert ops.conv_igemm(xd, cin, wd, cout, route_only=True, **kw)[0] == "pwn"
+    got = ops.conv_igemm(xd, cin, wd, cout, **kw)
+    close(nchw(got), want, 1e-5, "narrow projection fp32 %d->%d" % (cin, cout))
+    prev = lib.ccvpe_set_pwn_kernels(0)
+    try:
+        ref = ops.conv_igemm(xd, cin, wd, cout, **kw)
+    finally:
+        lib.ccvpe_set_pwn_kernels(prev)
+    close(got, ref.cpu(), 2e-6, "streaming kernel vs generic kernel")
+    d = dict(kw)
+    d.pop("gate")
+    assert ops.conv_igemm(dev(nhwc(synth.normal((4, 240, 64, 64), 1))), 240, dev(_pack_conv(synth.normal((40, 240, 1, 1), 2))), 40, route_only=True,
+                          batch=4, in_h=64, in_w=64, scale=dev(synth.uniform((40,), 3, 0.5, 1.5)), shift=dev(synth.normal((40,), 4, 0.1)))[0] == "igemm"
+
+
 # ------------------------------------------------------------------------------------------
 # descriptors / matching / heads
 # ------------------------------------------------------------------------------------------

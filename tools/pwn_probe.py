@@ -9,8 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ccvpe_amd import ops, _lib       # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+F32 = len(sys.argv) > 2 and sys.argv[2] == "fp32"
 lib = _lib.load()
-BF = torch.bfloat16
+BF = torch.float32 if F32 else torch.bfloat16
 # (block, cin, cout, h, w, residual)
 layers = [(0, 32, 16, 256, 256, 0), (1, 96, 24, 128, 128, 0), (2, 144, 24, 128, 128, 1), (3, 144, 40, 64, 64, 0), (4, 240, 40, 64, 64, 1),
           (0, 32, 16, 160, 320, 0), (1, 96, 24, 80, 160, 0), (2, 144, 24, 80, 160, 1), (3, 144, 40, 40, 80, 0), (4, 240, 40, 40, 80, 1)]
@@ -32,7 +33,8 @@ def timed(fn):
 tot = [0.0, 0.0]
 for (blk, cin, cout, h, w, res) in layers:
     x = torch.randn((b, h, w, cin), device="cuda").to(BF)
-    kp = (cin + 31) // 32 * 32
+    km = 16 if F32 else 32
+    kp = (cin + km - 1) // km * km
     wt = torch.zeros((16 * ((cout + 15) // 16), kp), device="cuda")
     wt[:cout, :cin] = torch.randn((cout, cin), device="cuda") * cin ** -0.5
     wt = wt.to(BF)
@@ -44,7 +46,7 @@ for (blk, cin, cout, h, w, res) in layers:
     t0 = timed(fn)
     lib.ccvpe_set_pwn_kernels(1)
     t1 = timed(fn)
-    nbytes = 2.0 * b * h * w * (cin + cout * (2 if res else 1))
+    nbytes = (4.0 if F32 else 2.0) * b * h * w * (cin + cout * (2 if res else 1))
     tot[0] += t0
     tot[1] += t1
     print("block %d %3d -> %2d %3dx%-3d %s  generic %6.1f us (%4.2f TB/s)   streaming %6.1f us (%4.2f TB/s)" % (
