@@ -395,7 +395,7 @@ __global__ __launch_bounds__(256) void match_kernel(const TX* __restrict__ x, in
 // Streaming form for the NARROW levels (C <= 80: the 128 x 128 and 256 x 256 levels, where almost all of the matching's bytes are),
 // 9 <= N_rot <= 32, no tail scores.  The tiled kernel above runs three phases per workgroup in series (tile in -> product -> rows
 // out) and reaches 3.1-3.6 TB/s there; with C this small a pixel's whole channel vector fits a few registers, so — as in
-// csrc/pwn_bf16.hip — every WAVE streams its own contiguous run of 16-pixel tiles with no LDS and no barrier: x pieces come from
+// csrc/pwn.hip — every WAVE streams its own contiguous run of 16-pixel tiles with no LDS and no barrier: x pieces come from
 // global memory straight in MFMA B layout (lane = pixel l & 15, channels 16 blk + 4 (l >> 4) .. + 3), PF tiles ahead; the circulant A
 // fragments of the current sample's ground descriptor (and the 0/1 window table for partial windows) are built in registers from g
 // itself (any offset parity) and rebuilt when the run reaches the next sample; |x|^2 by two cross-lane adds; scores / max as in the

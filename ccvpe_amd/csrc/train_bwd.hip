@@ -659,6 +659,103 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float* __restrict__
   }
 }
 
+// Depthwise weight gradient  dW[ky][kx][c] = sum_{b,oy,ox} dy[b,oy,ox,c] * x[b, oy*S-PB+ky, ox*S-PB+kx, c]
+// (efficientnet_pytorch/model.py:69-75's _depthwise_conv under autograd) for the LATE blocks (planes of <= 1 024 pixels, 480-1 152
+// channels; round 6): a WAVE owns one kernel row ky, a lane four channels, so a thread carries K accumulators instead of K*K
+// (dw_wgrad_kernel above sits at 216 VGPRs = 2 waves per SIMD for K = 5, and on these planes a workgroup has a handful of strips
+// per thread: every strip a full load latency with little else resident; tools/dww_probe.py, B = 64, us: 32 x 32 k3 133 -> 94,
+// k5 275 -> 150 (480 ch) / 277 -> 221 (672 ch), 16 x 16 k5 158 -> 83, k3 125 -> 58.  On the large planes of blocks 0-4 it is
+// SLOWER than dw_wgrad_kernel — 404 -> 559 us at 144 ch x 128 x 128: its channel chunks cut a pixel's channel run into pieces
+// that are not cache-line multiples — so those keep the all-taps kernel).  Per strip of CW
+// output columns a thread issues CW dy loads + (CW-1)*S+K x loads together — branch-free buffer loads, out-of-image taps
+// steered to an out-of-range offset that returns zeros — and does K*CW multiply-adds.  Workgroup = K x NW waves on `rows`
+// output rows of one sample and one chunk of <= 64 channel groups (blockIdx.z: the channel split costs no extra partial
+// rows, unlike a finer row split); one LDS merge per workgroup, fixed order (deterministic).
+static inline int dww_rows_late(int Ho) { return 4; }
+
+// channel groups per chunk: the split of cg4 into n equal chunks of <= 64 that fills a wave best (lanes = cgx * (64 / cgx))
+static inline int dww_chunk(int cg4) {
+  int best = cg4 < 64 ? cg4 : 64;
+  double bu = 0.0;
+  for (int n = 1; n <= 16; ++n) {
+    const int cgx = (cg4 + n - 1) / n;
+    if (cgx > 64) continue;
+    const double u = (double)cg4 / (n * cgx) * (double)(cgx * (64 / cgx)) / 64.0;
+    if (u > bu + 1e-9) { bu = u; best = cgx; }
+    if (cgx == 1) break;
+  }
+  return best;
+}
+
+template <int K, int S, int NW>
+__global__ __launch_bounds__(K * NW * 64) void dw_wgrad_rows_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ part, int H, int W, int C, int Ho, int Wo,
+                                                                int circular, int nblk, int rows, int cgx) {
+  constexpr int PB = (S == 1) ? (K - 1) / 2 : (K - 2) / 2;
+  constexpr int CW = 4;
+  constexpr int XW = (CW - 1) * S + K;
+  extern __shared__ __attribute__((aligned(16))) float red[];   // [K][K][NW * Pw][cgx] float4
+  const int b = blockIdx.y;
+  const int cg4 = C >> 2;
+  const int Pw = 64 / cgx;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ky = wave / NW, slot = wave - ky * NW;
+  const int cgl = lane % cgx, pl = lane / cgx;
+  const int cg = blockIdx.z * cgx + cgl;
+  const bool live = pl < Pw && cg < cg4;
+  const int oy0 = blockIdx.x * rows;
+  const int nrow = min(rows, Ho - oy0);
+  const int nstrip = (Wo + CW - 1) / CW;
+  const unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)b * H * W * C), 0, H * W * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy + (size_t)b * Ho * Wo * C), 0, Ho * Wo * C * 4, 0x00020000);
+  f32x4 acc[K];
+#pragma unroll
+  for (int t = 0; t < K; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    for (int o = slot * Pw + pl; o < nrow * nstrip; o += NW * Pw) {
+      const int r = o / nstrip, ox0 = (o - r * nstrip) * CW;
+      const int oy = oy0 + r;
+      const int iy = oy * S - PB + ky;
+      const bool rowok = (unsigned)iy < (unsigned)H;
+      f32x4 g[CW], xw[XW];
+#pragma unroll
+      for (int j = 0; j < CW; ++j) {
+        const unsigned off = (ox0 + j < Wo && rowok) ? (unsigned)(((oy * Wo + ox0 + j) * C + cg * 4) * 4) : OOB;
+        g[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+      }
+#pragma unroll
+      for (int t = 0; t < XW; ++t) {
+        int ix = ox0 * S - PB + t;
+        if (circular) ix = ix < 0 ? ix + W : (ix >= W ? ix - W : ix);
+        const unsigned off = ((unsigned)ix < (unsigned)W && rowok) ? (unsigned)(((iy * W + ix) * C + cg * 4) * 4) : OOB;
+        xw[t] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+      }
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx)
+#pragma unroll
+        for (int j = 0; j < CW; ++j) acc[kx] += g[j] * xw[j * S + kx];
+    }
+  }
+  f32x4* red4 = reinterpret_cast<f32x4*>(red);
+  const int Q = NW * Pw;
+  if (pl < Pw) {
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) red4[((ky * K + kx) * Q + slot * Pw + pl) * cgx + cgl] = acc[kx];
+  }
+  __syncthreads();
+  float* out = part + ((size_t)b * nblk + blockIdx.x) * K * K * C;
+  for (int i = tid; i < K * K * cgx; i += K * NW * 64) {
+    const int tap = i / cgx, cl = i - tap * cgx;
+    const int cgo = blockIdx.z * cgx + cl;
+    if (cgo < cg4) {
+      f32x4 sacc = red4[(tap * Q) * cgx + cl];
+      for (int q = 1; q < Q; ++q) sacc += red4[(tap * Q + q) * cgx + cl];
+      *reinterpret_cast<f32x4*>(out + (size_t)tap * C + cgo * 4) = sacc;
+    }
+  }
+}
+
 }  // namespace ccvpe
 
 static void dw_out_dims(int H, int W, int k, int stride, int* Ho, int* Wo) {
@@ -685,10 +782,13 @@ extern "C" int ccvpe_dwconv_dgrad_f32(const float* dy, const float* w, float* dx
   return check_launch("dw_dgrad_kernel");
 }
 
+// planes of <= 1 024 pixels (blocks 5-15 at 512 x 512 / 320 x 640 images): the row-per-wave kernel
+static inline bool dww_late(int in_h, int in_w) { return (long)in_h * in_w <= 1024; }
+
 extern "C" int ccvpe_dwconv_wgrad_nblk(int in_h, int in_w, int k, int stride) {
   int Ho, Wo;
   dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
-  const int rows = dww_rows(Ho);
+  const int rows = dww_late(in_h, in_w) ? dww_rows_late(Ho) : dww_rows(Ho);
   return (Ho + rows - 1) / rows;
 }
 
@@ -698,18 +798,33 @@ extern "C" int ccvpe_dwconv_wgrad_f32(const float* x, const float* dy, float* dw
   if (!((k == 3 || k == 5) && (stride == 1 || stride == 2))) return fail(CCVPE_EINVAL, "dw_wgrad: k in {3,5}, stride in {1,2}");
   int Ho, Wo;
   dw_out_dims(in_h, in_w, k, stride, &Ho, &Wo);
-  const int rows = dww_rows(Ho);
+  const bool late = dww_late(in_h, in_w);
+  const int rows = late ? dww_rows_late(Ho) : dww_rows(Ho);
   const int nblk = (Ho + rows - 1) / rows;
-  const int cg4 = channels / 4, cgx = cg4 < 64 ? cg4 : 64, P = 256 / cgx;
-  dim3 grid(nblk, batch);
+  const int cg4 = channels / 4;
   hipStream_t st = (hipStream_t)stream;
-  const size_t lds = (size_t)k * P * cgx * 16;
+  if (late) {
+    const int cgx = dww_chunk(cg4), nchunk = (cg4 + cgx - 1) / cgx;
+    dim3 grid(nblk, batch, nchunk);
+#define WGR(K_, S_, NW_)                                                                                                           \
+  hipLaunchKernelGGL((dw_wgrad_rows_kernel<K_, S_, NW_>), grid, dim3(K_ * NW_ * 64), (size_t)K_ * K_ * NW_ * (64 / cgx) * cgx * 16, st, x, \
+                     dy, scratch, in_h, in_w, channels, Ho, Wo, circular, nblk, rows, cgx)
+    if (k == 3 && stride == 1) WGR(3, 1, 4);
+    else if (k == 3) WGR(3, 2, 4);
+    else if (stride == 1) WGR(5, 1, 2);
+    else WGR(5, 2, 2);
+#undef WGR
+  } else {
+    const int cgx = cg4 < 64 ? cg4 : 64, P = 256 / cgx;
+    dim3 grid(nblk, batch);
+    const size_t lds = (size_t)k * P * cgx * 16;
 #define WG(K_, S_) hipLaunchKernelGGL((dw_wgrad_kernel<K_, S_>), grid, dim3(256), lds, st, x, dy, scratch, in_h, in_w, channels, Ho, Wo, circular, nblk, rows)
-  if (k == 3 && stride == 1) WG(3, 1);
-  else if (k == 3) WG(3, 2);
-  else if (stride == 1) WG(5, 1);
-  else WG(5, 2);
+    if (k == 3 && stride == 1) WG(3, 1);
+    else if (k == 3) WG(3, 2);
+    else if (stride == 1) WG(5, 1);
+    else WG(5, 2);
 #undef WG
+  }
   const int n = k * k * channels;
   launch_sum_parts(scratch, nblk * batch, n, n, dw, st);
   return check_launch("dw_wgrad_kernel");

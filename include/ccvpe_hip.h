@@ -102,7 +102,7 @@ int ccvpe_conv_igemm_splitk_floats(const ccvpe_conv_desc* desc, int is_bf16);
 #define CCVPE_ROUTE_CONV3X3 2 /* LDS-halo 3x3 kernel */
 #define CCVPE_ROUTE_C3N 3     /* bf16 narrow 3x3 kernel: weights in registers, persistent workgroups (csrc/narrow_impl.h) */
 #define CCVPE_ROUTE_PW_RING 4 /* pointwise kernel with a three-stage LDS-DMA ring, two workgroups per CU, fp32 and bf16 (csrc/conv_pw2_impl.h) */
-#define CCVPE_ROUTE_PWN 5     /* (ABI 7) bf16 narrow projection kernel: N <= 48, K <= 256, weights x SE gate in registers, waves stream 16-pixel tiles (csrc/pwn_bf16.hip); the route's MT / NT fields hold N / 16 and K / 32 */
+#define CCVPE_ROUTE_PWN 5     /* (ABI 7) narrow projection kernel: N <= 48, K <= 256 (fp32: <= 144), weights x SE gate in registers, waves stream 16-pixel tiles (csrc/pwn.hip); the route's MT / NT fields hold N / 16 and K bytes / 64 */
 int ccvpe_conv_igemm_route(const ccvpe_conv_desc* desc, int is_bf16, int out_f32);
 /* A/B switch for measurements (process-wide, default on): 0 sends the narrow bf16 decoder layers (CCVPE_ROUTE_C3N, and the
  * narrow form of ccvpe_upconv3x3_bf16) back to the tiled kernels.  Returns the previous setting. */

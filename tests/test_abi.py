@@ -185,6 +185,7 @@ def test_planning_entry_points_without_a_gpu():
     assert lib.ccvpe_bn_stats_nblk(256) == 8                               # small tensors: 32-row workgroups
     assert 4096 <= lib.ccvpe_bn_stats_nblk(64 * 512 * 512) <= 4096 + 64 + 1
     assert lib.ccvpe_dwconv_wgrad_nblk(64, 64, 3, 1) == 64 and lib.ccvpe_dwconv_wgrad_nblk(256, 256, 3, 2) == 64
+    assert lib.ccvpe_dwconv_wgrad_nblk(16, 16, 5, 1) == 4 and lib.ccvpe_dwconv_wgrad_nblk(32, 32, 5, 2) == 4      # planes <= 1 024 px: dw_wgrad_rows_kernel
     assert lib.ccvpe_conv_wgrad_scratch_floats(2, 16, 16, 3, 3, 1, 1, 1344, 640) > 0
     assert lib.ccvpe_adam_chunk_elems() == 4096 and lib.ccvpe_train_targets_nblk(512, 512) == 256
 

@@ -134,7 +134,9 @@ def test_bn_act_bwd_vs_autograd(bw, c, h, w, act, with_se, with_dcs):
 
 @pytest.mark.parametrize("c,k,stride,h,w,circ", [(32, 3, 1, 12, 16, True), (96, 3, 2, 16, 20, True),
                                                  (144, 5, 2, 10, 14, False), (240, 5, 1, 7, 9, True),
-                                                 (1152, 3, 1, 4, 4, False), (672, 5, 2, 8, 8, True)])
+                                                 (1152, 3, 1, 4, 4, False), (672, 5, 2, 8, 8, True),
+                                                 # planes above 1 024 pixels: the all-taps weight-gradient kernel (the rows above run dw_wgrad_rows_kernel)
+                                                 (32, 3, 1, 40, 48, True), (96, 3, 2, 34, 38, True), (144, 5, 2, 36, 40, False), (240, 5, 1, 33, 36, True)])
 def test_dwconv_backward_vs_autograd(bw, c, k, stride, h, w, circ):
     from oracle import ccvpe_oracle as orc
     b = 3

@@ -121,7 +121,7 @@ def test_mbconv_plane_late_blocks_bf16(ops, k, s, cin, h, w, circ):
                                                      (144, 40, 16, 64, False), (240, 40, 17, 64, True), (96, 24, 3, 160, False)])
 def test_narrow_projection_kernel(ops, cin, cout, b, hw, with_res):
     """The MBConv projections of the early blocks (efficientnet_pytorch/model.py:118-131: SE gate on the input, 1x1 conv, BN, skip)
-    on the streaming kernel with the weights x gate in registers (csrc/pwn_bf16.hip, route CCVPE_ROUTE_PWN) behind the unchanged
+    on the streaming kernel with the weights x gate in registers (csrc/pwn.hip, route CCVPE_ROUTE_PWN) behind the unchanged
     ccvpe_conv_igemm_bf16: against the fp32 oracle on bf16-rounded inputs, and against the generic kernel (switch off).  A wave's run
     of tiles crosses sample boundaries (B = 17: per-sample gates are re-folded), the last tile is ragged (160 x 160 x 3 pixels)."""
     from ccvpe_amd import _lib

@@ -1,4 +1,4 @@
-"""Micro-probe of the narrow projection kernel (csrc/pwn_bf16.hip) on the early-block projections of both encoders at B = 64, against
+"""Micro-probe of the narrow projection kernel (csrc/pwn.hip; `python tools/pwn_probe.py [reps] [fp32]`) on the early-block projections of both encoders at B = 64, against
 the generic kernel on the same tensors, interleaved in one process:   python tools/pwn_probe.py [reps]"""
 import os
 import sys
