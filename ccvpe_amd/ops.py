@@ -105,10 +105,15 @@ def upconv_route_name(desc, is_bf16):
     return "%s<%s,%d,%d,%d%s>" % (k, ty, mt, nt, wn, ",pair" if pair else "")
 
 
-def conv_route_name(desc, is_bf16, out_f32=False, f32_names=False):
+def conv_route_name(desc, is_bf16, out_f32=False):
+    """Kernel family name of the launch the library would make for this descriptor, as the launch recorder and
+    profiles/pmc_traffic.json spell it: `<family>_f32_kernel<MT,NT,WN>` in fp32, `<family>_kernel<bf16,MT,NT,WN>` in bf16
+    (the narrow 3x3 kernel c3n exists in bf16 only and is named by its column count)."""
     fam, mt, nt, wn = conv_route(desc, is_bf16, out_f32)
     if fam == "c3n":
-        return "c3n_f32_kernel<%d>" % desc.n
+        return "c3n_kernel<bf16,%d>" % desc.n
+    if is_bf16:
+        return "%s_kernel<bf16,%d,%d,%d>" % (fam, mt, nt, wn)
     return "%s_f32_kernel<%d,%d,%d>" % (fam, mt, nt, wn)
 
 
@@ -215,8 +220,8 @@ def conv_igemm(src0, c0, w_packed, n, *, batch, in_h, in_w, kh=1, kw=1, stride=1
         if want > 0:      # split-K: always the generic gather kernel with the tile pick_cfg() chose
             name = igemm_tile(n, False)
         else:             # ask the library which kernel it ran (no Python mirror of the dispatch rules)
-            name = conv_route_name(d, dt != torch.float32, bool(out_f32), f32_names=True)
-        if dt != torch.float32:
+            name = conv_route_name(d, dt != torch.float32, bool(out_f32))
+        if want > 0 and dt != torch.float32:
             name = name.replace("_f32_kernel<", "_kernel<bf16,")
         rec.end(name, "%dx%d s%d M%d N%d K%d" % (kh, kw, stride, m, n, k_alg), flops, nbytes, ev0)
     return dst
