@@ -89,12 +89,13 @@ def test_optimizer_step_changes_outputs_and_is_deterministic(synth_sd):
     assert (post2 - post1).abs().max().item() < 1e-3 * scale          # and equals torch.optim.Adam's step
 
 
-@pytest.mark.parametrize("kind,ori_noise,circular,grd_key", [("kitti", None, False, "kitti"), ("vigor", 36, True, "vigor"),
-                                                             ("oxford", None, False, "oxford"),
+@pytest.mark.parametrize("kind,ori_noise,circular,grd_key", [("vigor", 36, True, "vigor"), ("oxford", None, False, "oxford"),
                                                              ("vigor", None, False, "vigor_fov180")])
 def test_full_backward_other_models_vs_oracle_autograd(synth_sd, kind, ori_noise, circular, grd_key):
-    """CVM_KITTI and CVM_VIGOR_ori_prior (5 localisation shifts + the recomputed 20-shift level-6 volume): no reference
-    golden is stored for these, so the gradients are compared with autograd through the oracle on the CPU."""
+    """CVM_VIGOR_ori_prior (5 localisation shifts + the recomputed 20-shift level-6 volume), CVM_OxfordRobotCar and the FoV-180
+    configuration: no reference golden is stored for these, so the gradients are compared with autograd through the oracle on the
+    CPU.  (CVM_KITTI has a golden from the reference class itself since round 6: test_full_backward_kitti_vs_reference_autograd —
+    its 49 s live-oracle variant was dropped from this list.)"""
     from ccvpe_amd import models
     from oracle import ccvpe_oracle as O
     sd = synth_sd(kind, 3)

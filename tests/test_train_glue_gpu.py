@@ -36,7 +36,7 @@ def test_train_targets_vs_dataset_restatement(n_bins, angles):
 
 def test_adam_matches_torch_adam():
     from ccvpe_amd import optim
-    shapes = [(640, 1344, 3, 3), (17,), (1, 10, 1, 1), (4099,), (96, 1, 5, 5)]
+    shapes = [(160, 336, 3, 3), (17,), (1, 10, 1, 1), (4099,), (96, 1, 5, 5)]      # 118 chunks of 4 096 elements in the first one
     ref_p = [torch.nn.Parameter(synth.normal(s, 2000 + i, 0.1)) for i, s in enumerate(shapes)]
     our_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
     ref = torch.optim.Adam(ref_p, lr=1e-4, betas=(0.9, 0.999))
