@@ -74,6 +74,32 @@ def test_eight_ranks_one_relayed_line(tmp_path):
     assert time.time() - t0 < 240
 
 
+def test_record_glued_to_another_ranks_output_is_cut_out(tmp_path, capfd):
+    """torch.distributed.run may deliver rank 0's record and another rank's text on ONE line (seen on this container: the
+    8-rank test above read `{...}noise from rank 7`): the parent relays the JSON object alone, the rest goes to stderr."""
+    import bench
+    glue = tmp_path / "glue_rank.py"
+    glue.write_text("import json, sys\n"
+                    "sys.stdout.write('prefix ' + json.dumps({'metric': 'stub', 'value': 1.5, 'config': {'a': '{\"x\"}'}}) + 'noise from rank 7\\n')\n")
+    rc = bench.launch_ranks(1, ["--gpus", "1"], script=str(glue), timeout=120)
+    cap = capfd.readouterr()
+    assert rc == 0
+    out = [l for l in cap.out.splitlines() if l.strip()]
+    assert len(out) == 1 and json.loads(out[0]) == {"metric": "stub", "value": 1.5, "config": {"a": '{"x"}'}}
+    assert "noise from rank 7" in cap.err and "prefix" in cap.err
+
+
+def test_a_launcher_that_dies_at_once_without_a_record_is_started_once_more(tmp_path, capfd):
+    import bench
+    marker = tmp_path / "attempts"
+    die = tmp_path / "die_rank.py"
+    die.write_text("import sys\nopen(%r, 'a').write('x')\nsys.exit(5)\n" % str(marker))
+    rc = bench.launch_ranks(1, ["--gpus", "1"], script=str(die), timeout=120)
+    cap = capfd.readouterr()
+    assert rc != 0 and cap.out.strip() == ""
+    assert marker.read_text() == "xx" and "one more attempt" in cap.err
+
+
 def test_timeout_kills_the_whole_rank_group(tmp_path):
     """A hung rank must not outlive the parent's timeout: the launcher runs in its own process group and the group is killed
     (killing torch.distributed.run alone would leave the rank processes holding their GPUs)."""
