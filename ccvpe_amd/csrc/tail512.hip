@@ -60,8 +60,17 @@ struct TailGeom {
   static constexpr int NTILE = (P + 15) / 16;
   static constexpr int TPW = (NTILE + WPP - 1) / WPP; // 16-position tiles per wave
   static constexpr int HR = TY + 2, HC = TX + 2, HPX = HR * HC;
-  static constexpr int LD = 20;                      // floats per staged pixel row (64 B + 16 B pad)
-  static constexpr int XBUF = HPX * LD;              // floats per x chunk buffer
+  // Staged pixel row: 64 bytes of data in a slot of LD floats, HCP slots per halo row.  The stage-1 fragment read is PER-LANE
+  // addressed (position pt -> (pt / (TX+1), pt % (TX+1)): the 16 lanes of a tile usually straddle two halo rows), so the panel
+  // swizzle of the GEMM kernels does not apply; in the bank model (tools/lds_layout.py, searched over pitch x slots per row x
+  // swizzle) the 80-byte slot in rows of TX + 2 costs 7.8 cycles per ds_read_b128 (ideal 4) and ONE geometry is conflict-free:
+  // 96-byte slots in rows of 25 (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS of the bf16-path tails: 1.5-2.1 with the LDS pipe
+  // 35 % busy, tools/gpu/lds_pmc.sh).  It costs 67 % more LDS per chunk buffer, so the latency-shaped 8 x 16 tiles of the bf16
+  // storage path take it (48 KB per workgroup) and the matrix-bound 16 x 16 fp32 tile (which would need 86 KB) keeps the 80-byte slot.
+  static constexpr bool WIDE_SLOT = TY == 8 && TX == 16 && (SPLIT || sizeof(T) == 2);
+  static constexpr int LD = WIDE_SLOT ? 24 : 20;     // floats per staged pixel slot
+  static constexpr int HCP = WIDE_SLOT ? 25 : HC;    // slots per halo row
+  static constexpr int XBUF = HR * HCP * LD;         // floats per x chunk buffer
   static constexpr int NXB = NCH > 1 ? 2 : 1;
   static constexpr int SH = 2 * TY + 2, SW = 2 * TX + 2, SPL = SH * SW;   // one tap plane of the mid grid
   static constexpr int NPL = 10;                     // 9 tap planes + one junk plane (lanes whose tap index is >= 9 store there)
@@ -86,13 +95,13 @@ __global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams 
   constexpr int E = ElemTraits<T>::E;
   constexpr int SK = 4 * E;                          // channels per 64-byte chunk
   constexpr int NTHR = G::NTHR, PW = G::PW, P = G::P, TPW = G::TPW;
-  constexpr int HC = G::HC, HPX = G::HPX, LD = G::LD, XBUF = G::XBUF;
+  constexpr int HC = G::HC, HCP = G::HCP, HPX = G::HPX, LD = G::LD, XBUF = G::XBUF;
   constexpr int SW = G::SW, SPL = G::SPL;
   constexpr int H_IT = (HPX * 4 + NTHR - 1) / NTHR;
   static_assert((4 * TY * TX) % NTHR == 0, "stage 3 hands every thread the same number of outputs");
 
   extern __shared__ __attribute__((aligned(16))) float t5_sm[];
-  float* Xs = t5_sm;                                 // [NXB][HPX][LD]   (stage 1)
+  float* Xs = t5_sm;                                 // [NXB][HR][HCP][LD]   (stage 1)
   float* Sp = t5_sm;                                 // [9][SH][SW]      (stage 2/3, aliases Xs)
   float* Sh9 = t5_sm + G::MAIN;                      // [9][16]
 
@@ -199,14 +208,15 @@ __global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams 
 #pragma unroll
     for (int it = 0; it < H_IT; ++it) {
       const int pxl = (tidv + NTHR * it) >> 2;
+      const int slot = HCP == HC ? pxl : (pxl / HC) * HCP + (pxl % HC);
       const f32x4 v = keep_if(h_reg[it], (h_keep >> it) & 1u);
       if constexpr (!SPLIT) {
-        if (pxl < HPX) *reinterpret_cast<f32x4*>(Xs + buf * XBUF + pxl * LD + hsub * 4) = v;
+        if (pxl < HPX) *reinterpret_cast<f32x4*>(Xs + buf * XBUF + slot * LD + hsub * 4) = v;
       } else {                                       // row = [hi 0..15 | lo 0..15] bf16: this piece's 4 channels -> 8 + 8 bytes
         bf16x4 hi, lo;
         split4(v, hi, lo);
         if (pxl < HPX) {
-          float* row = Xs + buf * XBUF + pxl * LD;
+          float* row = Xs + buf * XBUF + slot * LD;
           *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(row) + hsub * 4) = hi;
           *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(row) + 16 + hsub * 4) = lo;
         }
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams 
   for (int i = 0; i < TPW; ++i) {
     const int pc = min((wsub * TPW + i) * 16 + pixv, P - 1);
     const int iy = pc / PW, ix = pc - iy * PW;
-    fbase[i] = (iy * HC + ix) * LD + qv * 4;
+    fbase[i] = (iy * HCP + ix) * LD + qv * 4;
   }
   f32x4 acc[TPW];
 #pragma unroll
@@ -250,7 +260,7 @@ __global__ __launch_bounds__(256 * WPP, 2) void tail512_kernel(const TailParams 
     f32x4 fr[2][2];
     auto read_step = [&](int s, f32x4* dst) {
       const int g = s >> 2, tap = s & 3;
-      const int toff = ((tap >> 1) * HC + (tap & 1)) * LD;
+      const int toff = ((tap >> 1) * HCP + (tap & 1)) * LD;
       dst[0] = *reinterpret_cast<const f32x4*>(xb + fbase[2 * g] + toff);
       if (2 * g + 1 < TPW) dst[1] = *reinterpret_cast<const f32x4*>(xb + fbase[2 * g + 1] + toff);
     };
