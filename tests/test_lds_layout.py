@@ -107,3 +107,31 @@ def test_round5_layouts_in_the_source_are_conflict_free():
         wr = lambda lane, first=first: (first + (lane & 15)) * PP + 4 * (lane >> 4)
         assert L.cycles("write_b128", wr) == (8, 8)
     assert L.cycles("write_b128", lambda lane: (lane & 15) * 32 + 4 * (lane >> 4)) == (64, 8)   # (pitch 32: every group on one bank set)
+
+
+def test_tail512_wide_slot_geometry_in_the_source_is_conflict_free():
+    """csrc/tail512.hip stage 1 (round 6): a tile's 16 lanes are 16 CONSECUTIVE positions of a (TY+1) x (TX+1) grid, i.e. they
+    straddle two halo rows, and read their 2 x 2 taps at per-lane addresses.  With the 80-byte slot in rows of TX + 2 that is a 2-way
+    conflict on every read (SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS = 1.5-2.1 measured, profiles/r06/probes_second_half.txt); the
+    geometry the source takes for the bf16-path tiles — read from the source here — has none, for every tile and tap."""
+    src = open(os.path.join(ROOT, "ccvpe_amd", "csrc", "tail512.hip")).read()
+    m = re.search(r"static constexpr int LD = WIDE_SLOT \? (\d+) : (\d+);", src)
+    n = re.search(r"static constexpr int HCP = WIDE_SLOT \? (\d+) : HC;", src)
+    assert m and n, "TailGeom's slot geometry moved: update this test"
+    ld_wide, ld_plain, hcp_wide = int(m.group(1)), int(m.group(2)), int(n.group(1))
+    ty, tx = 8, 16
+    pw, hc, npos = tx + 1, tx + 2, (ty + 1) * (tx + 1)
+
+    def frag(ld, hcp, tile, tap):
+        def addr(lane):
+            pc = min(tile * 16 + lane % 16, npos - 1)
+            iy, ix = pc // pw, pc % pw
+            return ((iy + (tap >> 1)) * hcp + ix + (tap & 1)) * ld + 4 * (lane // 16)
+        return addr
+
+    nfull = npos // 16                                     # the last tile of a parity is ragged (clamped lanes): not asserted
+    wide = [L.cycles("read_b128", frag(ld_wide, hcp_wide, t, tap))[0] for t in range(nfull) for tap in range(4)]
+    plain = [L.cycles("read_b128", frag(ld_plain, hc, t, tap))[0] for t in range(nfull) for tap in range(4)]
+    assert max(wide) == 4, wide                            # conflict-free: 4 LDS cycles per ds_read_b128
+    assert sum(plain) / len(plain) > 7.0                   # the 80-byte slot: ~2-way everywhere (what the counters saw)
+    assert (ty + 2) * hcp_wide * ld_wide * 4 * 2 <= 48 * 1024      # two chunk buffers of the 8 x 16 tile: three workgroups per CU
